@@ -1,0 +1,152 @@
+/* yolact_hip.h — C-ABI of libyolact_hip.so, the MI355X (gfx950) hot path of YOLACT.
+ *
+ * The reference (feiyuhuahuo/Yolact_minimal) has NO native interface for this path: every tensor
+ * op goes through torch.nn / ATen, and its only native file is the Cython greedy NMS
+ * (cython_nms.pyx:24-74).  So the entry points below are what a maintainer would bind *instead of*
+ * the ATen calls at the cited reference lines.  Conventions:
+ *   - extern "C", raw DEVICE pointers + explicit sizes + a hipStream_t (passed as void*);
+ *   - fp32 everywhere, activations NHWC ([B][H][W][C], C contiguous), weights [Cout][KH][KW][Cin];
+ *   - every call is asynchronous on `stream`; nothing allocates, frees or synchronises;
+ *   - scratch memory is supplied by the caller (ask ym_*_workspace_bytes first);
+ *   - return 0 on success, a negative YM_E* code otherwise; ym_last_error() gives the text.
+ * No torch types appear here.  The Python host (yolact_minimal_amd/hip.py) binds these with ctypes.
+ */
+#ifndef YOLACT_HIP_H
+#define YOLACT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YM_OK 0
+#define YM_EINVAL (-1)   /* bad argument (shape, alignment, null pointer) */
+#define YM_ENOSPC (-2)   /* workspace too small */
+#define YM_ELAUNCH (-3)  /* hipGetLastError() after a launch was not hipSuccess */
+
+#define YM_ACT_NONE 0
+#define YM_ACT_RELU 1
+#define YM_ACT_TANH 2
+
+typedef void* ym_stream_t; /* hipStream_t */
+
+int ym_abi_version(void);
+const char* ym_last_error(void);
+
+/* ---- layout / parameter preparation ----------------------------------------------------------- */
+
+/* NCHW fp32 image -> NHWC with C padded to 4 (pad lanes = 0).  Replaces the implicit layout of
+ * `self.backbone(img)` input, reference modules/yolact.py:142. in:[B][C][H][W] (C<=4) out:[B][H][W][4] */
+int ym_nchw_to_nhwc4(const float* in, float* out, int B, int C, int H, int W, ym_stream_t s);
+
+/* OIHW fp32 weight (torch state-dict layout) -> [Cout][KH][KW][cin_pad] with zero padding of the
+ * channel dim, rows zero-extended to k_pad floats (k_pad >= KH*KW*cin_pad, multiple of 32). */
+int ym_pack_conv_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW,
+                        int cin_pad, int k_pad, ym_stream_t s);
+
+/* Eval-mode BatchNorm folded to y = x*scale + shift (reference modules/resnet.py:24,28,32 in eval):
+ * scale = gamma / sqrt(var + eps), shift = beta - mean*scale. */
+int ym_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+               float* scale, float* shift, int C, ym_stream_t s);
+
+/* ---- fused convolution (implicit GEMM on the f32 MFMA pipe) ------------------------------------- */
+
+typedef struct {
+    int n_begin, n_end;      /* output-channel range [n_begin, n_end) routed to this segment      */
+    float* out;              /* element (b, pixel, n) lives at out[b*batch_stride + pixel*pitch + (n-n_begin)] */
+    int64_t batch_stride;    /* floats */
+    int32_t pitch;           /* floats between consecutive output pixels */
+    int32_t act;             /* YM_ACT_* applied to this segment */
+} ym_conv_seg;
+
+typedef struct {
+    const float* in;         /* NHWC [B][H][W][Cin]; for Cin==4 ("stem" mode) the packed weight uses cin_pad=4 */
+    const float* weight;     /* packed by ym_pack_conv_weight: [Cout][k_pad] */
+    const float* scale;      /* [Cout] or NULL (=1) : folded BN scale */
+    const float* shift;      /* [Cout] or NULL (=0) : folded BN shift or conv bias */
+    const float* residual;   /* NULL or NHWC [B][Ho][Wo][Cout] added before the activation */
+    int32_t B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, k_pad;
+    int32_t nseg;            /* 1..3 */
+    ym_conv_seg seg[3];
+    int32_t tile_m, tile_n;  /* 0 = library heuristic; else one of 128/64 (tuning knob) */
+    int32_t ksplit;          /* 0 = heuristic; >=1 = number of K slices (slices>1 need workspace) */
+} ym_conv_desc;
+
+/* y = act(conv(x, w) * scale + shift + residual), one launch (plus a reduce launch if K is split).
+ * Replaces: conv+BN+ReLU(+add) of Bottleneck.forward (modules/resnet.py:20-40), the stem
+ * (modules/resnet.py:88-90), conv+bias+ReLU of FPN / ProtoNet (modules/yolact.py:62-68,37-47) and,
+ * with three segments, the bbox/conf/coef convs + tanh + permute/reshape/cat of
+ * PredictionModule.forward + Yolact.forward (modules/yolact.py:27-30,155-157). */
+size_t ym_conv2d_workspace_bytes(const ym_conv_desc* d);
+int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t workspace_bytes, ym_stream_t s);
+
+/* ---- small NHWC ops ------------------------------------------------------------------------------ */
+
+/* MaxPool2d(3, stride 2, pad 1), reference modules/resnet.py:91. C % 4 == 0. */
+int ym_maxpool3x3s2_fwd(const float* in, float* out, int B, int H, int W, int C, ym_stream_t s);
+
+/* Bilinear x2 upsample, align_corners 0 (FPN, modules/yolact.py:70-71) or 1 (ProtoNet, :43). C % 4 == 0. */
+int ym_bilinear2x_fwd(const float* in, float* out, int B, int H, int W, int C, int align_corners, ym_stream_t s);
+
+/* softmax over the last dim of [rows][C] (F.softmax(class_pred, -1), modules/yolact.py:163). in may equal out. */
+int ym_softmax_rows(const float* in, float* out, int64_t rows, int C, ym_stream_t s);
+
+/* ---- detection post-processing (utils/output_utils.py) ---------------------------------------------- */
+
+typedef struct {
+    int32_t num_anchors;     /* N */
+    int32_t num_classes;     /* C including background (81) */
+    int32_t coef_dim;        /* 32 */
+    int32_t top_k;           /* cfg.top_k = 200 (<= 256) */
+    int32_t max_det;         /* cfg.max_detections = 100 (<= 128) */
+    float score_thre;        /* cfg.nms_score_thre = 0.05 */
+    float iou_thre;          /* cfg.nms_iou_thre = 0.5 */
+    float img_size;          /* cfg.img_size, used by the greedy ("traditional") path only */
+} ym_nms_cfg;
+
+size_t ym_nms_workspace_bytes(const ym_nms_cfg* cfg);
+
+/* `nms()` with fast_nms (utils/output_utils.py:126-163 + :11-43 + box_iou utils/box_utils.py:8-37)
+ * for ONE image.  Inputs: class_pred [N][C] (softmaxed), box_pred [N][4], coef_pred [N][coef_dim],
+ * anchors [N][4] (cx,cy,w,h).  Outputs (device): out_count int32[1] (n <= max_det; 0 means the
+ * reference returns five Nones), out_ids int64[max_det], out_scores f32[max_det],
+ * out_boxes f32[max_det][4] (x1,y1,x2,y2 in 0..1), out_coefs f32[max_det][coef_dim]. */
+int ym_detect_fast_nms(const float* class_pred, const float* box_pred, const float* coef_pred,
+                       const float* anchors, const ym_nms_cfg* cfg, int32_t* out_count, int64_t* out_ids,
+                       float* out_scores, float* out_boxes, float* out_coefs, void* workspace,
+                       size_t workspace_bytes, ym_stream_t s);
+
+/* Same contract, greedy per-class NMS: replaces traditional_nms (utils/output_utils.py:84-123) and the
+ * Cython kernel it calls (cython_nms.pyx:24-74) without the 80 D2H/H2D round trips. */
+int ym_detect_greedy_nms(const float* class_pred, const float* box_pred, const float* coef_pred,
+                         const float* anchors, const ym_nms_cfg* cfg, int32_t* out_count, int64_t* out_ids,
+                         float* out_scores, float* out_boxes, float* out_coefs, void* workspace,
+                         size_t workspace_bytes, ym_stream_t s);
+
+/* Drop-in for `cython_nms.nms(dets, thresh)` (cython_nms.pyx:24) on device data: dets [n][5]
+ * (x1,y1,x2,y2,score), "+1" areas, suppress ovr >= thresh; keep_mask uint8[n] (1 = kept), in original
+ * index order like np.where(suppressed == 0).  workspace >= ym_greedy_nms_workspace_bytes(n). */
+size_t ym_greedy_nms_workspace_bytes(int n);
+int ym_greedy_nms(const float* dets, int n, float thresh, uint8_t* keep_mask, int32_t* out_count,
+                  void* workspace, size_t workspace_bytes, ym_stream_t s);
+
+/* Mask assembly: sigmoid(proto[Hp*Wp][K] @ coef[n][K]^T) cropped to the box window (padding 1) ->
+ * out [n][Hp][Wp].  Replaces utils/output_utils.py:217-222 (+ crop, utils/box_utils.py:147-168) and
+ * the same product in lincomb_mask_loss (modules/yolact.py:275-276).  K must be 32. do_crop=0 skips crop. */
+int ym_mask_assemble(const float* proto, const float* coefs, const float* boxes, int n, int Hp, int Wp,
+                     int K, int do_crop, float* out, ym_stream_t s);
+
+/* F.interpolate(masks, (S,S), bilinear, align_corners=False) -> gt(0.5) -> slice to [n][img_h][img_w]
+ * (utils/output_utils.py:224-228), S = max(img_h, img_w).  out values are exactly 0.0f / 1.0f. */
+int ym_mask_resize_binarize(const float* masks, int n, int Hp, int Wp, int img_h, int img_w, float* out,
+                            ym_stream_t s);
+
+/* box_p *= S; box_p.int()  (utils/output_utils.py:230-231): boxes_f is scaled IN PLACE like the reference. */
+int ym_boxes_to_pixels(float* boxes_f, int32_t* boxes_px, int n, float S, ym_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLACT_HIP_H */

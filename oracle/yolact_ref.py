@@ -1,0 +1,334 @@
+"""CPU ORACLE — TEST INFRASTRUCTURE ONLY.  Never imported by the product path.
+
+A plain PyTorch-CPU fp32 restatement of the reference hot path (feiyuhuahuo/Yolact_minimal), written
+functionally over a state-dict so that it does not depend on either the reference's or the
+product's module classes.  Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline`
+leg may import this file, and only as the checker / reported baseline.
+
+Pinned by: `oracle/make_golden.py` imports the real reference from /root/reference in the build
+container, runs it and this restatement on identical seeded inputs, asserts equality and writes the
+vectors under `tests/golden/` (the reference itself has no tests or golden vectors — SURVEY.md §4).
+The arithmetic that is not in the reference's own files (conv / batch-norm / softmax / sort /
+interpolate) is PyTorch's CPU implementation (un-pinned by the reference: "PyTorch >= 1.1"); the
+goldens are therefore tied to torch 2.10.0 CPU kernels.
+
+Each function cites the reference lines it restates (paths relative to /root/reference).
+"""
+import ctypes
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+# ------------------------------------------------------------------------------------------------
+# network forward (eval mode)
+# ------------------------------------------------------------------------------------------------
+def _conv(x, sd, name, stride=1, padding=0):
+    return F.conv2d(x, sd[name + '.weight'], sd.get(name + '.bias'), stride=stride, padding=padding)
+
+
+def _bn(x, sd, name):
+    # eval-mode BatchNorm2d, eps 1e-5 (torch default, modules/resnet.py:8-14)
+    return F.batch_norm(x, sd[name + '.running_mean'], sd[name + '.running_var'],
+                        sd[name + '.weight'], sd[name + '.bias'], False, 0.0, 1e-5)
+
+
+def bottleneck(x, sd, p, stride):
+    """modules/resnet.py:20-40 — stride on the 3x3, residual add then ReLU."""
+    y = F.relu(_bn(_conv(x, sd, p + '.conv1'), sd, p + '.bn1'))
+    y = F.relu(_bn(_conv(y, sd, p + '.conv2', stride=stride, padding=1), sd, p + '.bn2'))
+    y = _bn(_conv(y, sd, p + '.conv3'), sd, p + '.bn3')
+    if (p + '.downsample.0.weight') in sd:
+        x = _bn(_conv(x, sd, p + '.downsample.0', stride=stride), sd, p + '.downsample.1')
+    return F.relu(y + x)
+
+
+def resnet(x, sd, layers, p='backbone'):
+    """modules/resnet.py:86-98 — stem 7x7/2 + BN + ReLU + maxpool 3x3/2, then 4 stages."""
+    x = F.relu(_bn(_conv(x, sd, p + '.conv1', stride=2, padding=3), sd, p + '.bn1'))
+    x = F.max_pool2d(x, 3, 2, 1)
+    outs = []
+    for li, nblk in enumerate(layers):
+        for bi in range(nblk):
+            x = bottleneck(x, sd, f'{p}.layers.{li}.{bi}', 2 if (bi == 0 and li > 0) else 1)
+        outs.append(x)
+    return outs
+
+
+def fpn(c3, c4, c5, sd, p='fpn'):
+    """modules/yolact.py:73-89 — note P6 is computed from P5 *after* its pred conv."""
+    def up(t):
+        return F.interpolate(t, scale_factor=2, mode='bilinear', align_corners=False)
+    p5_1 = _conv(c5, sd, p + '.lat_layers.2')
+    p4_1 = _conv(c4, sd, p + '.lat_layers.1') + up(p5_1)
+    p3_1 = _conv(c3, sd, p + '.lat_layers.0') + up(p4_1)
+    p5 = F.relu(_conv(p5_1, sd, p + '.pred_layers.2.0', padding=1))
+    p4 = F.relu(_conv(p4_1, sd, p + '.pred_layers.1.0', padding=1))
+    p3 = F.relu(_conv(p3_1, sd, p + '.pred_layers.0.0', padding=1))
+    p6 = F.relu(_conv(p5, sd, p + '.downsample_layers.0.0', stride=2, padding=1))
+    p7 = F.relu(_conv(p6, sd, p + '.downsample_layers.1.0', stride=2, padding=1))
+    return [p3, p4, p5, p6, p7]
+
+
+def protonet(p3, sd, p='proto_net'):
+    """modules/yolact.py:49-53 — the only align_corners=True upsample in the net."""
+    x = p3
+    for i in (0, 2, 4):
+        x = F.relu(_conv(x, sd, f'{p}.proto1.{i}', padding=1))
+    x = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True)
+    x = F.relu(_conv(x, sd, p + '.proto2.0', padding=1))
+    x = F.relu(_conv(x, sd, p + '.proto2.2'))
+    return x
+
+
+def head(x, sd, num_classes, coef_dim=32, p='prediction_layers'):
+    """modules/yolact.py:26-31 — anchor index = (y*W + x)*3 + a."""
+    b = x.shape[0]
+    x = F.relu(_conv(x, sd, p + '.upfeature.0', padding=1))
+    conf = _conv(x, sd, p + '.conf_layer', padding=1).permute(0, 2, 3, 1).reshape(b, -1, num_classes)
+    box = _conv(x, sd, p + '.bbox_layer', padding=1).permute(0, 2, 3, 1).reshape(b, -1, 4)
+    coef = torch.tanh(_conv(x, sd, p + '.coef_layer.0', padding=1)).permute(0, 2, 3, 1).reshape(b, -1, coef_dim)
+    return conf, box, coef
+
+
+def resnet_layers_from_sd(sd):
+    n = [0, 0, 0, 0]
+    for k in sd:
+        if k.startswith('backbone.layers.') and k.endswith('.conv1.weight'):
+            li, bi = int(k.split('.')[2]), int(k.split('.')[3])
+            n[li] = max(n[li], bi + 1)
+    return tuple(n)
+
+
+def features(img, sd):
+    """Backbone + FPN + protonet + head logits, before the eval softmax (modules/yolact.py:141-157)."""
+    layers = resnet_layers_from_sd(sd)
+    c2, c3, c4, c5 = resnet(img, sd, layers)
+    levels = fpn(c3, c4, c5, sd)
+    proto = protonet(levels[0], sd).permute(0, 2, 3, 1).contiguous()
+    num_classes = sd['prediction_layers.conf_layer.weight'].shape[0] // 3
+    confs, boxes, coefs = zip(*(head(lv, sd, num_classes) for lv in levels))
+    return (torch.cat(confs, 1), torch.cat(boxes, 1), torch.cat(coefs, 1), proto,
+            dict(c2=c2, c3=c3, c4=c4, c5=c5, levels=levels))
+
+
+def forward_eval(img, sd):
+    """modules/yolact.py:141-164, eval branch: returns (class_pred softmaxed, box, coef, proto NHWC)."""
+    conf, box, coef, proto, _ = features(img, sd)
+    return F.softmax(conf, -1), box, coef, proto
+
+
+# ------------------------------------------------------------------------------------------------
+# anchors
+# ------------------------------------------------------------------------------------------------
+def anchors_for(img_size, scales, aspect_ratios=(1, 0.5, 2)):
+    """modules/yolact.py:111-114 + utils/box_utils.py:86-101 (float64 list -> fp32 tensor [N,4])."""
+    out = []
+    for stride, scale in zip((8, 16, 32, 64, 128), scales):
+        n = math.ceil(img_size / stride)
+        for j in range(n):
+            for i in range(n):
+                for ar in aspect_ratios:
+                    r = math.sqrt(ar)
+                    out += [(i + 0.5) / n, (j + 0.5) / n, scale * r / img_size, scale / r / img_size]
+    return torch.tensor(out).reshape(-1, 4)
+
+
+# ------------------------------------------------------------------------------------------------
+# post-processing
+# ------------------------------------------------------------------------------------------------
+def pairwise_iou(a, b):
+    """utils/box_utils.py:8-37 — inter / (area_a + area_b - inter), no +1, 0/0 -> NaN. a:[n,A,4] b:[n,B,4]."""
+    lo = torch.max(a[:, :, None, :2], b[:, None, :, :2])
+    hi = torch.min(a[:, :, None, 2:], b[:, None, :, 2:])
+    wh = torch.clamp(hi - lo, min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    area_a = ((a[..., 2] - a[..., 0]) * (a[..., 3] - a[..., 1]))[:, :, None]
+    area_b = ((b[..., 2] - b[..., 0]) * (b[..., 3] - b[..., 1]))[:, None, :]
+    return inter / (area_a + area_b - inter)
+
+
+def decode(box_p, anchors):
+    """utils/output_utils.py:148-153 — centre-size decode to corners, clipped to [0,1]."""
+    cxcy = anchors[:, :2] + box_p[:, :2] * 0.1 * anchors[:, 2:]
+    wh = anchors[:, 2:] * torch.exp(box_p[:, 2:] * 0.2)
+    x1y1 = cxcy - wh / 2
+    x2y2 = wh + x1y1
+    return torch.clip(torch.cat((x1y1, x2y2), 1), min=0., max=1.)
+
+
+def fast_nms(boxes, coefs, scores, top_k=200, iou_thre=0.5, max_det=100):
+    """utils/output_utils.py:11-43. scores:[C,K] boxes:[K,4] coefs:[K,32]."""
+    scores, idx = scores.sort(1, descending=True)
+    idx, scores = idx[:, :top_k], scores[:, :top_k]
+    ncls, ndet = idx.shape
+    bx = boxes[idx.reshape(-1)].reshape(ncls, ndet, 4)
+    cf = coefs[idx.reshape(-1)].reshape(ncls, ndet, -1)
+    iou = pairwise_iou(bx, bx)
+    iou.triu_(diagonal=1)                 # zero-fills (does not multiply): lower-triangle NaNs vanish
+    iou_max, _ = iou.max(dim=1)           # NaN propagates -> `<=` below is False -> dropped
+    keep = iou_max <= iou_thre
+    cls = torch.arange(ncls)[:, None].expand_as(keep)[keep]
+    bx, cf, sc = bx[keep], cf[keep], scores[keep]
+    sc, order = sc.sort(0, descending=True)
+    order, sc = order[:max_det], sc[:max_det]
+    return bx[order], cf[order], cls[order], sc
+
+
+_greedy_lib = None
+
+
+def _greedy():
+    global _greedy_lib
+    if _greedy_lib is None:
+        path = os.path.join(_HERE, 'libgreedy_nms.so')
+        if not os.path.exists(path):
+            raise RuntimeError(f'{path} missing: run `make -C oracle` (done by __graft_entry__.build())')
+        lib = ctypes.CDLL(path)
+        lib.oracle_greedy_nms.restype = ctypes.c_int
+        lib.oracle_greedy_nms.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_void_p]
+        _greedy_lib = lib
+    return _greedy_lib
+
+
+def greedy_nms(dets, thresh):
+    """cython_nms.pyx:24-74 via the C restatement oracle/greedy_nms.c. dets float32 [n,5] -> kept idx (ascending)."""
+    dets = np.ascontiguousarray(dets, dtype=np.float32)
+    keep = np.empty(dets.shape[0], dtype=np.int64)
+    n = _greedy().oracle_greedy_nms(dets.ctypes.data, dets.shape[0], ctypes.c_float(thresh), keep.ctypes.data)
+    return keep[:n]
+
+
+def traditional_nms(boxes, coefs, scores, img_size, score_thre=0.05, iou_thre=0.5, max_det=100):
+    """utils/output_utils.py:84-123 — per-class greedy NMS on boxes scaled by img_size."""
+    boxes = boxes * img_size
+    idx_l, cls_l, scr_l = [], [], []
+    for c in range(scores.shape[0]):
+        s = scores[c]
+        m = s > score_thre
+        if int(m.sum()) == 0:
+            continue
+        cand = torch.arange(s.shape[0])[m]
+        dets = torch.cat([boxes[m], s[m][:, None]], 1).numpy()
+        keep = torch.from_numpy(greedy_nms(dets, iou_thre)).long()
+        idx_l.append(cand[keep])
+        cls_l.append(torch.full_like(keep, c))
+        scr_l.append(s[m][keep])
+    idx, cls, scr = torch.cat(idx_l), torch.cat(cls_l), torch.cat(scr_l)
+    scr, order = scr.sort(0, descending=True)
+    order, scr = order[:max_det], scr[:max_det]
+    idx, cls = idx[order], cls[order]
+    return boxes[idx] / img_size, coefs[idx], cls, scr
+
+
+def nms(class_pred, box_pred, coef_pred, proto_out, anchors, score_thre=0.05, iou_thre=0.5, top_k=200,
+        max_det=100, traditional=False, img_size=544):
+    """utils/output_utils.py:126-163 (batch of one). Returns (ids, scores, boxes, coefs, proto) or 5x None."""
+    cls = class_pred.squeeze(0).transpose(1, 0).contiguous()[1:]       # [C-1, N], background dropped
+    box_p, coef_p, proto = box_pred.squeeze(0), coef_pred.squeeze(0), proto_out.squeeze(0)
+    keep = cls.max(dim=0)[0] > score_thre
+    cls_k = cls[:, keep]
+    boxes = decode(box_p[keep], anchors[keep])
+    coefs = coef_p[keep]
+    if cls_k.shape[1] == 0:
+        return None, None, None, None, None
+    if traditional:
+        bx, cf, ids, sc = traditional_nms(boxes, coefs, cls_k, img_size, score_thre, iou_thre, max_det)
+    else:
+        bx, cf, ids, sc = fast_nms(boxes, coefs, cls_k, top_k, iou_thre, max_det)
+    return ids, sc, bx, cf, proto
+
+
+def crop_window(boxes, w, h, padding=1):
+    """utils/box_utils.py:117-132,147-153 — float window [x1,x2) x [y1,y2) in prototype pixels."""
+    def span(a, b, size):
+        a, b = a * size, b * size
+        lo, hi = torch.min(a, b), torch.max(a, b)
+        return torch.clamp(lo - padding, min=0), torch.clamp(hi + padding, max=size)
+    x1, x2 = span(boxes[:, 0], boxes[:, 2], w)
+    y1, y2 = span(boxes[:, 1], boxes[:, 3], h)
+    return x1, x2, y1, y2
+
+
+def crop(masks, boxes, padding=1):
+    """utils/box_utils.py:147-168. masks [h,w,n]."""
+    h, w, n = masks.shape
+    x1, x2, y1, y2 = crop_window(boxes, w, h, padding)
+    xs = torch.arange(w, dtype=x1.dtype).view(1, -1, 1)
+    ys = torch.arange(h, dtype=x1.dtype).view(-1, 1, 1)
+    inside = (xs >= x1.view(1, 1, -1)) & (xs < x2.view(1, 1, -1)) & (ys >= y1.view(1, 1, -1)) & (ys < y2.view(1, 1, -1))
+    return masks * inside.float()
+
+
+def assemble_masks(proto, coefs, boxes, do_crop=True):
+    """utils/output_utils.py:217-222 — sigmoid(proto @ coef^T), crop, -> [n, Hp, Wp] (pre-resize, soft)."""
+    m = torch.sigmoid(torch.matmul(proto, coefs.t()))
+    if do_crop:
+        m = crop(m, boxes)
+    return m.permute(2, 0, 1).contiguous()
+
+
+def after_nms(ids, scores, boxes, coefs, proto, img_h, img_w, visual_thre=0.0, do_crop=True, return_soft=False):
+    """utils/output_utils.py:200-233. `boxes` is NOT mutated here (the reference scales it in place)."""
+    if ids is None:
+        return None, None, None, None
+    if visual_thre > 0:
+        k = scores >= visual_thre
+        if not bool(k.any()):
+            return None, None, None, None
+        ids, scores, boxes, coefs = ids[k], scores[k], boxes[k], coefs[k]
+    soft = assemble_masks(proto, coefs, boxes, do_crop)
+    size = max(img_h, img_w)
+    up = F.interpolate(soft.unsqueeze(0), (size, size), mode='bilinear', align_corners=False).squeeze(0)
+    masks = (up > 0.5).float()
+    masks = masks[:, :img_h, :] if img_h < img_w else masks[:, :, :img_w]
+    boxes_px = (boxes * size).int()
+    if return_soft:
+        up = up[:, :img_h, :] if img_h < img_w else up[:, :, :img_w]
+        return ids, scores, boxes_px, masks, soft, up
+    return ids, scores, boxes_px, masks
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic inputs shared by goldens, tests and bench
+# ------------------------------------------------------------------------------------------------
+def synth_head_outputs(n_anchors, num_classes=81, proto_hw=136, seed=1, bg_bias=4.0, spread=2.5):
+    """softmax(randn*spread + bg_bias*e_bg), randn*0.5 boxes, tanh(randn) coefs, relu(randn) protos."""
+    g = torch.Generator().manual_seed(seed)
+    logits = torch.randn(1, n_anchors, num_classes, generator=g) * spread
+    logits[..., 0] += bg_bias
+    cls = F.softmax(logits, -1)
+    box = torch.randn(1, n_anchors, 4, generator=g) * 0.5
+    coef = torch.tanh(torch.randn(1, n_anchors, 32, generator=g))
+    proto = F.relu(torch.randn(1, proto_hw, proto_hw, 32, generator=g))
+    return cls, box, coef, proto
+
+
+def randomize_bn_(sd, seed=7):
+    """Give every BatchNorm non-trivial statistics/affine (default init is identity-like and would not test folding)."""
+    g = torch.Generator().manual_seed(seed)
+    for k in sorted(sd):
+        if k.endswith('running_mean'):
+            sd[k].copy_(torch.randn(sd[k].shape, generator=g) * 0.1)
+        elif k.endswith('running_var'):
+            sd[k].copy_(torch.rand(sd[k].shape, generator=g) * 0.5 + 0.75)
+        elif '.bn' in k or 'downsample.1' in k:
+            if k.endswith('.weight'):
+                sd[k].copy_(torch.rand(sd[k].shape, generator=g) * 0.2 + 0.4)
+            elif k.endswith('.bias'):
+                sd[k].copy_(torch.randn(sd[k].shape, generator=g) * 0.05)
+    return sd
+
+
+def randomize_bias_(sd, seed=11):
+    """Conv biases are zero-initialised by the reference; make them non-zero so the bias path is exercised."""
+    g = torch.Generator().manual_seed(seed)
+    for k in sorted(sd):
+        if k.endswith('.bias') and sd[k].dim() == 1 and '.bn' not in k and 'downsample.1' not in k:
+            sd[k].copy_(torch.randn(sd[k].shape, generator=g) * 0.05)
+    return sd

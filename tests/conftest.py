@@ -1,0 +1,37 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def pytest_collection_modifyitems(config, items):
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason='no GPU visible')
+    for item in items:
+        if 'gpu' in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope='session')
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope='session', autouse=True)
+def _oracle_built():
+    """The C half of the oracle is a build product (oracle/Makefile)."""
+    import subprocess
+    so = os.path.join(REPO, 'oracle', 'libgreedy_nms.so')
+    if not os.path.exists(so):
+        subprocess.check_call(['make', '-C', os.path.join(REPO, 'oracle')])

@@ -1,0 +1,195 @@
+"""GPU parity of the single ops behind the C-ABI against plain PyTorch fp32 on the CPU."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device('cuda:0')
+
+
+def run_conv(x_nchw, w, scale=None, shift=None, residual=None, stride=1, pad=0, act=0, tile=(0, 0), ksplit=0):
+    """Runs ym_conv2d_fwd on NHWC data; returns NCHW cpu tensor."""
+    from yolact_minimal_amd import hip
+    dev = _dev()
+    b, cin, h, wd = x_nchw.shape
+    cout, _, kh, kw = w.shape
+    stem = cin == 3
+    if stem:
+        xin = torch.zeros(b, h, wd, 4)
+        xin[..., :3] = x_nchw.permute(0, 2, 3, 1)
+    else:
+        xin = x_nchw.permute(0, 2, 3, 1)
+    xin = xin.contiguous().to(dev)
+    cin_pad = 4 if stem else cin
+    k_pad = (kh * kw * cin_pad + 31) // 32 * 32
+    wp = hip.pack_conv_weight(w.to(dev), cin_pad, k_pad)
+    ho, wo = (h + 2 * pad - kh) // stride + 1, (wd + 2 * pad - kw) // stride + 1
+    out = torch.full((b, ho, wo, cout), float('nan'), device=dev)
+    d = hip.ConvDesc()
+    d.inp, d.weight = xin.data_ptr(), wp.data_ptr()
+    sc = scale.to(dev) if scale is not None else None
+    sh = shift.to(dev) if shift is not None else None
+    rs = residual.permute(0, 2, 3, 1).contiguous().to(dev) if residual is not None else None
+    d.scale = sc.data_ptr() if sc is not None else None
+    d.shift = sh.data_ptr() if sh is not None else None
+    d.residual = rs.data_ptr() if rs is not None else None
+    d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW = b, h, wd, cin_pad, cout, kh, kw
+    d.stride, d.pad, d.Ho, d.Wo, d.k_pad, d.nseg = stride, pad, ho, wo, k_pad, 1
+    d.seg[0].n_begin, d.seg[0].n_end, d.seg[0].out = 0, cout, out.data_ptr()
+    d.seg[0].batch_stride, d.seg[0].pitch, d.seg[0].act = ho * wo * cout, cout, act
+    d.tile_m, d.tile_n = tile
+    d.ksplit = ksplit
+    nbytes = hip.conv_workspace_bytes(d)
+    ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+    hip.conv2d_fwd(d, ws)
+    torch.cuda.synchronize()
+    return out.cpu().permute(0, 3, 1, 2)
+
+
+def ref_conv(x, w, scale, shift, residual, stride, pad, act):
+    y = F.conv2d(x.double(), w.double(), None, stride, pad)
+    if scale is not None:
+        y = y * scale.double().view(1, -1, 1, 1)
+    if shift is not None:
+        y = y + shift.double().view(1, -1, 1, 1)
+    if residual is not None:
+        y = y + residual.double()
+    if act == 1:
+        y = F.relu(y)
+    elif act == 2:
+        y = torch.tanh(y)
+    return y.float()
+
+
+CONV_CASES = [
+    # b, cin, h, w, cout, k, stride, pad, act, residual, tile, ksplit
+    (1, 64, 17, 17, 64, 1, 1, 0, 1, False, (0, 0), 0),
+    (2, 64, 20, 23, 256, 1, 1, 0, 1, True, (128, 128), 1),
+    (1, 128, 19, 19, 128, 3, 2, 1, 1, False, (128, 64), 1),
+    (1, 256, 9, 9, 96, 3, 1, 1, 2, False, (64, 128), 1),
+    (2, 256, 12, 10, 255, 3, 1, 1, 0, False, (64, 64), 3),
+    (1, 512, 7, 7, 2048, 1, 2, 0, 0, False, (64, 64), 4),
+    (1, 32, 40, 40, 64, 3, 1, 1, 1, True, (0, 0), 0),
+    (2, 3, 64, 64, 64, 7, 2, 3, 1, False, (0, 0), 0),       # stem mode
+    (1, 3, 33, 47, 64, 7, 2, 3, 1, False, (0, 0), 0),       # stem, odd sizes
+    (1, 256, 5, 5, 256, 3, 2, 1, 1, False, (0, 0), 0),      # P7-like, heuristic split-K
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_parity(case):
+    b, cin, h, w, cout, k, stride, pad, act, use_res, tile, ksplit = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    res = torch.randn(b, cout, ho, wo, generator=g) if use_res else None
+    got = run_conv(x, wt, scale, shift, res, stride, pad, act, tile, ksplit)
+    want = ref_conv(x, wt, scale, shift, res, stride, pad, act)
+    assert not torch.isnan(got).any()
+    # tolerance: fp32 accumulation-order differences only
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5)
+
+
+def test_conv_identity_asymmetric():
+    """Transpose-detecting check (cdna guide G9): identity 1x1 weight must return the input exactly."""
+    x = torch.arange(2 * 64 * 5 * 7, dtype=torch.float32).reshape(2, 64, 5, 7) * 0.01
+    w = torch.eye(64).reshape(64, 64, 1, 1)
+    got = run_conv(x, w)
+    assert torch.equal(got, x)
+
+
+def test_conv_three_segments():
+    """Head-style routing: 351 output channels into three tensors with different pitch / activation."""
+    from yolact_minimal_amd import hip
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    b, h, w, cin = 2, 9, 9, 256
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(351, cin, 3, 3, generator=g) * 0.02
+    bias = torch.randn(351, generator=g) * 0.1
+    n_total, off = 400, 37
+    conf = torch.zeros(b, n_total, 81, device=dev)
+    box = torch.zeros(b, n_total, 4, device=dev)
+    coef = torch.zeros(b, n_total, 32, device=dev)
+    xin = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wp = hip.pack_conv_weight(wt.to(dev), cin, 9 * cin)
+    sh = bias.to(dev)
+    d = hip.ConvDesc()
+    d.inp, d.weight, d.shift = xin.data_ptr(), wp.data_ptr(), sh.data_ptr()
+    d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW = b, h, w, cin, 351, 3, 3
+    d.stride, d.pad, d.Ho, d.Wo, d.k_pad, d.nseg = 1, 1, h, w, 9 * cin, 3
+    for i, (n0, n1, t, c, act) in enumerate([(0, 243, conf, 81, 0), (243, 255, box, 4, 0), (255, 351, coef, 32, 2)]):
+        d.seg[i].n_begin, d.seg[i].n_end = n0, n1
+        d.seg[i].out = t.data_ptr() + off * c * 4
+        d.seg[i].batch_stride, d.seg[i].pitch, d.seg[i].act = n_total * c, 3 * c, act
+    hip.conv2d_fwd(d, None)
+    torch.cuda.synchronize()
+    y = F.conv2d(x, wt, bias, 1, 1).permute(0, 2, 3, 1)            # [b,h,w,351]
+    want_conf = y[..., :243].reshape(b, -1, 81)
+    want_box = y[..., 243:255].reshape(b, -1, 4)
+    want_coef = torch.tanh(y[..., 255:]).reshape(b, -1, 32)
+    n = h * w * 3
+    torch.testing.assert_close(conf[:, off:off + n].cpu(), want_conf, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(box[:, off:off + n].cpu(), want_box, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(coef[:, off:off + n].cpu(), want_coef, rtol=1e-4, atol=1e-5)
+    assert float(conf[:, :off].abs().sum()) == 0 and float(conf[:, off + n:].abs().sum()) == 0
+
+
+def test_conv_rejects_bad_args():
+    from yolact_minimal_amd import hip
+    d = hip.ConvDesc()
+    with pytest.raises(RuntimeError):
+        hip.conv2d_fwd(d, None)
+
+
+def test_maxpool():
+    from yolact_minimal_amd import hip
+    x = torch.randn(2, 64, 31, 30)
+    xin = x.permute(0, 2, 3, 1).contiguous().to(_dev())
+    out = torch.empty(2, 16, 15, 64, device=_dev())
+    hip.maxpool3x3s2(xin, out)
+    want = F.max_pool2d(x, 3, 2, 1)
+    assert torch.equal(out.cpu().permute(0, 3, 1, 2), want)
+
+
+@pytest.mark.parametrize('align', [False, True])
+def test_bilinear2x(align):
+    from yolact_minimal_amd import hip
+    x = torch.randn(2, 8, 9, 7)
+    xin = x.permute(0, 2, 3, 1).contiguous().to(_dev())
+    out = torch.empty(2, 18, 14, 8, device=_dev())
+    hip.bilinear2x(xin, out, align)
+    want = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=align)
+    torch.testing.assert_close(out.cpu().permute(0, 3, 1, 2), want, rtol=1e-6, atol=1e-6)
+
+
+def test_softmax_rows():
+    from yolact_minimal_amd import hip
+    x = torch.randn(3, 1000, 81) * 4
+    xd = x.to(_dev())
+    out = torch.empty_like(xd)
+    hip.softmax_rows(xd, out)
+    torch.testing.assert_close(out.cpu(), F.softmax(x, -1), rtol=1e-5, atol=1e-7)
+
+
+def test_fold_bn_and_pack():
+    from yolact_minimal_amd import hip
+    dev = _dev()
+    g, b, m, v = torch.rand(70) + 0.5, torch.randn(70), torch.randn(70), torch.rand(70) + 0.5
+    sc, sh = hip.fold_bn(g.to(dev), b.to(dev), m.to(dev), v.to(dev), 1e-5)
+    want_sc = g / torch.sqrt(v + 1e-5)
+    torch.testing.assert_close(sc.cpu(), want_sc, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(sh.cpu(), b - m * want_sc, rtol=1e-5, atol=1e-6)
+    w = torch.randn(5, 3, 7, 7)
+    p = hip.pack_conv_weight(w.to(dev), 4, 224).cpu()
+    want = torch.zeros(5, 7, 7, 4)
+    want[..., :3] = w.permute(0, 2, 3, 1)
+    assert torch.equal(p[:, :196], want.reshape(5, 196)) and float(p[:, 196:].abs().sum()) == 0

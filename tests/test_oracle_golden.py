@@ -1,0 +1,118 @@
+"""CPU: the oracle restatement reproduces the vectors the REAL reference produced (tests/golden/*.npz,
+written by oracle/make_golden.py in the build container) and the seeded construction of the product's
+`Yolact` is bit-identical to the reference's."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import yolact_ref as R
+from yolact_minimal_amd.config import build_cfg
+from yolact_minimal_amd.modules.yolact import Yolact
+
+
+def _digest(t):
+    t = t.detach().double()
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()])
+
+
+def make_net(name, size, seed):
+    cfg = build_cfg(name, 'val', size)
+    torch.manual_seed(seed)
+    net = Yolact(cfg).eval()
+    sd = net.state_dict()
+    R.randomize_bn_(sd, seed + 100)
+    R.randomize_bias_(sd, seed + 200)
+    net.load_state_dict(sd)
+    return net, cfg
+
+
+@pytest.mark.parametrize('name', ['res50_coco', 'res101_coco'])
+def test_seeded_state_dict_matches_reference(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, 'state.npz'))
+    cfg = build_cfg(name, 'val', 64)
+    torch.manual_seed(int(g[f'{name}_seed']))
+    net = Yolact(cfg)
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(g[f'{name}_keys'])
+    mine = np.stack([_digest(sd[k].float()) for k in sd])
+    np.testing.assert_array_equal(mine, g[f'{name}_digest'])
+    np.testing.assert_array_equal(np.array(net.anchors), g[f'{name}_anchors64'])
+
+
+def test_anchors_544(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'state.npz'))
+    a = R.anchors_for(544, [24, 48, 96, 192, 384]).numpy()
+    np.testing.assert_array_equal(a, g['anchors544_f32'])
+    cfg = build_cfg('res101_coco', 'val', 544)
+    from yolact_minimal_amd.utils.box_utils import make_anchors
+    flat = []
+    for size, scale in zip((68, 34, 17, 9, 5), cfg.scales):
+        flat += make_anchors(cfg, size, size, scale)
+    np.testing.assert_array_equal(torch.tensor(flat).reshape(-1, 4).numpy(), g['anchors544_f32'])
+
+
+@pytest.mark.parametrize('name,size,batch', [('res50_coco', 64, 1), ('res50_coco', 96, 2), ('res101_coco', 128, 1)])
+def test_oracle_forward_matches_golden(golden_dir, name, size, batch):
+    g = np.load(os.path.join(golden_dir, f'forward_{name}_{size}_b{batch}.npz'))
+    seed = int(g['seed'])
+    net, _ = make_net(name, size, seed)
+    img = torch.randn(batch, 3, size, size, generator=torch.Generator().manual_seed(seed + 300))
+    np.testing.assert_allclose(_digest(img), g['img_digest'], rtol=1e-12)
+    with torch.no_grad():
+        out = R.forward_eval(img, net.state_dict())
+    # conv summation order may differ between host CPUs (oneDNN ISA dispatch): tolerance, not bit-equality
+    for t, key in zip(out, ('class_pred', 'box_pred', 'coef_pred', 'proto_out')):
+        np.testing.assert_allclose(t.numpy(), g[key], rtol=2e-4, atol=2e-6, err_msg=key)
+
+
+POST_CASES = ['small128', 'empty128', 'degenerate128', 'ties128']
+
+
+@pytest.mark.parametrize('tag', POST_CASES)
+def test_oracle_post_matches_golden(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, f'post_{tag}.npz'))
+    cls, box, coef, proto = (torch.from_numpy(g[k]) for k in ('in_class', 'in_box', 'in_coef', 'in_proto'))
+    anchors = torch.from_numpy(g['in_anchors'])
+    r = R.nms(cls, box, coef, proto, anchors)
+    if int(g['n']) == 0:
+        assert r[0] is None
+        return
+    np.testing.assert_array_equal(r[0].numpy(), g['ids'])
+    np.testing.assert_array_equal(r[1].numpy(), g['scores'])
+    np.testing.assert_allclose(r[2].numpy(), g['boxes'], rtol=0, atol=2e-7)   # exp() is libm/ISA dependent
+    np.testing.assert_array_equal(r[3].numpy(), g['coefs'])
+    for key in g.files:
+        if key.startswith('px_boxes_'):
+            h, w = (int(v) for v in key[len('px_boxes_'):].split('x'))
+            a = R.after_nms(r[0], r[1], torch.from_numpy(g['boxes']), r[3], r[4], h, w)
+            np.testing.assert_array_equal(a[2].numpy(), g[key])
+            packed = np.packbits(a[3].numpy().astype(np.uint8).reshape(-1))
+            mism = np.unpackbits(packed ^ g[f'masks_{h}x{w}_packed']).sum()
+            assert mism <= 2, f'{mism} mask pixels differ'
+
+
+def test_oracle_dense544_matches_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'post_dense544.npz'))
+    cls, box, coef, proto = R.synth_head_outputs(18525, seed=1)
+    np.testing.assert_allclose(_digest(cls), g['in_class_digest'], rtol=1e-9)
+    anchors = R.anchors_for(544, [24, 48, 96, 192, 384])
+    r = R.nms(cls, box, coef, proto, anchors)
+    np.testing.assert_array_equal(r[0].numpy(), g['ids'])
+    np.testing.assert_array_equal(r[1].numpy(), g['scores'])
+    np.testing.assert_allclose(r[2].numpy(), g['boxes'], rtol=0, atol=2e-7)
+
+
+def test_degenerate_case_hits_nan_path(golden_dir):
+    """The fixture really contains zero-area boxes among the top-k (0/0 IoU -> NaN -> dropped)."""
+    g = np.load(os.path.join(golden_dir, 'post_degenerate128.npz'))
+    cls, box = torch.from_numpy(g['in_class']), torch.from_numpy(g['in_box'])
+    anchors = torch.from_numpy(g['in_anchors'])
+    c = cls.squeeze(0).t()[1:]
+    keep = c.max(0)[0] > 0.05
+    boxes = R.decode(box.squeeze(0)[keep], anchors[keep])
+    area = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+    assert int((area == 0).sum()) >= 2
+    iou = R.pairwise_iou(boxes[None], boxes[None])
+    assert bool(torch.isnan(iou).any())

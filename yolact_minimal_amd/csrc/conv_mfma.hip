@@ -1,0 +1,392 @@
+// Fused convolution for gfx950: NHWC fp32 implicit GEMM on the f32 MFMA pipe
+// (v_mfma_f32_32x32x2_f32), BN scale/shift + bias + residual + ReLU/tanh in the epilogue, up to three
+// output segments so the YOLACT head (conf|bbox|coef) is one launch writing straight into the
+// concatenated [B, N, C] tensors.
+//
+// GEMM view:  C[m][n] = sum_k A[m][k] * W[n][k]
+//   m = (b, oh, ow)            M = B*Ho*Wo       (output pixels, NHWC row index)
+//   n = output channel         N = Cout
+//   k = (kh, kw, cin)          K = KH*KW*Cin     (both operands are K-contiguous in HBM:
+//                                                 A row = Cin floats of one input pixel per tap,
+//                                                 W row = ym_pack_conv_weight image)
+// Workgroup = 256 threads = 4 waves (2x2), tile BM x BN, K step 32 floats (128 B per row).
+// LDS image: [rows][36] floats (pitch 144 B = 9 x 16 B -> ds_read_b128 of 16 consecutive rows hits 16
+// distinct 16-B slots of the 256-B bank row: conflict-free, cdna guide §2 / G4).
+// MFMA operand trick: 32x32x2 wants lane l to supply A[i=l&31][k=l>>5]; since the order of the K
+// sum is free, lane half h takes k = 8g+4h+s for step s of group g, so ONE ds_read_b128 per operand row
+// feeds four MFMA steps (both operands use the same k assignment, so products pair up correctly).
+// Per K-tile a wave issues 4*(TM+TN) ds_read_b128 for 16*TM*TN MFMAs of 64 cycles each: the kernel
+// is MFMA-issue bound, LDS and the global->LDS staging (register prefetch, double-buffered) sit
+// far below their limits.  Grid: one block per (tile, k-slice), XCD-aware remap so the N-tiles
+// sharing an A panel run on the same XCD L2.
+#include "ym_common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int PITCH = 36;  // floats
+
+struct SegDev {
+    float* out;
+    long long bstride;
+    int n0, n1, pitch, act;
+};
+
+struct ConvP {
+    const float* in;
+    const float* w;
+    const float* scale;
+    const float* shift;
+    const float* residual;
+    float* ws;  // split-K partials [ksplit][M][Cout] (only when ksplit > 1)
+    int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, Kpad;
+    int M, HoWo, nkt, ksplit, kt_per_split, tiles_m, tiles_n;
+    int nseg;
+    SegDev seg[3];
+};
+
+__device__ __forceinline__ void epilogue_store(const ConvP& p, int m, int n, float acc) {
+    float v = acc;
+    if (p.scale) v *= p.scale[n];
+    if (p.shift) v += p.shift[n];
+    if (p.residual) v += p.residual[(size_t)m * p.Cout + n];
+    const int b = m / p.HoWo, pix = m - b * p.HoWo;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        if (s < p.nseg && n >= p.seg[s].n0 && n < p.seg[s].n1) {
+            const SegDev& g = p.seg[s];
+            g.out[(size_t)b * g.bstride + (size_t)pix * g.pitch + (n - g.n0)] = ym_apply_act(v, g.act);
+        }
+    }
+}
+
+// MODE 0: Cin % 32 == 0 (every K tile lies inside one filter tap).  MODE 1: Cin == 4 (stem; one tap per float4).
+template <int BM, int BN, int MODE>
+__global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
+    constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave (wave tile = BM/2 x BN/2)
+    constexpr int AR = BM / 32, BR = BN / 32;   // staging rows per thread
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                         // [2][BM][PITCH]
+    float* Bs = smem + 2 * BM * PITCH;        // [2][BN][PITCH]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    int id = ym_xcd_remap(blockIdx.x, gridDim.x);
+    const int ks = id % p.ksplit;
+    id /= p.ksplit;
+    const int tile_m = id / p.tiles_n, tile_n = id - tile_m * p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int kt_beg = ks * p.kt_per_split;
+    const int kt_end = min(p.nkt, kt_beg + p.kt_per_split);
+
+    // ---- per-thread staging coordinates -------------------------------------------------------
+    const int c4 = tid & 7;      // which float4 of the 32-float K row
+    const int rbase = tid >> 3;  // 0..31
+    int a_pix[AR];               // (b*H + ih0)*W + iw0   (may be negative; only used when in range)
+    int a_ih0[AR], a_iw0[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        const int m = m0 + rbase + 32 * i;
+        if (m < p.M) {
+            const int b = m / p.HoWo, rem = m - b * p.HoWo;
+            const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+            a_ih0[i] = oh * p.stride - p.pad;
+            a_iw0[i] = ow * p.stride - p.pad;
+            a_pix[i] = (b * p.H + a_ih0[i]) * p.W + a_iw0[i];
+        } else {
+            a_ih0[i] = -(1 << 20);
+            a_iw0[i] = -(1 << 20);
+            a_pix[i] = 0;
+        }
+    }
+    const float* wrow[BR];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+        const int n = n0 + rbase + 32 * i;
+        wrow[i] = (n < p.Cout) ? p.w + (size_t)n * p.Kpad + c4 * 4 : nullptr;
+    }
+
+    // tap walker for MODE 0 (uniform across the block)
+    int kh = 0, kw = 0, c0 = 0;
+    if (MODE == 0) {
+        const int k0 = kt_beg * BK;
+        const int tap = k0 / p.Cin;
+        c0 = k0 - tap * p.Cin;
+        kh = tap / p.KW;
+        kw = tap - kh * p.KW;
+    }
+
+    f32x4 ra[AR], rb[BR];
+    auto load_tile = [&](int kt) {
+        if (MODE == 0) {
+            const int tap_off = (kh * p.W + kw);
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+                const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                if (ok) {
+                    const float* src = p.in + (size_t)(a_pix[i] + tap_off) * p.Cin + c0 + c4 * 4;
+                    ra[i] = *reinterpret_cast<const f32x4*>(src);
+                } else {
+                    ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            c0 += BK;
+            if (c0 >= p.Cin) {
+                c0 = 0;
+                if (++kw == p.KW) { kw = 0; ++kh; }
+            }
+        } else {
+            const int tap = kt * 8 + c4;  // Cin == 4: one tap per float4
+            const int th = tap / p.KW, tw = tap - th * p.KW;
+            const bool tap_ok = tap < p.KH * p.KW;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const int ih = a_ih0[i] + th, iw = a_iw0[i] + tw;
+                const bool ok = tap_ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                if (ok) {
+                    const float* src = p.in + (size_t)(a_pix[i] + th * p.W + tw) * 4;
+                    ra[i] = *reinterpret_cast<const f32x4*>(src);
+                } else {
+                    ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            if (wrow[i]) rb[i] = *reinterpret_cast<const f32x4*>(wrow[i] + (size_t)kt * BK);
+            else rb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* a = As + buf * BM * PITCH;
+        float* b = Bs + buf * BN * PITCH;
+#pragma unroll
+        for (int i = 0; i < AR; ++i)
+            *reinterpret_cast<f32x4*>(a + (rbase + 32 * i) * PITCH + c4 * 4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BR; ++i)
+            *reinterpret_cast<f32x4*>(b + (rbase + 32 * i) * PITCH + c4 * 4) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frag_row = lane & 31, khalf = lane >> 5;
+    const int a_frag_off = (wm * (BM / 2) + frag_row) * PITCH + khalf * 4;
+    const int b_frag_off = (wn * (BN / 2) + frag_row) * PITCH + khalf * 4;
+
+    if (kt_beg < kt_end) {
+        load_tile(kt_beg);
+        store_tile(0);
+    }
+    __syncthreads();
+
+    for (int kt = kt_beg; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_beg) & 1;
+        const bool more = (kt + 1) < kt_end;
+        if (more) load_tile(kt + 1);
+
+        const float* a = As + cur * BM * PITCH + a_frag_off;
+        const float* b = Bs + cur * BN * PITCH + b_frag_off;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * PITCH + g * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * PITCH + g * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+        }
+
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) --
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + frag_row;
+        const bool n_ok = n < p.Cout;
+        // per-lane column state: which segment, its base pointer, BN scale/shift
+        float sc = 1.f, sh = 0.f;
+        float* optr = nullptr;
+        long long obs = 0;
+        int opitch = 0, oact = 0;
+        if (n_ok) {
+            if (p.scale) sc = p.scale[n];
+            if (p.shift) sh = p.shift[n];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                if (s < p.nseg && n >= p.seg[s].n0 && n < p.seg[s].n1) {
+                    optr = p.seg[s].out + (n - p.seg[s].n0);
+                    obs = p.seg[s].bstride; opitch = p.seg[s].pitch; oact = p.seg[s].act;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * khalf;
+            if (p.ksplit > 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    if (n_ok && m < p.M) p.ws[((size_t)ks * p.M + m) * p.Cout + n] = acc[i][j][r];
+                }
+            } else if (optr) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    if (m < p.M) {
+                        float v = acc[i][j][r] * sc + sh;
+                        if (p.residual) v += p.residual[(size_t)m * p.Cout + n];
+                        const int b = m / p.HoWo, pix = m - b * p.HoWo;
+                        optr[(size_t)b * obs + (size_t)pix * opitch] = ym_apply_act(v, oact);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void conv_splitk_reduce(const ConvP p) {
+    const size_t total = (size_t)p.M * p.Cout;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        float v = 0.f;
+        for (int s = 0; s < p.ksplit; ++s) v += p.ws[(size_t)s * total + e];
+        const int m = (int)(e / p.Cout), n = (int)(e - (size_t)m * p.Cout);
+        epilogue_store(p, m, n, v);
+    }
+}
+
+struct Plan {
+    int bm, bn, ksplit, kt_per_split, tiles_m, tiles_n, nkt, M;
+};
+
+int make_plan(const ym_conv_desc* d, Plan* pl) {
+    YM_REQUIRE(d && d->in && d->weight, "conv: null descriptor / pointer");
+    YM_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cout > 0, "conv: bad shape");
+    YM_REQUIRE(d->Cin == 4 || d->Cin % 32 == 0, "conv: Cin must be 4 (stem) or a multiple of 32, got %d", d->Cin);
+    YM_REQUIRE(d->k_pad % BK == 0 && d->k_pad >= d->KH * d->KW * d->Cin, "conv: k_pad %d invalid", d->k_pad);
+    YM_REQUIRE(d->Ho == (d->H + 2 * d->pad - d->KH) / d->stride + 1 && d->Wo == (d->W + 2 * d->pad - d->KW) / d->stride + 1,
+               "conv: Ho/Wo inconsistent with H/W/K/stride/pad");
+    YM_REQUIRE(d->nseg >= 1 && d->nseg <= 3, "conv: nseg must be 1..3");
+    for (int s = 0; s < d->nseg; ++s)
+        YM_REQUIRE(d->seg[s].out && d->seg[s].n_end > d->seg[s].n_begin && d->seg[s].n_end <= d->Cout,
+                   "conv: bad segment %d", s);
+    const long long M = (long long)d->B * d->Ho * d->Wo;
+    YM_REQUIRE(M * (long long)d->Cout < (1ll << 31) && (long long)d->B * d->H * d->W * d->Cin < (1ll << 31) * 1ll,
+               "conv: tensor too large for 32-bit indexing");
+    pl->M = (int)M;
+    pl->nkt = d->k_pad / BK;
+    int bm = d->tile_m, bn = d->tile_n;
+    if (bm == 0 || bn == 0) {
+        // largest tile that still gives every CU at least ~2 workgroups
+        const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+        bm = 64; bn = 64;
+        for (int c = 0; c < 3; ++c) {
+            const long long wgs = (long long)ym_cdiv(pl->M, cand[c][0]) * ym_cdiv(d->Cout, cand[c][1]);
+            if (wgs >= 512) { bm = cand[c][0]; bn = cand[c][1]; break; }
+        }
+        if (d->Cin == 4) { bm = 128; bn = 64; }
+    }
+    YM_REQUIRE((bm == 128 || bm == 64) && (bn == 128 || bn == 64), "conv: tile must be 64/128");
+    YM_REQUIRE(d->Cin != 4 || (bm == 128 && bn == 64), "conv: stem mode supports the 128x64 tile only");
+    pl->bm = bm; pl->bn = bn;
+    pl->tiles_m = ym_cdiv(pl->M, bm);
+    pl->tiles_n = ym_cdiv(d->Cout, bn);
+    int ks = d->ksplit;
+    if (ks <= 0) {
+        ks = 1;
+        const int wgs = pl->tiles_m * pl->tiles_n;
+        if (wgs < 256) {
+            ks = ym_cdiv(512, wgs);
+            const int max_ks = pl->nkt / 4 > 0 ? pl->nkt / 4 : 1;   // keep >= 4 K tiles per slice
+            if (ks > max_ks) ks = max_ks;
+            if (ks > 16) ks = 16;
+        }
+    }
+    if (ks > pl->nkt) ks = pl->nkt;
+    if (ks < 1) ks = 1;
+    pl->kt_per_split = ym_cdiv(pl->nkt, ks);
+    pl->ksplit = ym_cdiv(pl->nkt, pl->kt_per_split);
+    return YM_OK;
+}
+
+template <int BM, int BN, int MODE>
+void launch(const ConvP& p, int grid, hipStream_t st) {
+    const size_t lds = (size_t)2 * (BM + BN) * PITCH * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_f32<BM, BN, MODE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, MODE>), dim3(grid), dim3(256), lds, st, p);
+}
+
+}  // namespace
+
+extern "C" size_t ym_conv2d_workspace_bytes(const ym_conv_desc* d) {
+    Plan pl;
+    if (make_plan(d, &pl) != YM_OK) return 0;
+    return pl.ksplit > 1 ? (size_t)pl.ksplit * pl.M * d->Cout * sizeof(float) : 0;
+}
+
+extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t workspace_bytes, ym_stream_t s) {
+    Plan pl;
+    int rc = make_plan(d, &pl);
+    if (rc != YM_OK) return rc;
+    const size_t need = pl.ksplit > 1 ? (size_t)pl.ksplit * pl.M * d->Cout * sizeof(float) : 0;
+    if (need > workspace_bytes || (need && !workspace)) {
+        ym_set_error("conv: workspace %zu B < %zu B needed (ksplit %d)", workspace_bytes, need, pl.ksplit);
+        return YM_ENOSPC;
+    }
+    ConvP p;
+    p.in = d->in; p.w = d->weight; p.scale = d->scale; p.shift = d->shift; p.residual = d->residual;
+    p.ws = (float*)workspace;
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW;
+    p.stride = d->stride; p.pad = d->pad; p.Ho = d->Ho; p.Wo = d->Wo; p.Kpad = d->k_pad;
+    p.M = pl.M; p.HoWo = d->Ho * d->Wo; p.nkt = pl.nkt; p.ksplit = pl.ksplit; p.kt_per_split = pl.kt_per_split;
+    p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.nseg = d->nseg;
+    for (int i = 0; i < 3; ++i) {
+        if (i < d->nseg) {
+            p.seg[i].out = d->seg[i].out; p.seg[i].bstride = d->seg[i].batch_stride; p.seg[i].n0 = d->seg[i].n_begin;
+            p.seg[i].n1 = d->seg[i].n_end; p.seg[i].pitch = d->seg[i].pitch; p.seg[i].act = d->seg[i].act;
+        } else {
+            p.seg[i] = SegDev{nullptr, 0, 0, 0, 0, 0};
+        }
+    }
+    hipStream_t st = (hipStream_t)s;
+    const int grid = pl.tiles_m * pl.tiles_n * pl.ksplit;
+    if (d->Cin == 4) launch<128, 64, 1>(p, grid, st);
+    else if (pl.bm == 128 && pl.bn == 128) launch<128, 128, 0>(p, grid, st);
+    else if (pl.bm == 128 && pl.bn == 64) launch<128, 64, 0>(p, grid, st);
+    else if (pl.bm == 64 && pl.bn == 128) launch<64, 128, 0>(p, grid, st);
+    else launch<64, 64, 0>(p, grid, st);
+    rc = ym_check_launch("conv_igemm_f32");
+    if (rc != YM_OK) return rc;
+    if (pl.ksplit > 1) {
+        const size_t total = (size_t)pl.M * d->Cout;
+        int rgrid = (int)((total + 255) / 256);
+        if (rgrid > 2048) rgrid = 2048;
+        hipLaunchKernelGGL(conv_splitk_reduce, dim3(rgrid), dim3(256), 0, st, p);
+        rc = ym_check_launch("conv_splitk_reduce");
+    }
+    return rc;
+}

@@ -1,0 +1,604 @@
+// Detection post-processing for gfx950: score filter + ordered compaction + box decode, Fast-NMS
+// (per-class radix-select top-k, wavefront-reduction IoU column test, global top-100), greedy
+// per-class NMS (the cython_nms replacement), MFMA mask assembly with fused sigmoid+crop, and the
+// bilinear resize + binarise that produces the final masks.
+//
+// Bit-exactness: every comparison that decides an index (score > thre, IoU <= thre, ordering) is
+// evaluated in fp32 with the reference's operation order, IEEE division and NO fma contraction —
+// hence the pragma below.  Sort ties (torch.sort is unstable for n > 16, so the reference's tie order is
+// implementation-defined) are resolved here as "lower index first" (= a stable descending sort).
+#pragma clang fp contract(off)
+#include <limits.h>
+#include "ym_common.h"
+
+namespace {
+
+constexpr int NT = 1024;      // threads of the selection kernels
+constexpr int TOPK_CAP = 256; // >= cfg.top_k
+constexpr int DET_CAP = 128;  // >= cfg.max_detections
+
+__device__ __forceinline__ uint32_t f2key(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k) {
+    return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+
+// utils/box_utils.py:8-37, one pair: inter / (area_a + area_b - inter); 0/0 -> NaN like torch.
+__device__ __forceinline__ float iou_pair(const f32x4 a, const f32x4 b) {
+    const float hx = fminf(a[2], b[2]), hy = fminf(a[3], b[3]);
+    const float lx = fmaxf(a[0], b[0]), ly = fmaxf(a[1], b[1]);
+    float w = hx - lx, h = hy - ly;
+    w = w < 0.f ? 0.f : w;
+    h = h < 0.f ? 0.f : h;
+    const float inter = w * h;
+    const float area_a = (a[2] - a[0]) * (a[3] - a[1]);
+    const float area_b = (b[2] - b[0]) * (b[3] - b[1]);
+    return __fdiv_rn(inter, (area_a + area_b) - inter);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// block-level "top R of L, sorted" (radix select on order-preserving keys + bitonic sort in LDS)
+// ---------------------------------------------------------------------------------------------------
+template <int CAP>
+struct TopkShared {
+    uint32_t hist[256];
+    uint32_t keys[CAP];
+    int idx[CAP];
+    int wave_tot[NT / 64];
+    int sel_digit, remaining, eq_total, cnt_gt, cnt_eq, running;
+};
+
+template <int CAP, typename KeyAt>
+__device__ int block_topk_sorted(KeyAt key_at, int L, int R, TopkShared<CAP>& sh) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < CAP; i += nt) { sh.keys[i] = 0u; sh.idx[i] = INT_MAX; }
+    if (tid == 0) { sh.cnt_gt = 0; sh.cnt_eq = 0; sh.running = 0; }
+    __syncthreads();
+    int cnt;
+    if (L <= R) {
+        for (int i = tid; i < L; i += nt) { sh.keys[i] = key_at(i); sh.idx[i] = i; }
+        cnt = L;
+    } else {
+        uint32_t prefix = 0u, mask = 0u;
+        int remaining = R;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            for (int i = tid; i < 256; i += nt) sh.hist[i] = 0u;
+            __syncthreads();
+            for (int i = tid; i < L; i += nt) {
+                const uint32_t k = key_at(i);
+                if ((k & mask) == prefix) atomicAdd(&sh.hist[(k >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int acc = 0, d = 255;
+                for (; d > 0; --d) {
+                    const int h = (int)sh.hist[d];
+                    if (acc + h >= remaining) break;
+                    acc += h;
+                }
+                sh.sel_digit = d;
+                sh.remaining = remaining - acc;
+                sh.eq_total = (int)sh.hist[d];
+            }
+            __syncthreads();
+            prefix |= (uint32_t)sh.sel_digit << shift;
+            mask |= 0xFFu << shift;
+            remaining = sh.remaining;
+            __syncthreads();
+        }
+        const uint32_t T = prefix;
+        const int r_eq = remaining, n_gt = R - r_eq, eq_total = sh.eq_total;
+        for (int i = tid; i < L; i += nt) {
+            const uint32_t k = key_at(i);
+            if (k > T) {
+                const int p = atomicAdd(&sh.cnt_gt, 1);
+                sh.keys[p] = k; sh.idx[p] = i;
+            } else if (k == T && eq_total == r_eq) {
+                const int p = atomicAdd(&sh.cnt_eq, 1);
+                sh.keys[n_gt + p] = k; sh.idx[n_gt + p] = i;
+            }
+        }
+        if (eq_total != r_eq) {
+            // more ties at the cut than slots: take the r_eq LOWEST indices (ordered block scan)
+            const int lane = tid & 63, wv = tid >> 6;
+            for (int base = 0; base < L; base += nt) {
+                const int i = base + tid;
+                const bool f = (i < L) && key_at(i) == T;
+                const unsigned long long bal = __ballot(f);
+                const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+                if (lane == 0) sh.wave_tot[wv] = __popcll(bal);
+                __syncthreads();
+                int off = sh.running;
+                for (int w = 0; w < wv; ++w) off += sh.wave_tot[w];
+                if (f && off + pre < r_eq) { sh.keys[n_gt + off + pre] = T; sh.idx[n_gt + off + pre] = i; }
+                __syncthreads();
+                if (tid == 0) { int t = 0; for (int w = 0; w < nt / 64; ++w) t += sh.wave_tot[w]; sh.running += t; }
+                __syncthreads();
+                if (sh.running >= r_eq) break;
+            }
+        }
+        cnt = R;
+    }
+    __syncthreads();
+    for (int k = 2; k <= CAP; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < CAP; i += nt) {
+                const int x = i ^ j;
+                if (x > i) {
+                    const uint32_t ka = sh.keys[i], kb = sh.keys[x];
+                    const int ia = sh.idx[i], ib = sh.idx[x];
+                    const bool a_first = ka > kb || (ka == kb && ia < ib);
+                    const bool want_a_first = (i & k) == 0;
+                    if (a_first != want_a_first) { sh.keys[i] = kb; sh.keys[x] = ka; sh.idx[i] = ib; sh.idx[x] = ia; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    return cnt;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// workspace
+// ---------------------------------------------------------------------------------------------------
+struct NmsWs {
+    int* counters;       // [0] = K (anchors over threshold)  [1] = scratch
+    uint8_t* flag;       // [N]
+    int* keep_idx;       // [N]   compacted anchor indices, ascending
+    float* boxes_k;      // [N][4] decoded + clipped boxes of the kept anchors
+    float* scores_t;     // [C-1][N] class-major scores of the kept anchors (background dropped)
+    int* top_idx;        // [C-1][TOPK_CAP] index into the compacted list
+    float* top_score;    // [C-1][TOPK_CAP]
+    int* top_cnt;        // [C-1]
+    uint8_t* col_keep;   // [C-1][TOPK_CAP]
+    size_t bytes;
+};
+
+inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+NmsWs carve(void* base, int N, int C) {
+    NmsWs w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = (char*)base + off; off += align_up(bytes); return (void*)p; };
+    w.counters = (int*)take(64 * sizeof(int));
+    w.flag = (uint8_t*)take((size_t)N);
+    w.keep_idx = (int*)take((size_t)N * sizeof(int));
+    w.boxes_k = (float*)take((size_t)N * 4 * sizeof(float));
+    w.scores_t = (float*)take((size_t)(C - 1) * N * sizeof(float));
+    w.top_idx = (int*)take((size_t)(C - 1) * TOPK_CAP * sizeof(int));
+    w.top_score = (float*)take((size_t)(C - 1) * TOPK_CAP * sizeof(float));
+    w.top_cnt = (int*)take((size_t)(C - 1) * sizeof(int));
+    w.col_keep = (uint8_t*)take((size_t)(C - 1) * TOPK_CAP);
+    w.bytes = off;
+    return w;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stage A: score filter, ordered compaction, decode + transpose  (utils/output_utils.py:135-153)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_score_flag(const float* __restrict__ cls, int N, int C, float thre,
+                                                     uint8_t* __restrict__ flag) {
+    const int lane = threadIdx.x & 63;
+    const int wave0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    for (int a = wave0; a < N; a += nw) {
+        const float* row = cls + (size_t)a * C;
+        float m = -INFINITY;
+        for (int c = 1 + lane; c < C; c += 64) m = fmaxf(m, row[c]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) flag[a] = m > thre ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_compact(const uint8_t* __restrict__ flag, int N, int* __restrict__ keep_idx,
+                                                int* __restrict__ counters) {
+    __shared__ int wave_tot[NT / 64];
+    __shared__ int running;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) running = 0;
+    __syncthreads();
+    for (int base = 0; base < N; base += NT) {
+        const int i = base + tid;
+        const bool f = i < N && flag[i];
+        const unsigned long long bal = __ballot(f);
+        const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wv] = __popcll(bal);
+        __syncthreads();
+        int off = running;
+        for (int w = 0; w < wv; ++w) off += wave_tot[w];
+        if (f) keep_idx[off + pre] = i;
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int w = 0; w < NT / 64; ++w) t += wave_tot[w]; running += t; }
+        __syncthreads();
+    }
+    if (tid == 0) counters[0] = running;
+}
+
+__global__ __launch_bounds__(256) void k_decode_transpose(const float* __restrict__ cls, const float* __restrict__ box,
+                                                           const float* __restrict__ anchors, int N, int C,
+                                                           const int* __restrict__ keep_idx, const int* __restrict__ counters,
+                                                           float* __restrict__ boxes_k, float* __restrict__ scores_t) {
+    extern __shared__ float tile[];  // [64][C]
+    const int K = counters[0];
+    const int k0 = blockIdx.x * 64;
+    if (k0 >= K) return;
+    const int tid = threadIdx.x, CC = C - 1;
+    if (tid < 64 && k0 + tid < K) {
+        const int a = keep_idx[k0 + tid];
+        const f32x4 an = *reinterpret_cast<const f32x4*>(anchors + (size_t)a * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(box + (size_t)a * 4);
+        const float cx = an[0] + (b[0] * 0.1f) * an[2];
+        const float cy = an[1] + (b[1] * 0.1f) * an[3];
+        const float w = an[2] * (float)exp((double)(b[2] * 0.2f));
+        const float h = an[3] * (float)exp((double)(b[3] * 0.2f));
+        float x1 = cx - w / 2.f, y1 = cy - h / 2.f;
+        float x2 = w + x1, y2 = h + y1;
+        auto clip01 = [](float v) { return v != v ? v : fminf(fmaxf(v, 0.f), 1.f); };
+        f32x4 o = {clip01(x1), clip01(y1), clip01(x2), clip01(y2)};
+        *reinterpret_cast<f32x4*>(boxes_k + (size_t)(k0 + tid) * 4) = o;
+    }
+    for (int e = tid; e < 64 * CC; e += 256) {
+        const int r = e / CC, c = e - r * CC;
+        tile[r * C + c] = (k0 + r < K) ? cls[(size_t)keep_idx[k0 + r] * C + 1 + c] : 0.f;
+    }
+    __syncthreads();
+    for (int e = tid; e < 64 * CC; e += 256) {
+        const int c = e >> 6, r = e & 63;
+        if (k0 + r < K) scores_t[(size_t)c * N + k0 + r] = tile[r * C + c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stage B: per-class top-k + IoU column test  (utils/output_utils.py:12-26)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_class_topk_iou(const NmsWs w, int N, int top_k, float iou_thre) {
+    __shared__ TopkShared<TOPK_CAP> sh;
+    __shared__ __attribute__((aligned(16))) float sbox[TOPK_CAP * 4];
+    const int K = w.counters[0];
+    if (K == 0) return;
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const float* srow = w.scores_t + (size_t)c * N;
+    const int cnt = block_topk_sorted<TOPK_CAP>([&](int i) { return f2key(srow[i]); }, K, top_k, sh);
+    for (int j = tid; j < cnt; j += NT) {
+        const int k = sh.idx[j];
+        w.top_idx[c * TOPK_CAP + j] = k;
+        w.top_score[c * TOPK_CAP + j] = key2f(sh.keys[j]);
+        *reinterpret_cast<f32x4*>(sbox + j * 4) = *reinterpret_cast<const f32x4*>(w.boxes_k + (size_t)k * 4);
+    }
+    if (tid == 0) w.top_cnt[c] = cnt;
+    __syncthreads();
+    // wavefront reduction: one wave per column j, lanes stride over the higher-scored rows i < j.
+    // keep[j] = max_i<j IoU(i,j) <= thre with torch.max's NaN propagation  <=>  every IoU(i,j) <= thre.
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int j = wv; j < cnt; j += NT / 64) {
+        const f32x4 bj = *reinterpret_cast<const f32x4*>(sbox + j * 4);
+        bool bad = false;
+        for (int i = lane; i < j; i += 64) {
+            const f32x4 bi = *reinterpret_cast<const f32x4*>(sbox + i * 4);
+            const float v = iou_pair(bi, bj);
+            bad |= !(v <= iou_thre);
+        }
+        const bool any_bad = __any(bad);
+        if (lane == 0) w.col_keep[c * TOPK_CAP + j] = any_bad ? 0 : 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stage C: global top max_det over the kept (class, rank) pairs + gather  (utils/output_utils.py:31-43)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_final_topk(const NmsWs w, int ncls, int max_det, const float* __restrict__ coef,
+                                                   int coef_dim, int32_t* __restrict__ out_count,
+                                                   int64_t* __restrict__ out_ids, float* __restrict__ out_scores,
+                                                   float* __restrict__ out_boxes, float* __restrict__ out_coefs) {
+    __shared__ TopkShared<DET_CAP> sh;
+    __shared__ int n_valid;
+    const int tid = threadIdx.x;
+    const int K = w.counters[0];
+    if (K == 0) {
+        if (tid == 0) out_count[0] = 0;
+        return;
+    }
+    const int L = ncls * TOPK_CAP;
+    auto key_at = [&](int f) -> uint32_t {
+        const int c = f / TOPK_CAP, j = f - c * TOPK_CAP;
+        if (j < w.top_cnt[c] && w.col_keep[f]) return f2key(w.top_score[f]);
+        return 0u;
+    };
+    block_topk_sorted<DET_CAP>(key_at, L, max_det, sh);
+    if (tid == 0) n_valid = 0;
+    __syncthreads();
+    if (tid < max_det && sh.keys[tid] != 0u) atomicAdd(&n_valid, 1);
+    __syncthreads();
+    const int n = n_valid;
+    if (tid == 0) out_count[0] = n;
+    for (int j = tid; j < n; j += NT) {
+        const int f = sh.idx[j];
+        const int c = f / TOPK_CAP;
+        const int k = w.top_idx[f];
+        out_ids[j] = c;
+        out_scores[j] = key2f(sh.keys[j]);
+        *reinterpret_cast<f32x4*>(out_boxes + j * 4) = *reinterpret_cast<const f32x4*>(w.boxes_k + (size_t)k * 4);
+    }
+    for (int e = tid; e < n * coef_dim; e += NT) {
+        const int j = e / coef_dim, d = e - j * coef_dim;
+        const int a = w.keep_idx[w.top_idx[sh.idx[j]]];
+        out_coefs[e] = coef[(size_t)a * coef_dim + d];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// greedy NMS (cython_nms.pyx:24-74): rank by counting -> sorted order -> sequential suppression
+// ---------------------------------------------------------------------------------------------------
+// order: score descending, ties by HIGHER index first (argsort()[::-1] of a stable ascending sort).
+__device__ __forceinline__ bool greedy_before(float sa, int ia, float sb, int ib) {
+    return sa > sb || (sa == sb && ia > ib);
+}
+
+// One block handles one list of n detections given as (box[4], score) with element accessor lambdas.
+// sorted_box/sorted_id/alive are global scratch of n entries each.
+template <typename BoxAt, typename ScoreAt>
+__device__ void block_greedy_nms(BoxAt box_at, ScoreAt score_at, int n, float thresh, float scale,
+                                 float* sorted_box, int* sorted_id, uint8_t* alive) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < n; i += nt) {
+        const float s = score_at(i);
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += greedy_before(score_at(j), j, s, i) ? 1 : 0;
+        const f32x4 b = box_at(i);
+        f32x4 sb = {b[0] * scale, b[1] * scale, b[2] * scale, b[3] * scale};
+        *reinterpret_cast<f32x4*>(sorted_box + (size_t)rank * 4) = sb;
+        sorted_id[rank] = i;
+        alive[rank] = 1;
+    }
+    __syncthreads();
+    for (int a = 0; a < n; ++a) {
+        if (alive[a]) {   // uniform: written before the previous barrier
+            const f32x4 bi = *reinterpret_cast<const f32x4*>(sorted_box + (size_t)a * 4);
+            const float iarea = (bi[2] - bi[0] + 1.f) * (bi[3] - bi[1] + 1.f);
+            for (int b = a + 1 + tid; b < n; b += nt) {
+                if (!alive[b]) continue;
+                const f32x4 bj = *reinterpret_cast<const f32x4*>(sorted_box + (size_t)b * 4);
+                const float xx1 = fmaxf(bi[0], bj[0]), yy1 = fmaxf(bi[1], bj[1]);
+                const float xx2 = fminf(bi[2], bj[2]), yy2 = fminf(bi[3], bj[3]);
+                float ww = xx2 - xx1 + 1.f, hh = yy2 - yy1 + 1.f;
+                ww = ww >= 0.f ? ww : 0.f;
+                hh = hh >= 0.f ? hh : 0.f;
+                const float inter = ww * hh;
+                const float jarea = (bj[2] - bj[0] + 1.f) * (bj[3] - bj[1] + 1.f);
+                const float ovr = __fdiv_rn(inter, (iarea + jarea) - inter);
+                if (ovr >= thresh) alive[b] = 0;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_greedy_standalone(const float* __restrict__ dets, int n, float thresh,
+                                                           uint8_t* __restrict__ keep_mask, int32_t* __restrict__ out_count,
+                                                           float* sorted_box, int* sorted_id, uint8_t* alive) {
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    block_greedy_nms(
+        [&](int i) { const float* d = dets + (size_t)i * 5; return f32x4{d[0], d[1], d[2], d[3]}; },
+        [&](int i) { return dets[(size_t)i * 5 + 4]; }, n, thresh, 1.f, sorted_box, sorted_id, alive);
+    for (int r = threadIdx.x; r < n; r += NT) {
+        keep_mask[sorted_id[r]] = alive[r];
+        if (alive[r]) atomicAdd(&cnt, 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && out_count) out_count[0] = cnt;
+}
+
+// per class: candidates = kept anchors with score[c] > thre (utils/output_utils.py:93-109)
+struct GreedyWs {
+    int* cand;          // [C-1][N] compacted-list indices of the class candidates (ascending)
+    int* cand_cnt;      // [C-1]
+    float* sorted_box;  // [C-1][N][4]
+    int* sorted_id;     // [C-1][N]
+    uint8_t* alive;     // [C-1][N]
+    uint8_t* kept;      // [C-1][N] kept flag by candidate position (ascending index order)
+};
+
+__global__ __launch_bounds__(NT) void k_greedy_per_class(const NmsWs w, const GreedyWs g, int N, float score_thre,
+                                                          float iou_thre, float img_size) {
+    __shared__ int wave_tot[NT / 64];
+    __shared__ int running;
+    const int K = w.counters[0];
+    if (K == 0) return;
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* srow = w.scores_t + (size_t)c * N;
+    int* cand = g.cand + (size_t)c * N;
+    if (tid == 0) running = 0;
+    __syncthreads();
+    for (int base = 0; base < K; base += NT) {
+        const int i = base + tid;
+        const bool f = i < K && srow[i] > score_thre;
+        const unsigned long long bal = __ballot(f);
+        const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wv] = __popcll(bal);
+        __syncthreads();
+        int off = running;
+        for (int x = 0; x < wv; ++x) off += wave_tot[x];
+        if (f) cand[off + pre] = i;
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int x = 0; x < NT / 64; ++x) t += wave_tot[x]; running += t; }
+        __syncthreads();
+    }
+    const int n = running;
+    if (tid == 0) g.cand_cnt[c] = n;
+    if (n == 0) return;
+    float* sbox = g.sorted_box + (size_t)c * N * 4;
+    int* sid = g.sorted_id + (size_t)c * N;
+    uint8_t* alive = g.alive + (size_t)c * N;
+    block_greedy_nms(
+        [&](int i) { return *reinterpret_cast<const f32x4*>(w.boxes_k + (size_t)cand[i] * 4); },
+        [&](int i) { return srow[cand[i]]; }, n, iou_thre, img_size, sbox, sid, alive);
+    uint8_t* kept = g.kept + (size_t)c * N;
+    for (int r = tid; r < n; r += NT) kept[sid[r]] = alive[r];
+}
+
+// global top max_det over all kept (class, candidate) pairs; flat order = class-major, ascending index
+// inside a class (torch.cat of idx[keep] with keep ascending, utils/output_utils.py:107-115).
+__global__ __launch_bounds__(NT) void k_greedy_final(const NmsWs w, const GreedyWs g, int N, int ncls, int max_det,
+                                                     float img_size, const float* __restrict__ coef, int coef_dim,
+                                                     int32_t* __restrict__ out_count, int64_t* __restrict__ out_ids,
+                                                     float* __restrict__ out_scores, float* __restrict__ out_boxes,
+                                                     float* __restrict__ out_coefs) {
+    __shared__ TopkShared<DET_CAP> sh;
+    __shared__ int n_valid;
+    const int tid = threadIdx.x;
+    const int K = w.counters[0];
+    if (K == 0) {
+        if (tid == 0) out_count[0] = 0;
+        return;
+    }
+    const long long Lfull = (long long)ncls * N;
+    const int L = (int)Lfull;
+    auto key_at = [&](int f) -> uint32_t {
+        const int c = f / N, p = f - c * N;
+        if (p < g.cand_cnt[c] && g.kept[f]) return f2key(w.scores_t[(size_t)c * N + g.cand[f]]);
+        return 0u;
+    };
+    block_topk_sorted<DET_CAP>(key_at, L, max_det, sh);
+    if (tid == 0) n_valid = 0;
+    __syncthreads();
+    if (tid < max_det && sh.keys[tid] != 0u) atomicAdd(&n_valid, 1);
+    __syncthreads();
+    const int n = n_valid;
+    if (tid == 0) out_count[0] = n;
+    for (int j = tid; j < n; j += NT) {
+        const int f = sh.idx[j];
+        const int c = f / N;
+        const int k = g.cand[f];
+        out_ids[j] = c;
+        out_scores[j] = key2f(sh.keys[j]);
+        // boxes[idx] / img_size of boxes * img_size (utils/output_utils.py:90,123)
+        const f32x4 b = *reinterpret_cast<const f32x4*>(w.boxes_k + (size_t)k * 4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = __fdiv_rn(b[e] * img_size, img_size);
+        *reinterpret_cast<f32x4*>(out_boxes + j * 4) = o;
+    }
+    for (int e = tid; e < n * coef_dim; e += NT) {
+        const int j = e / coef_dim, d = e - j * coef_dim;
+        const int a = w.keep_idx[g.cand[sh.idx[j]]];
+        out_coefs[e] = coef[(size_t)a * coef_dim + d];
+    }
+}
+
+size_t greedy_extra_bytes(int N, int C) {
+    const size_t cn = (size_t)(C - 1) * N;
+    return align_up(cn * 4) + align_up((size_t)(C - 1) * 4) + align_up(cn * 16) + align_up(cn * 4) + align_up(cn) + align_up(cn);
+}
+
+GreedyWs carve_greedy(void* base, int N, int C) {
+    GreedyWs g;
+    size_t off = 0;
+    const size_t cn = (size_t)(C - 1) * N;
+    auto take = [&](size_t bytes) { char* p = (char*)base + off; off += align_up(bytes); return (void*)p; };
+    g.cand = (int*)take(cn * 4);
+    g.cand_cnt = (int*)take((size_t)(C - 1) * 4);
+    g.sorted_box = (float*)take(cn * 16);
+    g.sorted_id = (int*)take(cn * 4);
+    g.alive = (uint8_t*)take(cn);
+    g.kept = (uint8_t*)take(cn);
+    return g;
+}
+
+int check_cfg(const ym_nms_cfg* cfg) {
+    YM_REQUIRE(cfg, "nms: null cfg");
+    YM_REQUIRE(cfg->num_anchors > 0 && cfg->num_classes >= 2 && cfg->num_classes <= 256, "nms: bad N/C");
+    YM_REQUIRE(cfg->top_k >= 1 && cfg->top_k <= TOPK_CAP, "nms: top_k must be 1..%d", TOPK_CAP);
+    YM_REQUIRE(cfg->max_det >= 1 && cfg->max_det <= DET_CAP, "nms: max_det must be 1..%d", DET_CAP);
+    YM_REQUIRE(cfg->coef_dim >= 1, "nms: coef_dim");
+    YM_REQUIRE((long long)(cfg->num_classes - 1) * cfg->num_anchors < (1ll << 31), "nms: N*C too large");
+    return YM_OK;
+}
+
+int run_stage_a(const float* cls, const float* box, const float* anchors, const ym_nms_cfg* cfg, const NmsWs& w,
+                hipStream_t st) {
+    const int N = cfg->num_anchors, C = cfg->num_classes;
+    int g1 = ym_cdiv(N, 4);
+    if (g1 > 2048) g1 = 2048;
+    hipLaunchKernelGGL(k_score_flag, dim3(g1), dim3(256), 0, st, cls, N, C, cfg->score_thre, w.flag);
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(NT), 0, st, w.flag, N, w.keep_idx, w.counters);
+    hipLaunchKernelGGL(k_decode_transpose, dim3(ym_cdiv(N, 64)), dim3(256), (size_t)64 * C * sizeof(float), st, cls, box,
+                       anchors, N, C, w.keep_idx, w.counters, w.boxes_k, w.scores_t);
+    return ym_check_launch("nms stage A");
+}
+
+}  // namespace
+
+extern "C" size_t ym_nms_workspace_bytes(const ym_nms_cfg* cfg) {
+    if (check_cfg(cfg) != YM_OK) return 0;
+    NmsWs w = carve(nullptr, cfg->num_anchors, cfg->num_classes);
+    return w.bytes + greedy_extra_bytes(cfg->num_anchors, cfg->num_classes);
+}
+
+extern "C" int ym_detect_fast_nms(const float* class_pred, const float* box_pred, const float* coef_pred,
+                                  const float* anchors, const ym_nms_cfg* cfg, int32_t* out_count, int64_t* out_ids,
+                                  float* out_scores, float* out_boxes, float* out_coefs, void* workspace,
+                                  size_t workspace_bytes, ym_stream_t s) {
+    int rc = check_cfg(cfg);
+    if (rc != YM_OK) return rc;
+    YM_REQUIRE(class_pred && box_pred && coef_pred && anchors && out_count && out_ids && out_scores && out_boxes &&
+                   out_coefs && workspace, "fast_nms: null pointer");
+    NmsWs w = carve(workspace, cfg->num_anchors, cfg->num_classes);
+    if (w.bytes > workspace_bytes) { ym_set_error("fast_nms: workspace %zu < %zu", workspace_bytes, w.bytes); return YM_ENOSPC; }
+    hipStream_t st = (hipStream_t)s;
+    rc = run_stage_a(class_pred, box_pred, anchors, cfg, w, st);
+    if (rc != YM_OK) return rc;
+    const int ncls = cfg->num_classes - 1;
+    hipLaunchKernelGGL(k_class_topk_iou, dim3(ncls), dim3(NT), 0, st, w, cfg->num_anchors, cfg->top_k, cfg->iou_thre);
+    hipLaunchKernelGGL(k_final_topk, dim3(1), dim3(NT), 0, st, w, ncls, cfg->max_det, coef_pred, cfg->coef_dim, out_count,
+                       out_ids, out_scores, out_boxes, out_coefs);
+    return ym_check_launch("fast_nms");
+}
+
+extern "C" int ym_detect_greedy_nms(const float* class_pred, const float* box_pred, const float* coef_pred,
+                                    const float* anchors, const ym_nms_cfg* cfg, int32_t* out_count, int64_t* out_ids,
+                                    float* out_scores, float* out_boxes, float* out_coefs, void* workspace,
+                                    size_t workspace_bytes, ym_stream_t s) {
+    int rc = check_cfg(cfg);
+    if (rc != YM_OK) return rc;
+    YM_REQUIRE(class_pred && box_pred && coef_pred && anchors && out_count && out_ids && out_scores && out_boxes &&
+                   out_coefs && workspace, "greedy_nms: null pointer");
+    const int N = cfg->num_anchors, C = cfg->num_classes;
+    NmsWs w = carve(workspace, N, C);
+    const size_t need = w.bytes + greedy_extra_bytes(N, C);
+    if (need > workspace_bytes) { ym_set_error("greedy_nms: workspace %zu < %zu", workspace_bytes, need); return YM_ENOSPC; }
+    GreedyWs g = carve_greedy((char*)workspace + w.bytes, N, C);
+    hipStream_t st = (hipStream_t)s;
+    rc = run_stage_a(class_pred, box_pred, anchors, cfg, w, st);
+    if (rc != YM_OK) return rc;
+    hipLaunchKernelGGL(k_greedy_per_class, dim3(C - 1), dim3(NT), 0, st, w, g, N, cfg->score_thre, cfg->iou_thre,
+                       cfg->img_size);
+    hipLaunchKernelGGL(k_greedy_final, dim3(1), dim3(NT), 0, st, w, g, N, C - 1, cfg->max_det, cfg->img_size, coef_pred,
+                       cfg->coef_dim, out_count, out_ids, out_scores, out_boxes, out_coefs);
+    return ym_check_launch("greedy_nms");
+}
+
+extern "C" size_t ym_greedy_nms_workspace_bytes(int n) {
+    if (n <= 0) return 256;
+    return align_up((size_t)n * 16) + align_up((size_t)n * 4) + align_up((size_t)n);
+}
+
+extern "C" int ym_greedy_nms(const float* dets, int n, float thresh, uint8_t* keep_mask, int32_t* out_count,
+                             void* workspace, size_t workspace_bytes, ym_stream_t s) {
+    YM_REQUIRE(n >= 0, "greedy_nms: n < 0");
+    if (n == 0) {
+        if (out_count) (void)hipMemsetAsync(out_count, 0, sizeof(int32_t), (hipStream_t)s);
+        return YM_OK;
+    }
+    YM_REQUIRE(dets && keep_mask && workspace, "greedy_nms: null pointer");
+    if (ym_greedy_nms_workspace_bytes(n) > workspace_bytes) { ym_set_error("greedy_nms: workspace too small"); return YM_ENOSPC; }
+    char* p = (char*)workspace;
+    float* sorted_box = (float*)p; p += align_up((size_t)n * 16);
+    int* sorted_id = (int*)p; p += align_up((size_t)n * 4);
+    uint8_t* alive = (uint8_t*)p;
+    hipLaunchKernelGGL(k_greedy_standalone, dim3(1), dim3(NT), 0, (hipStream_t)s, dets, n, thresh, keep_mask, out_count,
+                       sorted_box, sorted_id, alive);
+    return ym_check_launch("greedy_nms");
+}

@@ -1,0 +1,44 @@
+// Shared helpers for the gfx950 kernels of libyolact_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "yolact_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+void ym_set_error(const char* fmt, ...);
+
+#define YM_REQUIRE(cond, ...)                \
+    do {                                     \
+        if (!(cond)) {                       \
+            ym_set_error(__VA_ARGS__);       \
+            return YM_EINVAL;                \
+        }                                    \
+    } while (0)
+
+static inline int ym_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        ym_set_error("%s: %s", what, hipGetErrorString(e));
+        return YM_ELAUNCH;
+    }
+    return YM_OK;
+}
+
+static inline int ym_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Bijective XCD-aware remap (cdna guide T1): hardware places block b on XCD b % 8; give each XCD a
+// contiguous chunk of the logical tile space so neighbouring tiles share one L2.
+__device__ __forceinline__ int ym_xcd_remap(int bid, int nwg) {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+__device__ __forceinline__ float ym_apply_act(float v, int act) {
+    if (act == YM_ACT_RELU) return v < 0.f ? 0.f : v;   // NaN stays NaN, like torch.relu
+    if (act == YM_ACT_TANH) return tanhf(v);
+    return v;
+}

@@ -1,0 +1,297 @@
+"""Inference plan for `Yolact.forward` on one MI355X.
+
+Reference path being replaced: `/root/reference/modules/yolact.py:141-164` (backbone `modules/resnet.py:86-98`,
+FPN `modules/yolact.py:73-89`, ProtoNet `:49-53`, PredictionModule `:26-31`, cat + softmax `:155-163`).
+
+The plan is built once per (batch, H, W): it owns every activation buffer in HBM (NHWC fp32, never freed
+or re-allocated while serving), the packed weight images ([Cout][kh][kw][Cin], BN folded to scale/shift) and
+one `ym_conv_desc` per layer, and then replays a fixed list of C-ABI launches on the current stream —
+optionally captured once into a hipGraph (`YM_GRAPH=1`, default) so a bs=1 forward is one graph launch
+instead of ~150 kernel launches.
+
+Fusions (what never touches HBM as a separate tensor):
+  conv + BN + ReLU                  -> one launch          (resnet.py:23-31)
+  conv + BN + residual add + ReLU   -> one launch          (resnet.py:33-38)
+  conv + bias + ReLU / + top-down add (FPN lateral)        (yolact.py:74-84)
+  bbox | conf | coef convs + tanh + permute + reshape + cat over levels -> one 351-channel launch per level
+                                     writing straight into the [B, N, C] outputs (yolact.py:27-30,155-157)
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from . import hip
+from .hip import ConvDesc, ACT_NONE, ACT_RELU, ACT_TANH
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class _Conv:
+    """One fused convolution: packed parameters + static descriptor."""
+
+    def __init__(self, name, convs, bn=None, act=ACT_NONE, stem=False):
+        self.name = name
+        self.convs = convs if isinstance(convs, (list, tuple)) else [convs]   # >1: concatenated along Cout
+        self.bn = bn
+        self.act = act
+        self.stem = stem
+        c0 = self.convs[0]
+        self.cin = c0.in_channels
+        self.kh, self.kw = c0.kernel_size
+        self.stride = c0.stride[0]
+        self.pad = c0.padding[0]
+        self.cout = sum(c.out_channels for c in self.convs)
+        self.cin_pad = 4 if stem else self.cin
+        self.k_pad = _round_up(self.kh * self.kw * self.cin_pad, 32)
+        self.weight = self.scale = self.shift = None
+        self.desc = None
+        self.tile = (0, 0)
+        self.ksplit = 0
+
+    def refresh(self):
+        """(Re)pack parameters from the nn.Modules into the kernel layout, on device."""
+        packed = [hip.pack_conv_weight(c.weight.detach().float(), self.cin_pad, self.k_pad) for c in self.convs]
+        self.weight = packed[0] if len(packed) == 1 else torch.cat(packed, 0).contiguous()
+        if self.bn is not None:
+            bn = self.bn
+            self.scale, self.shift = hip.fold_bn(bn.weight.detach().float().contiguous(),
+                                                 bn.bias.detach().float().contiguous(),
+                                                 bn.running_mean.float().contiguous(),
+                                                 bn.running_var.float().contiguous(), float(bn.eps))
+        else:
+            self.scale = None
+            biases = [c.bias for c in self.convs]
+            if all(b is None for b in biases):
+                self.shift = None
+            else:
+                self.shift = torch.cat([b.detach().float() for b in biases]).contiguous()
+        if self.desc is not None:
+            self._bind_params()
+
+    def _bind_params(self):
+        d = self.desc
+        d.weight = self.weight.data_ptr()
+        d.scale = self.scale.data_ptr() if self.scale is not None else None
+        d.shift = self.shift.data_ptr() if self.shift is not None else None
+
+    def bind(self, x, segs, residual=None):
+        """x: NHWC input buffer; segs: list of (n_begin, n_end, tensor_base_ptr, batch_stride, pitch, act)."""
+        b, h, w, cin = x.shape
+        assert cin == self.cin_pad, (self.name, cin, self.cin_pad)
+        ho = (h + 2 * self.pad - self.kh) // self.stride + 1
+        wo = (w + 2 * self.pad - self.kw) // self.stride + 1
+        d = ConvDesc()
+        d.inp = x.data_ptr()
+        d.residual = residual.data_ptr() if residual is not None else None
+        d.B, d.H, d.W, d.Cin, d.Cout = b, h, w, cin, self.cout
+        d.KH, d.KW, d.stride, d.pad, d.Ho, d.Wo, d.k_pad = self.kh, self.kw, self.stride, self.pad, ho, wo, self.k_pad
+        d.nseg = len(segs)
+        for i, (n0, n1, base_ptr, bstride, pitch, act) in enumerate(segs):
+            d.seg[i].n_begin, d.seg[i].n_end = n0, n1
+            d.seg[i].out = base_ptr
+            d.seg[i].batch_stride, d.seg[i].pitch, d.seg[i].act = bstride, pitch, act
+        d.tile_m, d.tile_n = self.tile
+        d.ksplit = self.ksplit
+        self.desc = d
+        self._bind_params()
+        self.out_hw = (ho, wo)
+        self.flops = 2.0 * b * ho * wo * self.cout * self.kh * self.kw * self.cin
+        return ho, wo
+
+
+class InferEngine:
+    def __init__(self, net, batch, height, width, device, use_graph=None):
+        self.net = net
+        self.device = device
+        self.B, self.H, self.W = batch, height, width
+        self.num_classes = net.cfg.num_classes
+        self.coef_dim = net.coef_dim
+        self.na = len(net.cfg.aspect_ratios)
+        if use_graph is None:
+            use_graph = os.environ.get('YM_GRAPH', '1') != '0'
+        self.use_graph = use_graph
+        self.graph = None
+        self.ops = []          # list of zero-arg callables (one C-ABI launch each)
+        self.convs = []        # every _Conv, for weight refresh / flop accounting
+        self._weights_epoch = -1
+        self._bufs = []
+        hip.lib()              # fail loudly here if the .so is missing
+        with torch.cuda.device(device):
+            self._build()
+
+    # ---- construction ------------------------------------------------------------------------
+    def _buf(self, *shape):
+        t = torch.empty(*shape, device=self.device, dtype=torch.float32)
+        self._bufs.append(t)
+        return t
+
+    def _conv(self, layer, x, out=None, residual=None, segs=None):
+        """Register a fused conv launch; returns its NHWC output buffer."""
+        b, h, w, _ = x.shape
+        ho = (h + 2 * layer.pad - layer.kh) // layer.stride + 1
+        wo = (w + 2 * layer.pad - layer.kw) // layer.stride + 1
+        if segs is None:
+            if out is None:
+                out = self._buf(b, ho, wo, layer.cout)
+            segs = [(0, layer.cout, out.data_ptr(), ho * wo * layer.cout, layer.cout, layer.act)]
+        layer.bind(x, segs, residual)
+        self.convs.append(layer)
+        self.ops.append(('conv', layer))
+        return out
+
+    def _build(self):
+        net, B, H, W = self.net, self.B, self.H, self.W
+        bb = net.backbone
+        self.x_in = self._buf(B, H, W, 4)
+        self.static_img = None
+
+        # stem + maxpool
+        stem = _Conv('backbone.conv1', bb.conv1, bb.bn1, ACT_RELU, stem=True)
+        x = self._conv(stem, self.x_in)
+        hp, wp = (x.shape[1] + 2 - 3) // 2 + 1, (x.shape[2] + 2 - 3) // 2 + 1
+        pooled = self._buf(B, hp, wp, 64)
+        self.ops.append(('maxpool', (x, pooled)))
+        x = pooled
+
+        # residual stages
+        stage_outs = []
+        for li, stage in enumerate(bb.layers):
+            for bi, blk in enumerate(stage):
+                p = f'backbone.layers.{li}.{bi}'
+                y = self._conv(_Conv(p + '.conv1', blk.conv1, blk.bn1, ACT_RELU), x)
+                y = self._conv(_Conv(p + '.conv2', blk.conv2, blk.bn2, ACT_RELU), y)
+                if blk.downsample is not None:
+                    skip = self._conv(_Conv(p + '.downsample', blk.downsample[0], blk.downsample[1], ACT_NONE), x)
+                else:
+                    skip = x
+                x = self._conv(_Conv(p + '.conv3', blk.conv3, blk.bn3, ACT_RELU), y, residual=skip)
+            stage_outs.append(x)
+        c3, c4, c5 = stage_outs[1:4]
+
+        # FPN (top-down adds fused as the lateral conv's residual)
+        fpn = net.fpn
+        p5_1 = self._conv(_Conv('fpn.lat_layers.2', fpn.lat_layers[2]), c5)
+        u5 = self._buf(B, p5_1.shape[1] * 2, p5_1.shape[2] * 2, 256)
+        self.ops.append(('bilinear', (p5_1, u5, False)))
+        assert u5.shape[1:3] == c4.shape[1:3], 'img_size must be divisible by 32 (reference config.py:75)'
+        p4_1 = self._conv(_Conv('fpn.lat_layers.1', fpn.lat_layers[1]), c4, residual=u5)
+        u4 = self._buf(B, p4_1.shape[1] * 2, p4_1.shape[2] * 2, 256)
+        self.ops.append(('bilinear', (p4_1, u4, False)))
+        p3_1 = self._conv(_Conv('fpn.lat_layers.0', fpn.lat_layers[0]), c3, residual=u4)
+        p5 = self._conv(_Conv('fpn.pred_layers.2', fpn.pred_layers[2][0], act=ACT_RELU), p5_1)
+        p4 = self._conv(_Conv('fpn.pred_layers.1', fpn.pred_layers[1][0], act=ACT_RELU), p4_1)
+        p3 = self._conv(_Conv('fpn.pred_layers.0', fpn.pred_layers[0][0], act=ACT_RELU), p3_1)
+        p6 = self._conv(_Conv('fpn.downsample_layers.0', fpn.downsample_layers[0][0], act=ACT_RELU), p5)
+        p7 = self._conv(_Conv('fpn.downsample_layers.1', fpn.downsample_layers[1][0], act=ACT_RELU), p6)
+        levels = [p3, p4, p5, p6, p7]
+
+        # ProtoNet
+        pn = net.proto_net
+        y = p3
+        for i in (0, 2, 4):
+            y = self._conv(_Conv(f'proto_net.proto1.{i}', pn.proto1[i], act=ACT_RELU), y)
+        up = self._buf(B, y.shape[1] * 2, y.shape[2] * 2, 256)
+        self.ops.append(('bilinear', (y, up, True)))
+        y = self._conv(_Conv('proto_net.proto2.0', pn.proto2[0], act=ACT_RELU), up)
+        self.proto_out = self._conv(_Conv('proto_net.proto2.2', pn.proto2[2], act=ACT_RELU), y)  # NHWC = [B,Hp,Wp,32]
+
+        # shared head, written straight into the concatenated outputs
+        hd = net.prediction_layers
+        nc, cd, na = self.num_classes, self.coef_dim, self.na
+        n_total = sum(lv.shape[1] * lv.shape[2] * na for lv in levels)
+        assert n_total * 4 == len(net.anchors) or not isinstance(net.anchors, list), 'anchor count mismatch'
+        self.n_anchors = n_total
+        self.class_logits = self._buf(B, n_total, nc)
+        self.class_pred = self._buf(B, n_total, nc)
+        self.box_pred = self._buf(B, n_total, 4)
+        self.coef_pred = self._buf(B, n_total, cd)
+        off = 0
+        for li, lv in enumerate(levels):
+            xh = self._conv(_Conv(f'prediction_layers.upfeature@P{li + 3}', hd.upfeature[0], act=ACT_RELU), lv)
+            fused = _Conv(f'prediction_layers.conf|bbox|coef@P{li + 3}', [hd.conf_layer, hd.bbox_layer, hd.coef_layer[0]])
+            c_conf, c_box, c_coef = na * nc, na * 4, na * cd
+            es = 4  # bytes per float
+            segs = [
+                (0, c_conf, self.class_logits.data_ptr() + off * nc * es, n_total * nc, c_conf, ACT_NONE),
+                (c_conf, c_conf + c_box, self.box_pred.data_ptr() + off * 4 * es, n_total * 4, c_box, ACT_NONE),
+                (c_conf + c_box, c_conf + c_box + c_coef, self.coef_pred.data_ptr() + off * cd * es, n_total * cd,
+                 c_coef, ACT_TANH),
+            ]
+            self._conv(fused, xh, segs=segs)
+            off += lv.shape[1] * lv.shape[2] * na
+        self.ops.append(('softmax', (self.class_logits, self.class_pred)))
+
+        ws_bytes = max([hip.conv_workspace_bytes(c.desc) for c in self.convs] + [256])
+        self.workspace = torch.empty(ws_bytes, device=self.device, dtype=torch.uint8)
+        self.total_flops = sum(c.flops for c in self.convs)
+
+    # ---- execution ---------------------------------------------------------------------------
+    def refresh_weights(self):
+        seen = set()
+        for c in self.convs:
+            key = id(c.convs[0]), c.name.split('@')[0]
+            c.refresh()
+            seen.add(key)
+        self._weights_epoch = self.net._weights_epoch
+        self.graph = None
+
+    def retune(self):
+        """Re-read tile/ksplit knobs of every conv into its descriptor (after changing `layer.tile/ksplit`)."""
+        for c in self.convs:
+            c.desc.tile_m, c.desc.tile_n = c.tile
+            c.desc.ksplit = c.ksplit
+        ws_bytes = max([hip.conv_workspace_bytes(c.desc) for c in self.convs] + [256])
+        if ws_bytes > self.workspace.numel():
+            self.workspace = torch.empty(ws_bytes, device=self.device, dtype=torch.uint8)
+        self.graph = None
+
+    def _launch_all(self, img):
+        hip.nchw_to_nhwc4(img, self.x_in)
+        ws = self.workspace
+        for kind, arg in self.ops:
+            if kind == 'conv':
+                hip.conv2d_fwd(arg.desc, ws)
+            elif kind == 'maxpool':
+                hip.maxpool3x3s2(arg[0], arg[1])
+            elif kind == 'bilinear':
+                hip.bilinear2x(arg[0], arg[1], arg[2])
+            elif kind == 'softmax':
+                hip.softmax_rows(arg[0], arg[1])
+
+    def run(self, img):
+        """Launch the plan; results land in the engine-owned buffers (no allocation, no sync)."""
+        if img.dtype != torch.float32 or not img.is_contiguous():
+            img = img.float().contiguous()
+        if tuple(img.shape) != (self.B, 3, self.H, self.W):
+            raise RuntimeError(f'engine built for {(self.B, 3, self.H, self.W)}, got {tuple(img.shape)}')
+        if self._weights_epoch != self.net._weights_epoch:
+            self.refresh_weights()
+        if not self.use_graph:
+            self._launch_all(img)
+            return
+        if self.graph is None:
+            self.static_img = torch.empty_like(img)
+            self.static_img.copy_(img)
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._launch_all(self.static_img)          # warm-up outside capture
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._launch_all(self.static_img)
+            self.graph = g
+        self.static_img.copy_(img)
+        self.graph.replay()
+
+    def outputs(self):
+        return self.class_pred, self.box_pred, self.coef_pred, self.proto_out
+
+    def forward(self, img):
+        self.run(img)
+        return tuple(t.clone() for t in self.outputs())

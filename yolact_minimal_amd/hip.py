@@ -1,0 +1,178 @@
+"""ctypes binding of the C-ABI in include/yolact_hip.h (libyolact_hip.so, gfx950).
+
+This is the only place Python touches the native library.  Every wrapper takes torch CUDA tensors
+(torch is used for device memory and streams only), checks dtype/contiguity, and passes raw device
+pointers + sizes + the current HIP stream.  There is deliberately NO fallback: if the shared library
+is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'libyolact_hip.so')
+
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+
+# every symbol include/yolact_hip.h declares (checked by tests/test_abi.py without a GPU)
+ABI_SYMBOLS = (
+    'ym_abi_version', 'ym_last_error', 'ym_nchw_to_nhwc4', 'ym_pack_conv_weight', 'ym_fold_bn',
+    'ym_conv2d_workspace_bytes', 'ym_conv2d_fwd', 'ym_maxpool3x3s2_fwd', 'ym_bilinear2x_fwd',
+    'ym_softmax_rows', 'ym_nms_workspace_bytes', 'ym_detect_fast_nms', 'ym_detect_greedy_nms',
+    'ym_greedy_nms_workspace_bytes', 'ym_greedy_nms', 'ym_mask_assemble', 'ym_mask_resize_binarize',
+    'ym_boxes_to_pixels',
+)
+
+
+class ConvSeg(ctypes.Structure):
+    _fields_ = [('n_begin', ctypes.c_int), ('n_end', ctypes.c_int), ('out', ctypes.c_void_p),
+                ('batch_stride', ctypes.c_int64), ('pitch', ctypes.c_int32), ('act', ctypes.c_int32)]
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [('inp', ctypes.c_void_p), ('weight', ctypes.c_void_p), ('scale', ctypes.c_void_p),
+                ('shift', ctypes.c_void_p), ('residual', ctypes.c_void_p),
+                ('B', ctypes.c_int32), ('H', ctypes.c_int32), ('W', ctypes.c_int32), ('Cin', ctypes.c_int32),
+                ('Cout', ctypes.c_int32), ('KH', ctypes.c_int32), ('KW', ctypes.c_int32),
+                ('stride', ctypes.c_int32), ('pad', ctypes.c_int32), ('Ho', ctypes.c_int32),
+                ('Wo', ctypes.c_int32), ('k_pad', ctypes.c_int32), ('nseg', ctypes.c_int32),
+                ('seg', ConvSeg * 3), ('tile_m', ctypes.c_int32), ('tile_n', ctypes.c_int32),
+                ('ksplit', ctypes.c_int32)]
+
+
+class NmsCfg(ctypes.Structure):
+    _fields_ = [('num_anchors', ctypes.c_int32), ('num_classes', ctypes.c_int32), ('coef_dim', ctypes.c_int32),
+                ('top_k', ctypes.c_int32), ('max_det', ctypes.c_int32), ('score_thre', ctypes.c_float),
+                ('iou_thre', ctypes.c_float), ('img_size', ctypes.c_float)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libyolact_hip.so once; raise (never fall back) if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                f'(or `make -C yolact_minimal_amd/csrc`). yolact_minimal_amd has no non-HIP fallback.')
+        L = ctypes.CDLL(LIB_PATH)
+        vp, i32, i64, f32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
+        L.ym_abi_version.restype = ctypes.c_int
+        L.ym_last_error.restype = ctypes.c_char_p
+        L.ym_nchw_to_nhwc4.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+        L.ym_pack_conv_weight.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp]
+        L.ym_fold_bn.argtypes = [vp, vp, vp, vp, f32, vp, vp, i32, vp]
+        L.ym_conv2d_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
+        L.ym_conv2d_workspace_bytes.restype = sz
+        L.ym_conv2d_fwd.argtypes = [ctypes.POINTER(ConvDesc), vp, sz, vp]
+        L.ym_maxpool3x3s2_fwd.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+        L.ym_bilinear2x_fwd.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+        L.ym_softmax_rows.argtypes = [vp, vp, i64, i32, vp]
+        L.ym_nms_workspace_bytes.argtypes = [ctypes.POINTER(NmsCfg)]
+        L.ym_nms_workspace_bytes.restype = sz
+        nms_args = [vp, vp, vp, vp, ctypes.POINTER(NmsCfg), vp, vp, vp, vp, vp, vp, sz, vp]
+        L.ym_detect_fast_nms.argtypes = nms_args
+        L.ym_detect_greedy_nms.argtypes = nms_args
+        L.ym_greedy_nms_workspace_bytes.argtypes = [i32]
+        L.ym_greedy_nms_workspace_bytes.restype = sz
+        L.ym_greedy_nms.argtypes = [vp, i32, f32, vp, vp, vp, sz, vp]
+        L.ym_mask_assemble.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
+        L.ym_mask_resize_binarize.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
+        L.ym_boxes_to_pixels.argtypes = [vp, vp, i32, f32, vp]
+        for name in ABI_SYMBOLS:
+            fn = getattr(L, name)
+            if name not in ('ym_last_error', 'ym_conv2d_workspace_bytes', 'ym_nms_workspace_bytes',
+                            'ym_greedy_nms_workspace_bytes'):
+                fn.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f'{what} failed (rc={rc}): {lib().ym_last_error().decode()}')
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, dtype=torch.float32):
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+        raise RuntimeError(f'expected a contiguous {dtype} CUDA tensor, got {t.dtype} {t.device} '
+                           f'contiguous={t.is_contiguous()}')
+    return ctypes.c_void_p(t.data_ptr())
+
+
+# ---- thin per-op wrappers (used by engine.py, utils/output_utils.py and the tests) ----------------
+
+def nchw_to_nhwc4(img, out):
+    b, c, h, w = img.shape
+    check(lib().ym_nchw_to_nhwc4(ptr(img), ptr(out), b, c, h, w, stream_ptr()), 'ym_nchw_to_nhwc4')
+
+
+def pack_conv_weight(w_oihw, cin_pad, k_pad):
+    cout, cin, kh, kw = w_oihw.shape
+    out = torch.empty(cout, k_pad, device=w_oihw.device, dtype=torch.float32)
+    check(lib().ym_pack_conv_weight(ptr(w_oihw.contiguous()), ptr(out), cout, cin, kh, kw, cin_pad, k_pad,
+                                    stream_ptr()), 'ym_pack_conv_weight')
+    return out
+
+
+def fold_bn(gamma, beta, mean, var, eps):
+    c = gamma.numel()
+    scale, shift = torch.empty_like(gamma), torch.empty_like(gamma)
+    check(lib().ym_fold_bn(ptr(gamma), ptr(beta), ptr(mean), ptr(var), eps, ptr(scale), ptr(shift), c,
+                           stream_ptr()), 'ym_fold_bn')
+    return scale, shift
+
+
+def conv_workspace_bytes(desc):
+    return lib().ym_conv2d_workspace_bytes(ctypes.byref(desc))
+
+
+def conv2d_fwd(desc, workspace=None):
+    ws_ptr = ctypes.c_void_p(workspace.data_ptr()) if workspace is not None else None
+    ws_bytes = workspace.numel() * workspace.element_size() if workspace is not None else 0
+    check(lib().ym_conv2d_fwd(ctypes.byref(desc), ws_ptr, ws_bytes, stream_ptr()), 'ym_conv2d_fwd')
+
+
+def maxpool3x3s2(x, out):
+    b, h, w, c = x.shape
+    check(lib().ym_maxpool3x3s2_fwd(ptr(x), ptr(out), b, h, w, c, stream_ptr()), 'ym_maxpool3x3s2_fwd')
+
+
+def bilinear2x(x, out, align_corners):
+    b, h, w, c = x.shape
+    check(lib().ym_bilinear2x_fwd(ptr(x), ptr(out), b, h, w, c, int(bool(align_corners)), stream_ptr()),
+          'ym_bilinear2x_fwd')
+
+
+def softmax_rows(x, out):
+    c = x.shape[-1]
+    rows = x.numel() // c
+    check(lib().ym_softmax_rows(ptr(x), ptr(out), rows, c, stream_ptr()), 'ym_softmax_rows')
+
+
+def mask_assemble(proto, coefs, boxes, out, do_crop=True):
+    hp, wp, k = proto.shape
+    n = coefs.shape[0]
+    check(lib().ym_mask_assemble(ptr(proto), ptr(coefs), ptr(boxes), n, hp, wp, k, int(do_crop), ptr(out),
+                                 stream_ptr()), 'ym_mask_assemble')
+
+
+def mask_resize_binarize(masks, img_h, img_w, out):
+    n, hp, wp = masks.shape
+    check(lib().ym_mask_resize_binarize(ptr(masks), n, hp, wp, img_h, img_w, ptr(out), stream_ptr()),
+          'ym_mask_resize_binarize')
+
+
+def boxes_to_pixels(boxes_f, boxes_px, size):
+    n = boxes_f.shape[0]
+    check(lib().ym_boxes_to_pixels(ptr(boxes_f), ptr(boxes_px, torch.int32), n, float(size), stream_ptr()),
+          'ym_boxes_to_pixels')

@@ -1,0 +1,157 @@
+"""`Yolact` with the reference's constructor / forward / state-dict surface, executed by HIP kernels.
+
+Reference: `/root/reference/modules/yolact.py` — PredictionModule `:12-31`, ProtoNet `:34-53`,
+FPN `:56-89`, Yolact `:92-164` (ctor `:93-125`, load_weights `:127-139`, forward `:141-164`).
+
+What is kept identical:
+  * `Yolact(cfg)`; backbone chosen from the cfg *class name*; `net.anchors` (flat python list);
+  * every parameter / buffer name and OIHW fp32 shape, created in the reference's order, so a seeded
+    construction is bit-identical and published `.pth` files load with `strict=True`;
+  * `forward(img, box_classes=None, masks_gt=None)`; eval returns
+    `(class_pred[B,N,C] softmaxed, box_pred[B,N,4], coef_pred[B,N,32], proto_out[B,Hp,Wp,32])`.
+
+What is different: no layer here computes anything in PyTorch.  `forward` hands the image to
+`yolact_minimal_amd.engine.InferEngine`, which runs NHWC fp32 implicit-GEMM convolutions on the
+f32 MFMA pipe with BN/bias/ReLU/residual/tanh fused in the epilogue, and writes the five head
+levels straight into the concatenated `[B, N, C]` outputs.  There is no eager/CPU fallback: a CPU
+tensor or a missing `libyolact_hip.so` raises.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .resnet import ResNet
+from ..utils.box_utils import make_anchors
+
+
+def _conv_relu(cin, cout, k, stride=1, padding=0):
+    # nn.ReLU is kept only so that state-dict indices match (`pred_layers.N.0`, `proto1.{0,2,4}`).
+    return nn.Sequential(nn.Conv2d(cin, cout, k, stride=stride, padding=padding), nn.ReLU(inplace=True))
+
+
+class PredictionModule(nn.Module):
+    """Shared head: upfeature 3x3+ReLU then bbox / conf / coef(tanh) 3x3 (reference :13-24)."""
+
+    def __init__(self, cfg, coef_dim=32):
+        super().__init__()
+        self.num_classes = cfg.num_classes
+        self.coef_dim = coef_dim
+        na = len(cfg.aspect_ratios)
+        self.upfeature = _conv_relu(256, 256, 3, padding=1)
+        self.bbox_layer = nn.Conv2d(256, na * 4, 3, padding=1)
+        self.conf_layer = nn.Conv2d(256, na * self.num_classes, 3, padding=1)
+        self.coef_layer = nn.Sequential(nn.Conv2d(256, na * coef_dim, 3, padding=1), nn.Tanh())
+
+
+class ProtoNet(nn.Module):
+    """3x(3x3+ReLU) -> bilinear x2 (align_corners=True) -> 3x3+ReLU -> 1x1+ReLU (reference :35-47)."""
+
+    def __init__(self, coef_dim):
+        super().__init__()
+        seq = []
+        for _ in range(3):
+            seq += list(_conv_relu(256, 256, 3, padding=1))
+        self.proto1 = nn.Sequential(*seq)
+        self.upsample = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)
+        self.proto2 = nn.Sequential(*_conv_relu(256, 256, 3, padding=1), *_conv_relu(256, coef_dim, 1))
+
+
+class FPN(nn.Module):
+    """Lateral 1x1, top-down bilinear x2 (align_corners=False) add, 3x3 pred, 2 stride-2 extras (:57-71)."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.in_channels = in_channels
+        self.lat_layers = nn.ModuleList(nn.Conv2d(c, 256, 1) for c in in_channels)
+        self.pred_layers = nn.ModuleList(_conv_relu(256, 256, 3, padding=1) for _ in in_channels)
+        self.downsample_layers = nn.ModuleList(_conv_relu(256, 256, 3, stride=2, padding=1)
+                                               for _ in range(2))
+
+
+class Yolact(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.coef_dim = 32
+
+        name = cfg.__class__.__name__
+        if name.startswith('res101'):
+            self.backbone = ResNet(layers=(3, 4, 23, 3))
+            self.fpn = FPN(in_channels=(512, 1024, 2048))
+        elif name.startswith('res50'):
+            self.backbone = ResNet(layers=(3, 4, 6, 3))
+            self.fpn = FPN(in_channels=(512, 1024, 2048))
+        elif name.startswith('swin_tiny'):
+            raise NotImplementedError(
+                'swin_tiny_* (SURVEY.md §8 row a18) is not built yet; res50_* / res101_* are.')
+        else:
+            raise ValueError(f'cannot derive a backbone from cfg class {name!r}')
+
+        self.proto_net = ProtoNet(coef_dim=self.coef_dim)
+        self.prediction_layers = PredictionModule(cfg, coef_dim=self.coef_dim)
+
+        # anchors: flat python list [cx, cy, w, h] * N, level-major, as the reference keeps them
+        self.fpn_fm_shape = [math.ceil(cfg.img_size / stride) for stride in (8, 16, 32, 64, 128)]
+        self.anchors = []
+        for size, scale in zip(self.fpn_fm_shape, cfg.scales):
+            self.anchors += make_anchors(cfg, size, size, scale)
+
+        if cfg.mode == 'train':
+            self.semantic_seg_conv = nn.Conv2d(256, cfg.num_classes - 1, kernel_size=1)
+
+        for module in self.modules():
+            if isinstance(module, nn.Conv2d):
+                nn.init.xavier_uniform_(module.weight.data)
+                if module.bias is not None:
+                    module.bias.data.zero_()
+
+        self._engines = {}
+        self._weights_epoch = 0
+
+    # ---- weights -----------------------------------------------------------------------------
+    def mark_weights_changed(self):
+        """Packed HBM weight images are rebuilt on the next forward."""
+        self._weights_epoch += 1
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.mark_weights_changed()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        if hasattr(self, '_engines'):
+            self._engines.clear()
+            self.mark_weights_changed()
+        return out
+
+    def load_weights(self, weight, cuda):
+        """Same contract as reference `:127-139`: strict load, train-only keys dropped in eval."""
+        state_dict = torch.load(weight) if cuda else torch.load(weight, map_location='cpu')
+        if self.cfg.mode != 'train':
+            for key in [k for k in state_dict if k.startswith('semantic_seg_conv')]:
+                del state_dict[key]
+        self.load_state_dict(state_dict, strict=True)
+        print(f'Model loaded with {weight}.\n')
+        print(f'Number of all parameters: {sum(p.numel() for p in self.parameters())}\n')
+
+    # ---- forward -----------------------------------------------------------------------------
+    def _engine(self, img):
+        from ..engine import InferEngine
+        key = (img.device.index, img.shape[0], img.shape[2], img.shape[3])
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = InferEngine(self, batch=img.shape[0], height=img.shape[2], width=img.shape[3],
+                              device=img.device)
+            self._engines[key] = eng
+        return eng
+
+    def forward(self, img, box_classes=None, masks_gt=None):
+        if not img.is_cuda:
+            raise RuntimeError('yolact_minimal_amd.Yolact runs on an MI355X only: got a CPU tensor and '
+                               'there is no CPU fallback (the CPU restatement lives in oracle/ and is '
+                               'test infrastructure).')
+        if self.training:
+            raise NotImplementedError('training forward (SURVEY.md §8 rows a12-a17) is not built yet')
+        return self._engine(img).forward(img)
