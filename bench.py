@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py — img/s of the YOLACT hot path on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
+    Yolact.forward(img[B,3,544,544])                         (HIP engine, hipGraph replay)
+    + for every image: nms() + after_nms(480x640)            (HIP kernels; on the dense synthetic head
+                                                              outputs of BASELINE.md §3, because a random-init
+                                                              network produces degenerate detection counts)
+Image size is 544 (the reference cannot run at 550: SURVEY.md §0.1).  Weights: seeded random init.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--cfg res101_coco] [--batch 1]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): inference does not shard — images are
+independent — so every rank runs an independent replica on its own batch ("replicas only", no data-path
+collective); the timed region is bracketed by barrier + synchronize and the MAX over ranks is reported.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--cfg', default='res101_coco')
+    ap.add_argument('--batch', type=int, default=1, help='images per GPU per step')
+    ap.add_argument('--img_size', type=int, default=544)
+    ap.add_argument('--no-post', action='store_true', help='time the network forward only')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip the bs=8 side measurements')
+    ap.add_argument('--local_rank', type=int, default=None)
+    return ap.parse_args()
+
+
+def build_net(cfg_name, img_size, device, seed=0):
+    from yolact_minimal_amd.config import build_cfg
+    from yolact_minimal_amd.modules.yolact import Yolact
+    cfg = build_cfg(cfg_name, 'val', img_size)
+    torch.manual_seed(seed)
+    net = Yolact(cfg).eval().to(device)
+    return net, cfg
+
+
+class Workload:
+    """forward(batch) + per-image post-processing, everything resident on the device."""
+
+    def __init__(self, net, cfg, batch, img_size, device, with_post=True, seed=0):
+        from oracle.yolact_ref import synth_head_outputs   # only its *input generator* is used here
+        self.net, self.cfg, self.batch, self.device = net, cfg, batch, device
+        g = torch.Generator().manual_seed(seed)
+        self.img = torch.randn(batch, 3, img_size, img_size, generator=g).to(device)
+        self.with_post = with_post
+        n_anchors = len(net.anchors) // 4
+        cls, box, coef, proto = synth_head_outputs(n_anchors, num_classes=cfg.num_classes, proto_hw=img_size // 4,
+                                                   seed=1)
+        self.head = [t.to(device) for t in (cls, box, coef, proto)]
+        self.anchors = torch.tensor(net.anchors, dtype=torch.float32).reshape(-1, 4).to(device)
+        self.engine = net._engine(self.img)
+
+    def step(self):
+        from yolact_minimal_amd.utils.output_utils import nms, after_nms
+        self.engine.run(self.img)
+        if self.with_post:
+            cls, box, coef, proto = self.head
+            for _ in range(self.batch):
+                r = nms(cls, box, coef, proto, self.anchors, self.cfg)
+                after_nms(r[0], r[1], r[2], r[3], r[4], 480, 640, self.cfg)
+
+
+def timed(workload, steps, warmup, barrier):
+    for _ in range(warmup):
+        workload.step()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        workload.step()
+    torch.cuda.synchronize()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def conv_roofline(engine, img, iters=5):
+    """Live HIP-event timing of every conv_igemm_f32 launch on the stream it is launched on (torch's current
+    stream), eager (no graph) so each launch can be bracketed.  Returns (flops per forward, seconds per forward,
+    launches per forward)."""
+    from yolact_minimal_amd import hip
+    convs = [arg for kind, arg in engine.ops if kind == 'conv']
+    ws = engine.workspace
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in convs]
+    total = 0.0
+    per_layer = [0.0] * len(convs)
+    for it in range(iters + 1):
+        hip.nchw_to_nhwc4(img, engine.x_in)
+        ci = 0
+        for kind, arg in engine.ops:
+            if kind == 'conv':
+                evs[ci][0].record()
+                hip.conv2d_fwd(arg.desc, ws)
+                evs[ci][1].record()
+                ci += 1
+            elif kind == 'maxpool':
+                hip.maxpool3x3s2(arg[0], arg[1])
+            elif kind == 'bilinear':
+                hip.bilinear2x(arg[0], arg[1], arg[2])
+            elif kind == 'softmax':
+                hip.softmax_rows(arg[0], arg[1])
+        torch.cuda.synchronize()
+        if it == 0:
+            continue   # warm-up
+        for i, (a, b) in enumerate(evs):
+            ms = a.elapsed_time(b)
+            per_layer[i] += ms
+            total += ms
+    secs = total / iters / 1e3
+    flops = sum(c.flops for c in convs)
+    layers = [dict(name=c.name, ms=per_layer[i] / iters, gflop=c.flops / 1e9) for i, c in enumerate(convs)]
+    return flops, secs, len(convs), layers
+
+
+def cpu_baseline(cfg_name, img_size):
+    """The CPU oracle (plain PyTorch-CPU restatement of the reference) timed on this host's cores, bounded sample."""
+    from oracle import yolact_ref as R
+    from yolact_minimal_amd.config import build_cfg
+    from yolact_minimal_amd.modules.yolact import Yolact
+    cfg = build_cfg(cfg_name, 'val', img_size)
+    torch.manual_seed(0)
+    sd = Yolact(cfg).eval().state_dict()
+    img = torch.randn(1, 3, img_size, img_size, generator=torch.Generator().manual_seed(0))
+    n_anchors = sum(((img_size + s - 1) // s) ** 2 * 3 for s in (8, 16, 32, 64, 128))
+    cls, box, coef, proto = R.synth_head_outputs(n_anchors, proto_hw=img_size // 4, seed=1)
+    anchors = R.anchors_for(img_size, cfg.scales)
+    n_img, t_fwd, t_nms, t_after = 0, 0.0, 0.0, 0.0
+    t_start = time.perf_counter()
+    with torch.no_grad():
+        R.forward_eval(img, sd)                       # warm-up
+        while n_img < 3 or (time.perf_counter() - t_start < 12 and n_img < 10):
+            t0 = time.perf_counter(); R.forward_eval(img, sd); t1 = time.perf_counter()
+            r = R.nms(cls, box, coef, proto, anchors); t2 = time.perf_counter()
+            R.after_nms(r[0], r[1], r[2], r[3], r[4], 480, 640); t3 = time.perf_counter()
+            t_fwd += t1 - t0; t_nms += t2 - t1; t_after += t3 - t2
+            n_img += 1
+    per = (t_fwd + t_nms + t_after) / n_img
+    return dict(value=round(1.0 / per, 3), unit='img/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'{n_img} images bs=1 {cfg_name}@{img_size}: oracle forward {t_fwd / n_img * 1e3:.0f} ms + nms '
+                       f'{t_nms / n_img * 1e3:.0f} ms + after_nms(480x640) {t_after / n_img * 1e3:.0f} ms on '
+                       f'{os.cpu_count()} host cpus ({torch.get_num_threads()} torch threads)')
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', args.local_rank or 0))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend='nccl', init_method='env://')   # nccl == RCCL on ROCm
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    net, cfg = build_net(args.cfg, args.img_size, device)
+    wl = Workload(net, cfg, args.batch, args.img_size, device, with_post=not args.no_post)
+    elapsed = timed(wl, args.steps, args.warmup, barrier)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    imgs = args.batch * args.steps * world
+    value = imgs / elapsed
+
+    out = None
+    if rank == 0:
+        # forward-only rate on the same engine, and the live conv roofline
+        fw = Workload(net, cfg, args.batch, args.img_size, device, with_post=False)
+        t_fwd = timed(fw, args.steps, 2, lambda: None) / args.steps
+        flops, conv_secs, launches, layers = conv_roofline(fw.engine, fw.img)
+        achieved = flops / conv_secs / 1e12
+        roofline = dict(bound='mfma', achieved=round(achieved, 2), peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+                        frac=round(achieved / F32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                        kernel='conv_igemm_f32 (all instantiations)', launches_per_step=launches,
+                        flops_per_launch=round(flops / launches), avg_launch_us=round(conv_secs / launches * 1e6, 2),
+                        conv_ms_per_step=round(conv_secs * 1e3, 3))
+        extra = dict(forward_only_ms=round(t_fwd * 1e3, 3),
+                     forward_only_img_s=round(args.batch / t_fwd, 1),
+                     forward_tflops=round(flops / t_fwd / 1e12, 2),
+                     gflop_per_img=round(flops / args.batch / 1e9, 1))
+        slow = sorted(layers, key=lambda l: -l['ms'])[:5]
+        extra['slowest_convs'] = [dict(name=l['name'], ms=round(l['ms'], 4), tflops=round(l['gflop'] / l['ms'], 1)) for l in slow]
+        if not args.no_extra and world == 1:
+            for name, b in ((args.cfg, 8), ('res50_coco', 8)):
+                n2, c2 = (net, cfg) if name == args.cfg else build_net(name, args.img_size, device)
+                w2 = Workload(n2, c2, b, args.img_size, device, with_post=not args.no_post)
+                t2 = timed(w2, 8, 2, lambda: None)
+                f2 = Workload(n2, c2, b, args.img_size, device, with_post=False)
+                tf2 = timed(f2, 8, 2, lambda: None) / 8
+                fl2 = f2.engine.total_flops
+                extra[f'{name}_bs{b}'] = dict(img_s=round(b * 8 / t2, 1), forward_only_img_s=round(b / tf2, 1),
+                                              forward_tflops=round(fl2 / tf2 / 1e12, 2),
+                                              frac_f32_mfma_peak=round(fl2 / tf2 / 1e12 / F32_MFMA_PEAK_TFLOPS, 4))
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.cfg, args.img_size)
+        out = {
+            'metric': f'img/s {args.cfg} 544x544 inference (bs={args.batch}/GPU)',
+            'value': round(value, 2), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{args.cfg} 544x544 (the reference\'s "550-class" size) bs={args.batch} inference: '
+                                   f'forward + nms + after_nms(480x640) per image' if not args.no_post else
+                                   f'{args.cfg} 544x544 bs={args.batch} forward only',
+                       'global_batch': args.batch * world, 'parallelism': f'replicas x{world} (inference does not shard)',
+                       'weights': 'seeded random init', 'post_inputs': 'synthetic dense head outputs (17.8k candidates)'},
+            'roofline': roofline, 'cpu_baseline': cpu, 'extra': extra,
+        }
+    barrier()
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

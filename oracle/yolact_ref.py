@@ -162,9 +162,15 @@ def decode(box_p, anchors):
     return torch.clip(torch.cat((x1y1, x2y2), 1), min=0., max=1.)
 
 
-def fast_nms(boxes, coefs, scores, top_k=200, iou_thre=0.5, max_det=100):
+def _sort_desc(t, dim, stable):
+    # torch.sort(descending=True) is unstable for n > 16 on CPU; `stable=True` pins ties to "lower index
+    # first", which is what the HIP kernels implement (the reference's tie order is implementation-defined).
+    return t.sort(dim=dim, descending=True, stable=True) if stable else t.sort(dim, descending=True)
+
+
+def fast_nms(boxes, coefs, scores, top_k=200, iou_thre=0.5, max_det=100, stable=False):
     """utils/output_utils.py:11-43. scores:[C,K] boxes:[K,4] coefs:[K,32]."""
-    scores, idx = scores.sort(1, descending=True)
+    scores, idx = _sort_desc(scores, 1, stable)
     idx, scores = idx[:, :top_k], scores[:, :top_k]
     ncls, ndet = idx.shape
     bx = boxes[idx.reshape(-1)].reshape(ncls, ndet, 4)
@@ -175,7 +181,7 @@ def fast_nms(boxes, coefs, scores, top_k=200, iou_thre=0.5, max_det=100):
     keep = iou_max <= iou_thre
     cls = torch.arange(ncls)[:, None].expand_as(keep)[keep]
     bx, cf, sc = bx[keep], cf[keep], scores[keep]
-    sc, order = sc.sort(0, descending=True)
+    sc, order = _sort_desc(sc, 0, stable)
     order, sc = order[:max_det], sc[:max_det]
     return bx[order], cf[order], cls[order], sc
 
@@ -204,7 +210,7 @@ def greedy_nms(dets, thresh):
     return keep[:n]
 
 
-def traditional_nms(boxes, coefs, scores, img_size, score_thre=0.05, iou_thre=0.5, max_det=100):
+def traditional_nms(boxes, coefs, scores, img_size, score_thre=0.05, iou_thre=0.5, max_det=100, stable=False):
     """utils/output_utils.py:84-123 — per-class greedy NMS on boxes scaled by img_size."""
     boxes = boxes * img_size
     idx_l, cls_l, scr_l = [], [], []
@@ -220,14 +226,14 @@ def traditional_nms(boxes, coefs, scores, img_size, score_thre=0.05, iou_thre=0.
         cls_l.append(torch.full_like(keep, c))
         scr_l.append(s[m][keep])
     idx, cls, scr = torch.cat(idx_l), torch.cat(cls_l), torch.cat(scr_l)
-    scr, order = scr.sort(0, descending=True)
+    scr, order = _sort_desc(scr, 0, stable)
     order, scr = order[:max_det], scr[:max_det]
     idx, cls = idx[order], cls[order]
     return boxes[idx] / img_size, coefs[idx], cls, scr
 
 
 def nms(class_pred, box_pred, coef_pred, proto_out, anchors, score_thre=0.05, iou_thre=0.5, top_k=200,
-        max_det=100, traditional=False, img_size=544):
+        max_det=100, traditional=False, img_size=544, stable=False):
     """utils/output_utils.py:126-163 (batch of one). Returns (ids, scores, boxes, coefs, proto) or 5x None."""
     cls = class_pred.squeeze(0).transpose(1, 0).contiguous()[1:]       # [C-1, N], background dropped
     box_p, coef_p, proto = box_pred.squeeze(0), coef_pred.squeeze(0), proto_out.squeeze(0)
@@ -238,9 +244,9 @@ def nms(class_pred, box_pred, coef_pred, proto_out, anchors, score_thre=0.05, io
     if cls_k.shape[1] == 0:
         return None, None, None, None, None
     if traditional:
-        bx, cf, ids, sc = traditional_nms(boxes, coefs, cls_k, img_size, score_thre, iou_thre, max_det)
+        bx, cf, ids, sc = traditional_nms(boxes, coefs, cls_k, img_size, score_thre, iou_thre, max_det, stable)
     else:
-        bx, cf, ids, sc = fast_nms(boxes, coefs, cls_k, top_k, iou_thre, max_det)
+        bx, cf, ids, sc = fast_nms(boxes, coefs, cls_k, top_k, iou_thre, max_det, stable)
     return ids, sc, bx, cf, proto
 
 

@@ -130,7 +130,8 @@ def test_conv_three_segments():
         d.seg[i].n_begin, d.seg[i].n_end = n0, n1
         d.seg[i].out = t.data_ptr() + off * c * 4
         d.seg[i].batch_stride, d.seg[i].pitch, d.seg[i].act = n_total * c, 3 * c, act
-    hip.conv2d_fwd(d, None)
+    ws = torch.empty(max(hip.conv_workspace_bytes(d), 256), dtype=torch.uint8, device=dev)
+    hip.conv2d_fwd(d, ws)
     torch.cuda.synchronize()
     y = F.conv2d(x, wt, bias, 1, 1).permute(0, 2, 3, 1)            # [b,h,w,351]
     want_conf = y[..., :243].reshape(b, -1, 81)

@@ -137,6 +137,7 @@ class InferEngine:
             if out is None:
                 out = self._buf(b, ho, wo, layer.cout)
             segs = [(0, layer.cout, out.data_ptr(), ho * wo * layer.cout, layer.cout, layer.act)]
+        layer.refresh()
         layer.bind(x, segs, residual)
         self.convs.append(layer)
         self.ops.append(('conv', layer))
@@ -227,14 +228,12 @@ class InferEngine:
         ws_bytes = max([hip.conv_workspace_bytes(c.desc) for c in self.convs] + [256])
         self.workspace = torch.empty(ws_bytes, device=self.device, dtype=torch.uint8)
         self.total_flops = sum(c.flops for c in self.convs)
+        self._weights_epoch = self.net._weights_epoch
 
     # ---- execution ---------------------------------------------------------------------------
     def refresh_weights(self):
-        seen = set()
         for c in self.convs:
-            key = id(c.convs[0]), c.name.split('@')[0]
             c.refresh()
-            seen.add(key)
         self._weights_epoch = self.net._weights_epoch
         self.graph = None
 
