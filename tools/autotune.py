@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Measure the best (tile, ksplit) per conv shape on this MI355X and write yolact_minimal_amd/tuned_gfx950.json
+(merged with an existing table).  Run on the GPU box:  python tools/autotune.py --out gpurun_out/tuned_gfx950.json"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ['YM_NO_TUNED'] = '1'
+from bench import build_net  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--out', default='gpurun_out/tuned_gfx950.json')
+    ap.add_argument('--cfgs', default='res101_coco,res50_coco')
+    ap.add_argument('--batches', default='1,8')
+    ap.add_argument('--iters', type=int, default=10)
+    args = ap.parse_args()
+    dev = torch.device('cuda:0')
+    table, detail = {}, {}
+    for cfg_name in args.cfgs.split(','):
+        net, cfg = build_net(cfg_name, 544, dev)
+        for b in (int(x) for x in args.batches.split(',')):
+            img = torch.randn(b, 3, 544, 544, device=dev)
+            eng = net._engine(img)
+            res = eng.autotune(args.iters, verbose=True)
+            for k, v in res.items():
+                if k not in table:
+                    table[k] = v[:3]
+                    detail[k] = v
+            net._engines.clear()
+            torch.cuda.empty_cache()
+    os.makedirs(os.path.dirname(args.out) or '.', exist_ok=True)
+    json.dump(table, open(args.out, 'w'), indent=0, sort_keys=True)
+    json.dump(detail, open(args.out.replace('.json', '_detail.json'), 'w'), indent=0, sort_keys=True)
+    tot_b = sum(v[4] for v in detail.values())
+    tot_a = sum(v[3] for v in detail.values())
+    print(f'{len(table)} shapes; sum of per-shape best {tot_a:.0f} us vs default {tot_b:.0f} us')
+
+
+if __name__ == '__main__':
+    main()

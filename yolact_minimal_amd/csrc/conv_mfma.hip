@@ -42,6 +42,7 @@ struct ConvP {
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, Kpad;
     int M, HoWo, nkt, ksplit, kt_per_split, tiles_m, tiles_n;
     int nseg;
+    int vec;   // 1: single segment, plain NHWC [M][Cout], Cout % 4 == 0, 16-byte aligned -> vectorised epilogue
     SegDev seg[3];
 };
 
@@ -218,6 +219,57 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
     }
 
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) --
+    if (p.vec) {
+        // Stage the BM x BN accumulator tile through LDS (the K loop ended on a barrier, so the operand
+        // buffers are dead) and emit it row-major: every lane handles one float4 of a row, so residual loads
+        // and output stores are full 16-byte accesses, 512 B (BN=128) / 256 B (BN=64) contiguous per row.
+        constexpr int CP = BN + 4;                 // pitch in floats: keeps float4 alignment, skews banks
+        constexpr int C4 = BN / 4;                 // float4 per row
+        constexpr int RPP = 256 / C4;              // rows per pass
+        float* C = smem;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    C[(wm * (BM / 2) + i * 32 + 4 * khalf + (r & 3) + 8 * (r >> 2)) * CP + wn * (BN / 2) + j * 32 + frag_row] =
+                        acc[i][j][r];
+        __syncthreads();
+        const int col4 = tid % C4, row0 = tid / C4;
+        const int n = n0 + col4 * 4;
+        if (n < p.Cout) {
+            if (p.ksplit > 1) {
+                float* wsb = p.ws + (size_t)ks * p.M * p.Cout + n;
+#pragma unroll 4
+                for (int row = row0; row < BM; row += RPP) {
+                    const int m = m0 + row;
+                    if (m < p.M)
+                        *reinterpret_cast<f32x4*>(wsb + (size_t)m * p.Cout) = *reinterpret_cast<const f32x4*>(C + row * CP + col4 * 4);
+                }
+            } else {
+                f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+                if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+                if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+                const int act = p.seg[0].act;
+                float* outb = p.seg[0].out + n;
+                const float* resb = p.residual ? p.residual + n : nullptr;
+#pragma unroll 4
+                for (int row = row0; row < BM; row += RPP) {
+                    const int m = m0 + row;
+                    if (m < p.M) {
+                        f32x4 v = *reinterpret_cast<const f32x4*>(C + row * CP + col4 * 4);
+                        v = v * sc + sh;
+                        if (resb) v += *reinterpret_cast<const f32x4*>(resb + (size_t)m * p.Cout);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = ym_apply_act(v[e], act);
+                        *reinterpret_cast<f32x4*>(outb + (size_t)m * p.Cout) = v;
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * (BN / 2) + j * 32 + frag_row;
@@ -266,6 +318,23 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
 
 __global__ __launch_bounds__(256) void conv_splitk_reduce(const ConvP p) {
     const size_t total = (size_t)p.M * p.Cout;
+    if (p.vec) {
+        const size_t total4 = total / 4;
+        const int act = p.seg[0].act;
+        for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total4; q += (size_t)gridDim.x * 256) {
+            const size_t e = q * 4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(p.ws + e);
+            for (int s = 1; s < p.ksplit; ++s) v += *reinterpret_cast<const f32x4*>(p.ws + (size_t)s * total + e);
+            const int n = (int)(e % p.Cout);
+            if (p.scale) v *= *reinterpret_cast<const f32x4*>(p.scale + n);
+            if (p.shift) v += *reinterpret_cast<const f32x4*>(p.shift + n);
+            if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + e);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = ym_apply_act(v[k], act);
+            *reinterpret_cast<f32x4*>(p.seg[0].out + e) = v;
+        }
+        return;
+    }
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
         float v = 0.f;
         for (int s = 0; s < p.ksplit; ++s) v += p.ws[(size_t)s * total + e];
@@ -372,6 +441,13 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
             p.seg[i] = SegDev{nullptr, 0, 0, 0, 0, 0};
         }
     }
+    {
+        const ym_conv_seg& g = d->seg[0];
+        const bool aligned = (((uintptr_t)g.out | (uintptr_t)d->residual | (uintptr_t)d->scale | (uintptr_t)d->shift |
+                               (uintptr_t)workspace) & 15) == 0;
+        p.vec = (d->nseg == 1 && g.n_begin == 0 && g.n_end == d->Cout && g.pitch == d->Cout &&
+                 g.batch_stride == (int64_t)d->Ho * d->Wo * d->Cout && d->Cout % 4 == 0 && aligned) ? 1 : 0;
+    }
     hipStream_t st = (hipStream_t)s;
     const int grid = pl.tiles_m * pl.tiles_n * pl.ksplit;
     if (d->Cin == 4) launch<128, 64, 1>(p, grid, st);
@@ -383,7 +459,7 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
     if (rc != YM_OK) return rc;
     if (pl.ksplit > 1) {
         const size_t total = (size_t)pl.M * d->Cout;
-        int rgrid = (int)((total + 255) / 256);
+        int rgrid = (int)((total / (p.vec ? 4 : 1) + 255) / 256);
         if (rgrid > 2048) rgrid = 2048;
         hipLaunchKernelGGL(conv_splitk_reduce, dim3(rgrid), dim3(256), 0, st, p);
         rc = ym_check_launch("conv_splitk_reduce");

@@ -16,6 +16,7 @@ Fusions (what never touches HBM as a separate tensor):
   bbox | conf | coef convs + tanh + permute + reshape + cat over levels -> one 351-channel launch per level
                                      writing straight into the [B, N, C] outputs (yolact.py:27-30,155-157)
 """
+import json
 import os
 
 import torch
@@ -27,6 +28,21 @@ from .hip import ConvDesc, ACT_NONE, ACT_RELU, ACT_TANH
 
 def _round_up(x, m):
     return (x + m - 1) // m * m
+
+
+TUNED_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuned_gfx950.json')
+_tuned = None
+
+
+def tuned_table():
+    """Per-shape (tile_m, tile_n, ksplit) choices measured on an MI355X by tools/autotune.py."""
+    global _tuned
+    if _tuned is None:
+        _tuned = {}
+        if os.path.exists(TUNED_PATH) and os.environ.get('YM_NO_TUNED', '0') != '1':
+            with open(TUNED_PATH) as f:
+                _tuned = json.load(f)
+    return _tuned
 
 
 class _Conv:
@@ -99,6 +115,11 @@ class _Conv:
         self._bind_params()
         self.out_hw = (ho, wo)
         self.flops = 2.0 * b * ho * wo * self.cout * self.kh * self.kw * self.cin
+        self.sig = f'M{b * ho * wo}_N{self.cout}_C{cin}_k{self.kh}_s{self.stride}_seg{len(segs)}_r{int(residual is not None)}'
+        hit = tuned_table().get(self.sig)
+        if hit and self.tile == (0, 0) and self.ksplit == 0:
+            self.tile, self.ksplit = (hit[0], hit[1]), hit[2]
+            d.tile_m, d.tile_n, d.ksplit = hit[0], hit[1], hit[2]
         return ho, wo
 
 
@@ -246,6 +267,64 @@ class InferEngine:
         if ws_bytes > self.workspace.numel():
             self.workspace = torch.empty(ws_bytes, device=self.device, dtype=torch.uint8)
         self.graph = None
+
+    def autotune(self, iters=10, verbose=False):
+        """Time every (tile, ksplit) candidate of every distinct conv shape on this GPU; keep the fastest.
+        Returns {signature: [tile_m, tile_n, ksplit, best_us, default_us]}."""
+        results = {}
+        big_ws = torch.empty(1 << 28, device=self.device, dtype=torch.uint8)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+        def time_cfg(c, tile, ks):
+            d = c.desc
+            d.tile_m, d.tile_n, d.ksplit = tile[0], tile[1], ks
+            need = hip.conv_workspace_bytes(d)
+            if need > big_ws.numel():
+                return None
+            try:
+                for _ in range(2):
+                    hip.conv2d_fwd(d, big_ws)
+            except RuntimeError:
+                return None
+            best = 1e30
+            for _ in range(3):
+                ev0.record()
+                for _ in range(iters):
+                    hip.conv2d_fwd(d, big_ws)
+                ev1.record()
+                torch.cuda.synchronize()
+                best = min(best, ev0.elapsed_time(ev1) / iters * 1e3)
+            return best
+
+        seen = {}
+        for c in self.convs:
+            if c.sig in seen:
+                c.tile, c.ksplit = seen[c.sig]
+                continue
+            d = c.desc
+            M, nkt = d.B * d.Ho * d.Wo, d.k_pad // 32
+            base = time_cfg(c, (0, 0), 0)
+            cands = []
+            tiles = [(128, 64)] if c.stem else [(128, 128), (128, 64), (64, 128), (64, 64)]
+            for tm, tn in tiles:
+                wgs = -(-M // tm) * -(-d.Cout // tn)
+                for ks in (1, 2, 3, 4, 6, 8, 12, 16, 24):
+                    if ks > 1 and (wgs >= 1024 or ks * 2 > nkt or wgs * ks > 8192):
+                        continue
+                    cands.append(((tm, tn), ks))
+            best = (base, (0, 0), 0)
+            for tile, ks in cands:
+                t = time_cfg(c, tile, ks)
+                if t is not None and t < best[0] * 0.98:
+                    best = (t, tile, ks)
+            c.tile, c.ksplit = best[1], best[2]
+            seen[c.sig] = (c.tile, c.ksplit)
+            results[c.sig] = [best[1][0], best[1][1], best[2], round(best[0], 2), round(base, 2)]
+            if verbose:
+                print(f'{c.sig:44s} default {base:8.1f} us -> {best[1]} ks={best[2]} {best[0]:8.1f} us', flush=True)
+        del big_ws
+        self.retune()
+        return results
 
     def _launch_all(self, img):
         hip.nchw_to_nhwc4(img, self.x_in)
