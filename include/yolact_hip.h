@@ -70,8 +70,11 @@ typedef struct {
     int32_t B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, k_pad;
     int32_t nseg;            /* 1..3 */
     ym_conv_seg seg[3];
-    int32_t tile_m, tile_n;  /* 0 = library heuristic; else one of 128/64 (tuning knob) */
-    int32_t ksplit;          /* 0 = heuristic; >=1 = number of K slices (slices>1 need workspace) */
+    /* tuning knobs (0 = library heuristic); yolact_minimal_amd/tuned_gfx950.json holds measured choices */
+    int32_t tile_m, tile_n;  /* workgroup kernel: 128/64 (workgroup tile); wave kernel: 64/32 (per-wave tile) */
+    int32_t ksplit;          /* workgroup kernel: K slices across the grid (slices > 1 need workspace) */
+    int32_t kwaves;          /* 0 = LDS-tiled workgroup kernel; 1/2/4/8 = wave-private kernel with that many
+                                waves of one workgroup splitting K for each output tile */
 } ym_conv_desc;
 
 /* y = act(conv(x, w) * scale + shift + residual), one launch (plus a reduce launch if K is split).

@@ -12,7 +12,7 @@ def _dev():
     return torch.device('cuda:0')
 
 
-def run_conv(x_nchw, w, scale=None, shift=None, residual=None, stride=1, pad=0, act=0, tile=(0, 0), ksplit=0):
+def run_conv(x_nchw, w, scale=None, shift=None, residual=None, stride=1, pad=0, act=0, tile=(0, 0), ksplit=0, kwaves=0):
     """Runs ym_conv2d_fwd on NHWC data; returns NCHW cpu tensor."""
     from yolact_minimal_amd import hip
     dev = _dev()
@@ -44,6 +44,7 @@ def run_conv(x_nchw, w, scale=None, shift=None, residual=None, stride=1, pad=0, 
     d.seg[0].batch_stride, d.seg[0].pitch, d.seg[0].act = ho * wo * cout, cout, act
     d.tile_m, d.tile_n = tile
     d.ksplit = ksplit
+    d.kwaves = kwaves
     nbytes = hip.conv_workspace_bytes(d)
     ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
     hip.conv2d_fwd(d, ws)
@@ -96,6 +97,39 @@ def test_conv_parity(case):
     assert not torch.isnan(got).any()
     # tolerance: fp32 accumulation-order differences only
     torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5)
+
+
+WAVE_CASES = [
+    # b, cin, h, w, cout, k, stride, pad, act, residual, wave tile, kwaves
+    (1, 64, 17, 17, 64, 1, 1, 0, 1, False, (32, 32), 1),
+    (1, 256, 34, 34, 256, 3, 1, 1, 1, False, (32, 32), 4),
+    (1, 1024, 9, 11, 256, 1, 1, 0, 1, True, (32, 32), 8),
+    (2, 128, 19, 19, 128, 3, 2, 1, 1, False, (64, 32), 2),
+    (1, 256, 13, 13, 1024, 1, 1, 0, 1, True, (32, 64), 1),
+    (1, 512, 7, 7, 512, 3, 1, 1, 0, False, (64, 64), 4),
+    (2, 64, 20, 23, 96, 1, 1, 0, 2, False, (64, 64), 1),
+    (1, 256, 5, 5, 255, 3, 2, 1, 1, False, (32, 32), 8),   # Cout % 4 != 0 -> scalar epilogue
+    (1, 64, 6, 6, 64, 3, 1, 1, 1, False, (64, 32), 8),     # more K waves than useful tiles
+]
+
+
+@pytest.mark.parametrize('case', WAVE_CASES)
+def test_conv_wave_kernel_parity(case):
+    b, cin, h, w, cout, k, stride, pad, act, use_res, tile, kwaves = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    res = torch.randn(b, cout, ho, wo, generator=g) if use_res else None
+    got = run_conv(x, wt, scale, shift, res, stride, pad, act, tile, 0, kwaves)
+    want = ref_conv(x, wt, scale, shift, res, stride, pad, act)
+    assert not torch.isnan(got).any()
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5)
+    # deterministic: the K-wave partials are combined in a fixed order
+    again = run_conv(x, wt, scale, shift, res, stride, pad, act, tile, 0, kwaves)
+    assert torch.equal(got, again)
 
 
 def test_conv_identity_asymmetric():

@@ -1,0 +1,48 @@
+// Shared between the two convolution kernels (LDS-tiled workgroup kernel, wave-private kernel).
+#pragma once
+#include "ym_common.h"
+
+namespace ymk {
+
+constexpr int BK = 32;   // K step in floats (one 128-byte row of either operand)
+
+struct SegDev {
+    float* out;
+    long long bstride;
+    int n0, n1, pitch, act;
+};
+
+struct ConvP {
+    const float* in;
+    const float* w;
+    const float* scale;
+    const float* shift;
+    const float* residual;
+    float* ws;  // split-K partials [ksplit][M][Cout] (only when ksplit > 1)
+    int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, Kpad;
+    int M, HoWo, nkt, ksplit, kt_per_split, tiles_m, tiles_n;
+    int nseg;
+    int vec;   // 1: single segment, plain NHWC [M][Cout], Cout % 4 == 0, 16-byte aligned -> vectorised epilogue
+    SegDev seg[3];
+};
+
+__device__ __forceinline__ void epilogue_store(const ConvP& p, int m, int n, float acc) {
+    float v = acc;
+    if (p.scale) v *= p.scale[n];
+    if (p.shift) v += p.shift[n];
+    if (p.residual) v += p.residual[(size_t)m * p.Cout + n];
+    const int b = m / p.HoWo, pix = m - b * p.HoWo;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        if (s < p.nseg && n >= p.seg[s].n0 && n < p.seg[s].n1) {
+            const SegDev& g = p.seg[s];
+            g.out[(size_t)b * g.bstride + (size_t)pix * g.pitch + (n - g.n0)] = ym_apply_act(v, g.act);
+        }
+    }
+}
+
+
+}  // namespace ymk
+
+// conv_wave.hip: wave-private kernel; returns YM_OK / YM_EINVAL (unsupported variant)
+int ym_launch_conv_wave(const ymk::ConvP& p, int tm, int tn, int kwaves, hipStream_t st);

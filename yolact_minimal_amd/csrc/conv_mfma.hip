@@ -19,47 +19,13 @@
 // is MFMA-issue bound, LDS and the global->LDS staging (register prefetch, double-buffered) sit
 // far below their limits.  Grid: one block per (tile, k-slice), XCD-aware remap so the N-tiles
 // sharing an A panel run on the same XCD L2.
-#include "ym_common.h"
+#include "conv_common.h"
+
+using namespace ymk;
 
 namespace {
 
-constexpr int BK = 32;
 constexpr int PITCH = 36;  // floats
-
-struct SegDev {
-    float* out;
-    long long bstride;
-    int n0, n1, pitch, act;
-};
-
-struct ConvP {
-    const float* in;
-    const float* w;
-    const float* scale;
-    const float* shift;
-    const float* residual;
-    float* ws;  // split-K partials [ksplit][M][Cout] (only when ksplit > 1)
-    int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, Kpad;
-    int M, HoWo, nkt, ksplit, kt_per_split, tiles_m, tiles_n;
-    int nseg;
-    int vec;   // 1: single segment, plain NHWC [M][Cout], Cout % 4 == 0, 16-byte aligned -> vectorised epilogue
-    SegDev seg[3];
-};
-
-__device__ __forceinline__ void epilogue_store(const ConvP& p, int m, int n, float acc) {
-    float v = acc;
-    if (p.scale) v *= p.scale[n];
-    if (p.shift) v += p.shift[n];
-    if (p.residual) v += p.residual[(size_t)m * p.Cout + n];
-    const int b = m / p.HoWo, pix = m - b * p.HoWo;
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        if (s < p.nseg && n >= p.seg[s].n0 && n < p.seg[s].n1) {
-            const SegDev& g = p.seg[s];
-            g.out[(size_t)b * g.bstride + (size_t)pix * g.pitch + (n - g.n0)] = ym_apply_act(v, g.act);
-        }
-    }
-}
 
 // MODE 0: Cin % 32 == 0 (every K tile lies inside one filter tap).  MODE 1: Cin == 4 (stem; one tap per float4).
 template <int BM, int BN, int MODE>
@@ -374,6 +340,13 @@ int make_plan(const ym_conv_desc* d, Plan* pl) {
         }
         if (d->Cin == 4) { bm = 128; bn = 64; }
     }
+    if (d->kwaves > 0) {
+        YM_REQUIRE(d->Cin != 4, "conv: the wave-private kernel does not support the stem (Cin == 4)");
+        YM_REQUIRE((bm == 32 || bm == 64) && (bn == 32 || bn == 64), "conv(wave): tile must be 32/64, got %dx%d", bm, bn);
+        pl->bm = bm; pl->bn = bn; pl->tiles_m = ym_cdiv(pl->M, bm); pl->tiles_n = ym_cdiv(d->Cout, bn);
+        pl->ksplit = 1; pl->kt_per_split = pl->nkt;
+        return YM_OK;
+    }
     YM_REQUIRE((bm == 128 || bm == 64) && (bn == 128 || bn == 64), "conv: tile must be 64/128");
     YM_REQUIRE(d->Cin != 4 || (bm == 128 && bn == 64), "conv: stem mode supports the 128x64 tile only");
     pl->bm = bm; pl->bn = bn;
@@ -449,6 +422,7 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
                  g.batch_stride == (int64_t)d->Ho * d->Wo * d->Cout && d->Cout % 4 == 0 && aligned) ? 1 : 0;
     }
     hipStream_t st = (hipStream_t)s;
+    if (d->kwaves > 0) return ym_launch_conv_wave(p, pl.bm, pl.bn, d->kwaves, st);
     const int grid = pl.tiles_m * pl.tiles_n * pl.ksplit;
     if (d->Cin == 4) launch<128, 64, 1>(p, grid, st);
     else if (pl.bm == 128 && pl.bn == 128) launch<128, 128, 0>(p, grid, st);

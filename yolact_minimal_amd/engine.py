@@ -66,6 +66,7 @@ class _Conv:
         self.desc = None
         self.tile = (0, 0)
         self.ksplit = 0
+        self.kwaves = 0
 
     def refresh(self):
         """(Re)pack parameters from the nn.Modules into the kernel layout, on device."""
@@ -111,15 +112,16 @@ class _Conv:
             d.seg[i].batch_stride, d.seg[i].pitch, d.seg[i].act = bstride, pitch, act
         d.tile_m, d.tile_n = self.tile
         d.ksplit = self.ksplit
+        d.kwaves = self.kwaves
         self.desc = d
         self._bind_params()
         self.out_hw = (ho, wo)
         self.flops = 2.0 * b * ho * wo * self.cout * self.kh * self.kw * self.cin
         self.sig = f'M{b * ho * wo}_N{self.cout}_C{cin}_k{self.kh}_s{self.stride}_seg{len(segs)}_r{int(residual is not None)}'
         hit = tuned_table().get(self.sig)
-        if hit and self.tile == (0, 0) and self.ksplit == 0:
-            self.tile, self.ksplit = (hit[0], hit[1]), hit[2]
-            d.tile_m, d.tile_n, d.ksplit = hit[0], hit[1], hit[2]
+        if hit and self.tile == (0, 0) and self.ksplit == 0 and self.kwaves == 0:
+            self.tile, self.ksplit, self.kwaves = (hit[0], hit[1]), hit[2], (hit[3] if len(hit) > 3 else 0)
+            d.tile_m, d.tile_n, d.ksplit, d.kwaves = hit[0], hit[1], hit[2], self.kwaves
         return ho, wo
 
 
@@ -263,6 +265,7 @@ class InferEngine:
         for c in self.convs:
             c.desc.tile_m, c.desc.tile_n = c.tile
             c.desc.ksplit = c.ksplit
+            c.desc.kwaves = c.kwaves
         ws_bytes = max([hip.conv_workspace_bytes(c.desc) for c in self.convs] + [256])
         if ws_bytes > self.workspace.numel():
             self.workspace = torch.empty(ws_bytes, device=self.device, dtype=torch.uint8)
@@ -275,9 +278,9 @@ class InferEngine:
         big_ws = torch.empty(1 << 28, device=self.device, dtype=torch.uint8)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-        def time_cfg(c, tile, ks):
+        def time_cfg(c, tile, ks, kwv=0):
             d = c.desc
-            d.tile_m, d.tile_n, d.ksplit = tile[0], tile[1], ks
+            d.tile_m, d.tile_n, d.ksplit, d.kwaves = tile[0], tile[1], ks, kwv
             need = hip.conv_workspace_bytes(d)
             if need > big_ws.numel():
                 return None
@@ -299,11 +302,11 @@ class InferEngine:
         seen = {}
         for c in self.convs:
             if c.sig in seen:
-                c.tile, c.ksplit = seen[c.sig]
+                c.tile, c.ksplit, c.kwaves = seen[c.sig]
                 continue
             d = c.desc
             M, nkt = d.B * d.Ho * d.Wo, d.k_pad // 32
-            base = time_cfg(c, (0, 0), 0)
+            base = time_cfg(c, (0, 0), 0, 0)
             cands = []
             tiles = [(128, 64)] if c.stem else [(128, 128), (128, 64), (64, 128), (64, 64)]
             for tm, tn in tiles:
@@ -311,17 +314,28 @@ class InferEngine:
                 for ks in (1, 2, 3, 4, 6, 8, 12, 16, 24):
                     if ks > 1 and (wgs >= 1024 or ks * 2 > nkt or wgs * ks > 8192):
                         continue
-                    cands.append(((tm, tn), ks))
-            best = (base, (0, 0), 0)
-            for tile, ks in cands:
-                t = time_cfg(c, tile, ks)
+                    cands.append(((tm, tn), ks, 0))
+            if not c.stem:
+                for tm, tn in ((32, 32), (64, 32), (32, 64), (64, 64)):
+                    waves = -(-M // tm) * -(-d.Cout // tn)
+                    for kwv in (1, 2, 4, 8):
+                        if kwv > 1 and (waves >= 4096 or kwv > nkt):
+                            continue
+                        if kwv == 8 and tm * tn == 4096:
+                            continue
+                        if waves * kwv > 65536:
+                            continue
+                        cands.append(((tm, tn), 1, kwv))
+            best = (base, (0, 0), 0, 0)
+            for tile, ks, kwv in cands:
+                t = time_cfg(c, tile, ks, kwv)
                 if t is not None and t < best[0] * 0.98:
-                    best = (t, tile, ks)
-            c.tile, c.ksplit = best[1], best[2]
-            seen[c.sig] = (c.tile, c.ksplit)
-            results[c.sig] = [best[1][0], best[1][1], best[2], round(best[0], 2), round(base, 2)]
+                    best = (t, tile, ks, kwv)
+            c.tile, c.ksplit, c.kwaves = best[1], best[2], best[3]
+            seen[c.sig] = (c.tile, c.ksplit, c.kwaves)
+            results[c.sig] = [best[1][0], best[1][1], best[2], best[3], round(best[0], 2), round(base, 2)]
             if verbose:
-                print(f'{c.sig:44s} default {base:8.1f} us -> {best[1]} ks={best[2]} {best[0]:8.1f} us', flush=True)
+                print(f'{c.sig:44s} default {base:8.1f} us -> {best[1]} ks={best[2]} kw={best[3]} {best[0]:8.1f} us', flush=True)
         del big_ws
         self.retune()
         return results

@@ -38,7 +38,7 @@ class ConvDesc(ctypes.Structure):
                 ('stride', ctypes.c_int32), ('pad', ctypes.c_int32), ('Ho', ctypes.c_int32),
                 ('Wo', ctypes.c_int32), ('k_pad', ctypes.c_int32), ('nseg', ctypes.c_int32),
                 ('seg', ConvSeg * 3), ('tile_m', ctypes.c_int32), ('tile_n', ctypes.c_int32),
-                ('ksplit', ctypes.c_int32)]
+                ('ksplit', ctypes.c_int32), ('kwaves', ctypes.c_int32)]
 
 
 class NmsCfg(ctypes.Structure):
