@@ -75,6 +75,13 @@ typedef struct {
     int32_t ksplit;          /* workgroup kernel: K slices across the grid (slices > 1 need workspace) */
     int32_t kwaves;          /* 0 = LDS-tiled workgroup kernel; 1/2/4/8 = wave-private kernel with that many
                                 waves of one workgroup splitting K for each output tile */
+    int32_t transposed;      /* 0 = convolution.  1 = DATA GRADIENT of that convolution (conv-transpose gather):
+                                `in` is dy NHWC [B][H][W][Cin] (H,W = the forward OUTPUT size, Cin = forward Cout
+                                padded to a multiple of 32), the result is dx [B][Ho][Wo][Cout] (Ho,Wo = forward
+                                INPUT size, Cout = forward Cin), stride/pad/KH/KW are the forward conv's, and
+                                `weight` comes from ym_pack_conv_weight_dgrad.  Autograd counterpart of every
+                                nn.Conv2d on the path (loss_total.backward(), reference train.py:126). */
+    int32_t reserved;
 } ym_conv_desc;
 
 /* y = act(conv(x, w) * scale + shift + residual), one launch (plus a reduce launch if K is split).
@@ -84,6 +91,50 @@ typedef struct {
  * PredictionModule.forward + Yolact.forward (modules/yolact.py:27-30,155-157). */
 size_t ym_conv2d_workspace_bytes(const ym_conv_desc* d);
 int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t workspace_bytes, ym_stream_t s);
+
+/* ---- training: weight gradient, batch-norm with batch statistics, small backward ops, SGD -------------------
+ * These replace what autograd + ATen/cuDNN execute for `loss_total.backward()` / `optimizer.step()`
+ * (reference train.py:124-130) and nn.BatchNorm2d in train mode (modules/resnet.py:10-14,46). */
+
+/* OIHW weight -> [Cin][KH][KW][cout_pad] for the transposed gather above (cout_pad % 32 == 0, zero padded). */
+int ym_pack_conv_weight_dgrad(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, int cout_pad,
+                              ym_stream_t s);
+
+typedef struct {
+    const float* x;          /* forward input NHWC [B][H][W][Cin] (Cin = padded channel pitch; 4 for the stem) */
+    const float* dy;         /* output gradient [B][Ho][Wo][Cout] (Cout = channel pitch, multiple of 4) */
+    float* dw;               /* OIHW [Cout_real][Cin_real][KH][KW], overwritten */
+    int32_t B, H, W, Cin, Cin_real, Cout, Cout_real, KH, KW, stride, pad, Ho, Wo;
+    int32_t msplit;          /* 0 = heuristic; pixel-range slices across the grid */
+} ym_wgrad_desc;
+size_t ym_conv2d_wgrad_workspace_bytes(const ym_wgrad_desc* d);
+int ym_conv2d_wgrad(const ym_wgrad_desc* d, void* workspace, size_t workspace_bytes, ym_stream_t s);
+
+/* BatchNorm2d forward in TRAIN mode on a conv output y [M][C] (C % 4 == 0): batch mean / biased variance
+ * (fp64 accumulation), running stats updated in place with `momentum` (unbiased variance, torch semantics),
+ * out = relu?( (y-mean)*invstd*gamma + beta + residual? ).  save_mean/save_invstd [C] feed the backward.
+ * workspace >= 16*C bytes. */
+int ym_bn_train_fwd(const float* y, int64_t M, int C, const float* gamma, const float* beta, float eps, float momentum,
+                    float* running_mean, float* running_var, const float* residual, int relu, float* out,
+                    float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes, ym_stream_t s);
+
+/* Backward of the above: dz = dout * (out > 0 if relu); dres (optional) = dz; dgamma/dbeta [C];
+ * dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)).  workspace >= 16*C bytes. */
+int ym_bn_train_bwd(const float* dout, const float* out, const float* y, int64_t M, int C, const float* gamma,
+                    const float* save_mean, const float* save_invstd, int relu, float* dy, float* dres, float* dgamma,
+                    float* dbeta, void* workspace, size_t workspace_bytes, ym_stream_t s);
+
+/* Backward of a fused conv epilogue `y = act(conv + bias)`: dz = dy * act'(y) (dz may be NULL or == dy for
+ * YM_ACT_NONE), dbias[C] = column sums of dz (optional).  workspace >= 8*C bytes when dbias != NULL. */
+int ym_act_bias_bwd(const float* dy, const float* y, int64_t M, int C, int act, float* dz, float* dbias, void* workspace,
+                    size_t workspace_bytes, ym_stream_t s);
+
+int ym_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, ym_stream_t s);
+int ym_bilinear2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, int align_corners, ym_stream_t s);
+
+/* torch.optim.SGD(momentum, weight_decay) on one flat fp32 buffer (reference train.py:61,130). */
+int ym_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
+                float weight_decay, int first_step, ym_stream_t s);
 
 /* ---- small NHWC ops ------------------------------------------------------------------------------ */
 

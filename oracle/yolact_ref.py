@@ -338,3 +338,165 @@ def randomize_bias_(sd, seed=11):
         if k.endswith('.bias') and sd[k].dim() == 1 and '.bn' not in k and 'downsample.1' not in k:
             sd[k].copy_(torch.randn(sd[k].shape, generator=g) * 0.05)
     return sd
+
+
+# ------------------------------------------------------------------------------------------------
+# training: forward with batch-statistics BN + the YOLACT loss (modules/yolact.py:160-313)
+# ------------------------------------------------------------------------------------------------
+class TrainNet:
+    """Functional train-mode forward over a dict of leaf tensors (requires_grad as set by the caller).
+    BatchNorm uses batch statistics and updates `running_*` in place (momentum 0.1), like nn.BatchNorm2d."""
+
+    def __init__(self, params):
+        self.p = params
+
+    def conv(self, x, name, stride=1, padding=0):
+        return F.conv2d(x, self.p[name + '.weight'], self.p.get(name + '.bias'), stride=stride, padding=padding)
+
+    def bn(self, x, name):
+        return F.batch_norm(x, self.p[name + '.running_mean'], self.p[name + '.running_var'],
+                            self.p[name + '.weight'], self.p[name + '.bias'], True, 0.1, 1e-5)
+
+    def bottleneck(self, x, p, stride):
+        y = F.relu(self.bn(self.conv(x, p + '.conv1'), p + '.bn1'))
+        y = F.relu(self.bn(self.conv(y, p + '.conv2', stride, 1), p + '.bn2'))
+        y = self.bn(self.conv(y, p + '.conv3'), p + '.bn3')
+        if (p + '.downsample.0.weight') in self.p:
+            x = self.bn(self.conv(x, p + '.downsample.0', stride), p + '.downsample.1')
+        return F.relu(y + x)
+
+    def forward(self, img):
+        P = self.p
+        layers = resnet_layers_from_sd(P)
+        x = F.relu(self.bn(self.conv(img, 'backbone.conv1', 2, 3), 'backbone.bn1'))
+        x = F.max_pool2d(x, 3, 2, 1)
+        outs = []
+        for li, nblk in enumerate(layers):
+            for bi in range(nblk):
+                x = self.bottleneck(x, f'backbone.layers.{li}.{bi}', 2 if (bi == 0 and li > 0) else 1)
+            outs.append(x)
+        levels = fpn(outs[1], outs[2], outs[3], P)
+        proto = protonet(levels[0], P).permute(0, 2, 3, 1).contiguous()
+        nc = P['prediction_layers.conf_layer.weight'].shape[0] // 3
+        confs, boxes, coefs = zip(*(head(lv, P, nc) for lv in levels))
+        seg = F.conv2d(levels[0], P['semantic_seg_conv.weight'], P['semantic_seg_conv.bias'])
+        return torch.cat(confs, 1), torch.cat(boxes, 1), torch.cat(coefs, 1), proto, seg
+
+
+def encode_offsets(matched, priors):
+    """utils/box_utils.py:104-114."""
+    g_cxcy = ((matched[:, :2] + matched[:, 2:]) / 2 - priors[:, :2]) / (0.1 * priors[:, 2:])
+    g_wh = torch.log((matched[:, 2:] - matched[:, :2]) / priors[:, 2:]) / 0.2
+    return torch.cat([g_cxcy, g_wh], 1)
+
+
+def match_anchors(box_gt, anchors, class_gt, pos_thre=0.5, neg_thre=0.4):
+    """utils/box_utils.py:57-83. box_gt [g,4] corners, anchors [N,4] centre-size, class_gt [g] int64."""
+    corners = torch.cat((anchors[:, :2] - anchors[:, 2:] / 2, anchors[:, :2] + anchors[:, 2:] / 2), 1)
+    ov = pairwise_iou(box_gt[None], corners[None])[0]           # [g, N]
+    gt_best_anchor = ov.max(1)[1]
+    anchor_best, anchor_gt = ov.max(0)
+    anchor_best = anchor_best.clone()
+    anchor_gt = anchor_gt.clone()
+    anchor_best.index_fill_(0, gt_best_anchor, 2)
+    for j in range(gt_best_anchor.shape[0]):                    # later gt wins, like the reference loop :72-73
+        anchor_gt[gt_best_anchor[j]] = j
+    matched = box_gt[anchor_gt]
+    conf = class_gt[anchor_gt] + 1
+    conf[anchor_best < pos_thre] = -1
+    conf[anchor_best < neg_thre] = 0
+    return encode_offsets(matched, anchors), conf, matched, anchor_gt
+
+
+def ohem_class_loss(class_p, conf_gt, pos, conf_alpha=1.0, ratio=3, stable=False):
+    """modules/yolact.py:205-232."""
+    nc = class_p.shape[-1]
+    flat = class_p.reshape(-1, nc)
+    mx = flat.max()
+    mark = torch.log(torch.sum(torch.exp(flat - mx), 1)) + mx - flat[:, 0]
+    mark = mark.reshape(class_p.shape[0], -1).clone()
+    mark[pos] = 0
+    mark[conf_gt < 0] = 0
+    _, idx = _sort_desc(mark, 1, stable)
+    _, rank = idx.sort(1)
+    num_pos = pos.long().sum(1, keepdim=True)
+    num_neg = torch.clamp(ratio * num_pos, max=pos.shape[1] - 1)
+    neg = rank < num_neg.expand_as(rank)
+    neg[pos] = 0
+    neg[conf_gt < 0] = 0
+    sel = pos | neg
+    return conf_alpha * F.cross_entropy(class_p[sel].reshape(-1, nc), conf_gt[sel], reduction='sum') / num_pos.sum()
+
+
+def box_reg_loss(box_p, offsets, pos, bbox_alpha=1.5):
+    """modules/yolact.py:234-239."""
+    return bbox_alpha * F.smooth_l1_loss(box_p[pos, :], offsets[pos, :], reduction='sum') / pos.sum()
+
+
+def mask_loss(pos, anchor_gt, coef_p, proto_p, mask_gt, anchor_box, mask_alpha=6.125, masks_to_train=100):
+    """modules/yolact.py:241-291 (without the random sub-sampling branch: callers keep <= masks_to_train positives)."""
+    ph, pw = proto_p.shape[1:3]
+    total = 0
+    for i in range(coef_p.shape[0]):
+        ds = F.interpolate(mask_gt[i].unsqueeze(0), (ph, pw), mode='bilinear', align_corners=False).squeeze(0)
+        ds = ds.permute(1, 2, 0).contiguous().gt(0.5).to(proto_p.dtype)
+        idx = anchor_gt[i][pos[i]]
+        bx = anchor_box[i][pos[i]]
+        cf = coef_p[i][pos[i]]
+        if idx.shape[0] == 0:
+            continue
+        assert cf.shape[0] <= masks_to_train, 'oracle does not restate the randperm sub-sampling (yolact.py:261-267)'
+        gt = ds[:, :, idx]
+        mp = crop(torch.sigmoid(proto_p[i] @ cf.t()), bx)
+        l = F.binary_cross_entropy(torch.clamp(mp, 0, 1), gt, reduction='none')
+        area = (bx[:, 2] - bx[:, 0]) * (bx[:, 3] - bx[:, 1])
+        total = total + torch.sum(l.sum(dim=(0, 1)) / area)
+    return mask_alpha * total / ph / pw / pos.sum()
+
+
+def semantic_loss(seg_p, mask_gt, class_gt, semantic_alpha=1.0):
+    """modules/yolact.py:293-313."""
+    b, nc, mh, mw = seg_p.shape
+    total = 0
+    for i in range(b):
+        ds = F.interpolate(mask_gt[i].unsqueeze(0), (mh, mw), mode='bilinear', align_corners=False).squeeze(0)
+        ds = ds.gt(0.5).to(seg_p.dtype)
+        tgt = torch.zeros_like(seg_p[i])
+        for j in range(ds.shape[0]):
+            tgt[class_gt[i][j]] = torch.max(tgt[class_gt[i][j]], ds[j])
+        total = total + F.binary_cross_entropy_with_logits(seg_p[i], tgt, reduction='sum')
+    return semantic_alpha * total / mh / mw / b
+
+
+def compute_loss(class_p, box_p, coef_p, proto_p, seg_p, box_class, mask_gt, anchors, stable=False):
+    """modules/yolact.py:166-203. box_class: list of [g,5] (x1,y1,x2,y2,cls); mask_gt: list of [g,H,W]."""
+    b, n = box_p.shape[:2]
+    offs = torch.zeros(b, n, 4, dtype=box_p.dtype)
+    conf = torch.zeros(b, n, dtype=torch.int64)
+    abox = torch.zeros(b, n, 4, dtype=box_p.dtype)
+    aidx = torch.zeros(b, n, dtype=torch.int64)
+    cls_gt = []
+    for i in range(b):
+        cls_gt.append(box_class[i][:, -1].long())
+        offs[i], conf[i], abox[i], aidx[i] = match_anchors(box_class[i][:, :-1], anchors, cls_gt[i])
+    pos = conf > 0
+    return (ohem_class_loss(class_p, conf, pos, stable=stable), box_reg_loss(box_p, offs, pos),
+            mask_loss(pos, aidx, coef_p, proto_p, mask_gt, abox), semantic_loss(seg_p, mask_gt, cls_gt))
+
+
+def synth_targets(batch, img_size, n_gt=4, num_classes=80, seed=0):
+    """SURVEY.md §8d training inputs: n_gt boxes uniform in [0.1,0.9] with min side 0.1, rectangular float masks."""
+    boxes, masks = [], []
+    for i in range(batch):
+        g = torch.Generator().manual_seed(seed + i)
+        xy = torch.rand(n_gt, 2, generator=g) * 0.6 + 0.1
+        wh = torch.rand(n_gt, 2, generator=g) * 0.25 + 0.1
+        x2y2 = torch.clamp(xy + wh, max=0.9)
+        cls = torch.randint(0, num_classes, (n_gt, 1), generator=g).float()
+        boxes.append(torch.cat([xy, x2y2, cls], 1))
+        m = torch.zeros(n_gt, img_size, img_size)
+        for j in range(n_gt):
+            x1, y1, x2, y2 = (torch.cat([xy[j], x2y2[j]]) * img_size).round().long().tolist()
+            m[j, y1:y2, x1:x2] = 1.0
+        masks.append(m)
+    return boxes, masks

@@ -1,0 +1,207 @@
+"""GPU parity of the training path (HIP conv fwd/dgrad/wgrad, train-mode BN, pool/upsample backward) against the
+CPU oracle's autograd and the reference's golden losses / gradient digests."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import yolact_ref as R
+from yolact_minimal_amd.config import build_cfg
+from yolact_minimal_amd.modules.yolact import Yolact
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def _nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,hw,act,res', [(64, 64, 1, 1, 17, 1, False), (64, 128, 3, 2, 20, 1, False),
+                                                           (256, 96, 3, 1, 9, 2, False), (128, 256, 1, 2, 12, 0, True),
+                                                           (32, 352, 3, 1, 7, 0, False)])
+def test_conv_bias_fn_grads(cin, cout, k, stride, hw, act, res):
+    from yolact_minimal_amd.train_engine import ConvBias
+    g = torch.Generator().manual_seed(cin + cout + k)
+    x = torch.randn(2, cin, hw, hw, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * (1 / (cin * k * k) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.1
+    pad = k // 2
+    ho = (hw + 2 * pad - k) // stride + 1
+    r = torch.randn(2, cout, ho, ho, generator=g) if res else None
+    xc, wc, bc = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    rc = r.clone().requires_grad_() if res else None
+    y = F.conv2d(xc, wc, bc, stride, pad)
+    if res:
+        y = y + rc
+    y = F.relu(y) if act == 1 else torch.tanh(y) if act == 2 else y
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xg, wg, bg = _nhwc(x).to(DEV).requires_grad_(), w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    rg = _nhwc(r).to(DEV).requires_grad_() if res else None
+    cout_pad = (cout + 31) // 32 * 32
+    yg = ConvBias.apply(xg, wg, bg, stride, pad, act, cout_pad, rg)
+    torch.testing.assert_close(_nchw(yg[..., :cout]).cpu(), y.detach(), rtol=1e-4, atol=1e-5)
+    gyp = torch.zeros(2, ho, ho, cout_pad)
+    gyp[..., :cout] = _nhwc(gy)
+    yg.backward(gyp.to(DEV))
+    torch.testing.assert_close(_nchw(xg.grad).cpu(), xc.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(wg.grad.cpu(), wc.grad, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(bg.grad.cpu(), bc.grad, rtol=1e-4, atol=2e-5)
+    if res:
+        torch.testing.assert_close(_nchw(rg.grad).cpu(), rc.grad, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,hw,relu,res', [(64, 64, 1, 1, 16, True, False), (64, 64, 3, 1, 14, True, False),
+                                                            (128, 256, 1, 2, 12, False, False), (64, 256, 1, 1, 10, True, True),
+                                                            (3, 64, 7, 2, 32, True, False)])
+def test_conv_bn_fn_grads(cin, cout, k, stride, hw, relu, res):
+    from yolact_minimal_amd.train_engine import ConvBn
+    from yolact_minimal_amd import hip
+    g = torch.Generator().manual_seed(cin * 3 + cout + k)
+    x = torch.randn(3, cin, hw, hw, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * (1 / (cin * k * k) ** 0.5)
+    gamma, beta = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    rm, rv = torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5
+    pad = k // 2
+    ho = (hw + 2 * pad - k) // stride + 1
+    r = torch.randn(3, cout, ho, ho, generator=g) if res else None
+    xc, wc, gc, bc = (t.clone().requires_grad_() for t in (x, w, gamma, beta))
+    rc = r.clone().requires_grad_() if res else None
+    rmc, rvc = rm.clone(), rv.clone()
+    y = F.batch_norm(F.conv2d(xc, wc, None, stride, pad), rmc, rvc, gc, bc, True, 0.1, 1e-5)
+    if res:
+        y = y + rc
+    if relu:
+        y = F.relu(y)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    if cin == 3:
+        xin = torch.zeros(3, hw, hw, 4)
+        xin[..., :3] = _nhwc(x)
+        xg = xin.to(DEV)
+    else:
+        xg = _nhwc(x).to(DEV).requires_grad_()
+    wg, gg, bg = (t.to(DEV).requires_grad_() for t in (w, gamma, beta))
+    rg = _nhwc(r).to(DEV).requires_grad_() if res else None
+    rmg, rvg = rm.to(DEV), rv.to(DEV)
+    yg = ConvBn.apply(xg, wg, gg, bg, rmg, rvg, rg, stride, pad, relu, 0.1, 1e-5)
+    torch.testing.assert_close(_nchw(yg).cpu(), y.detach(), rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(rmg.cpu(), rmc, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rvg.cpu(), rvc, rtol=1e-5, atol=1e-6)
+    yg.backward(_nhwc(gy).to(DEV))
+    if cin != 3:
+        torch.testing.assert_close(_nchw(xg.grad).cpu(), xc.grad, rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(wg.grad.cpu(), wc.grad, rtol=2e-4, atol=5e-5)
+    torch.testing.assert_close(gg.grad.cpu(), gc.grad, rtol=2e-4, atol=5e-5)
+    torch.testing.assert_close(bg.grad.cpu(), bc.grad, rtol=2e-4, atol=5e-5)
+    if res:
+        torch.testing.assert_close(_nchw(rg.grad).cpu(), rc.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_pool_and_upsample_backward():
+    from yolact_minimal_amd.train_engine import MaxPool, Bilinear2x
+    g = torch.Generator().manual_seed(0)
+    x = torch.relu(torch.randn(2, 8, 13, 14, generator=g))          # relu: many exact ties at 0
+    xc = x.clone().requires_grad_()
+    y = F.max_pool2d(xc, 3, 2, 1)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xg = _nhwc(x).to(DEV).requires_grad_()
+    yg = MaxPool.apply(xg)
+    yg.backward(_nhwc(gy).to(DEV))
+    assert torch.equal(_nchw(yg).cpu(), y.detach())
+    torch.testing.assert_close(_nchw(xg.grad).cpu(), xc.grad, rtol=0, atol=0)
+    for align in (False, True):
+        x = torch.randn(2, 8, 9, 7, generator=g)
+        xc = x.clone().requires_grad_()
+        y = F.interpolate(xc, scale_factor=2, mode='bilinear', align_corners=align)
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy)
+        xg = _nhwc(x).to(DEV).requires_grad_()
+        yg = Bilinear2x.apply(xg, align)
+        yg.backward(_nhwc(gy).to(DEV))
+        torch.testing.assert_close(_nchw(xg.grad).cpu(), xc.grad, rtol=1e-5, atol=1e-6)
+
+
+def _oracle_grads(net, sd0, img, boxes, masks, dtype):
+    params = {k: (v.clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+    names = [k for k, _ in net.named_parameters()]
+    for k in names:
+        params[k].requires_grad_(True)
+    out = R.TrainNet(params).forward(img.to(dtype))
+    anchors = torch.tensor(net.anchors).reshape(-1, 4).to(dtype)
+    torch.set_default_dtype(dtype)
+    try:
+        losses = R.compute_loss(*out, [b.to(dtype) for b in boxes], [m.to(dtype) for m in masks], anchors)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    sum(losses).backward()
+    return [float(l.detach()) for l in losses], {k: params[k].grad.double() for k in names}, params
+
+
+def _rel_err(a, b):
+    return ((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30)).item()
+
+
+def test_train_step_matches_reference_golden(golden_dir):
+    """Four losses, every parameter gradient and the BN running stats vs the REAL reference (tests/golden/train_*.npz)
+    and vs the oracle's autograd on this host.
+
+    Conditioning: a random-init net with batch 2 at 64 px normalises 8-sample batches in layer4, so the backward
+    pass amplifies fp32 rounding by ~1e5 — the CPU fp32 oracle itself differs from the CPU fp64 oracle by ~1e-2
+    (relative to max|grad|) in the backbone.  The gradient bar is therefore "as close to the fp64 oracle as the fp32
+    CPU oracle is" (x3), per-op gradients are pinned at 1e-4 by the unit tests above, and losses at 2e-4."""
+    size = 64
+    g = np.load(os.path.join(golden_dir, f'train_res50_coco_{size}_b2.npz'))
+    seed = int(g['seed'])
+    cfg = build_cfg('res50_coco', 'train', size)
+    torch.manual_seed(seed)
+    net = Yolact(cfg).train()
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    img = torch.randn(2, 3, size, size, generator=torch.Generator().manual_seed(seed + 300))
+    boxes, masks = R.synth_targets(2, size, seed=seed)
+    l32, g32, _ = _oracle_grads(net, sd0, img, boxes, masks, torch.float32)
+    l64, g64, _ = _oracle_grads(net, sd0, img, boxes, masks, torch.float64)
+
+    net = net.to(DEV)
+    losses = net(img.to(DEV), [b.to(DEV) for b in boxes], [m.to(DEV) for m in masks])
+    sum(losses).backward()
+    got = np.array([float(l.detach()) for l in losses])
+    np.testing.assert_allclose(got, g['losses'], rtol=2e-4)          # the reference's own numbers
+    np.testing.assert_allclose(got, np.array(l64), rtol=2e-4)
+    e_gpu = np.array([_rel_err(p.grad.cpu(), g64[k]) for k, p in net.named_parameters()])
+    e_cpu = np.array([_rel_err(g32[k], g64[k]) for k, _ in net.named_parameters()])
+    # (the f32 MFMA accumulates a K-ordered fmaf chain, oneDNN on the CPU sums in blocks: ~3x the rounding noise)
+    assert np.median(e_gpu) <= 4 * np.median(e_cpu) + 1e-5, (np.median(e_gpu), np.median(e_cpu))
+    assert np.quantile(e_gpu, 0.9) <= 4 * np.quantile(e_cpu, 0.9) + 1e-4, (np.quantile(e_gpu, 0.9), np.quantile(e_cpu, 0.9))
+    assert e_gpu.max() <= 10 * e_cpu.max() + 1e-4, (e_gpu.max(), e_cpu.max())
+    # well-conditioned part of the net (everything after the backbone): tight
+    for k, p in net.named_parameters():
+        if k.startswith(('prediction_layers', 'semantic_seg_conv', 'fpn.pred_layers', 'fpn.downsample_layers')):
+            assert _rel_err(p.grad.cpu(), g64[k]) < 2e-3, k
+    gc1 = net.backbone.conv1.weight.grad.cpu().numpy()
+    assert np.abs(gc1 - g['grad_conv1']).max() <= 0.1 * np.abs(g['grad_conv1']).max()
+    np.testing.assert_allclose(net.backbone.bn1.running_mean.cpu().numpy(), g['run_mean_stem'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(net.backbone.bn1.running_var.cpu().numpy(), g['run_var_stem'], rtol=1e-4, atol=1e-6)
+    assert int(net.backbone.bn1.num_batches_tracked) == 1
+
+
+def test_train_losses_128_match_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'train_res50_coco_128_b2.npz'))
+    seed = int(g['seed'])
+    cfg = build_cfg('res50_coco', 'train', 128)
+    torch.manual_seed(seed)
+    net = Yolact(cfg).train().to(DEV)
+    img = torch.randn(2, 3, 128, 128, generator=torch.Generator().manual_seed(seed + 300))
+    boxes, masks = R.synth_targets(2, 128, seed=seed)
+    losses = net(img.to(DEV), [b.to(DEV) for b in boxes], [m.to(DEV) for m in masks])
+    np.testing.assert_allclose(np.array([float(l.detach()) for l in losses]), g['losses'], rtol=3e-4)
+    sum(losses).backward()
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters())

@@ -28,6 +28,7 @@ namespace {
 constexpr int PITCH = 36;  // floats
 
 // MODE 0: Cin % 32 == 0 (every K tile lies inside one filter tap).  MODE 1: Cin == 4 (stem; one tap per float4).
+// MODE 2: data gradient (transposed conv): output pixel (ih,iw) gathers dY[(ih+pad-kh)/s][(iw+pad-kw)/s] where divisible.
 template <int BM, int BN, int MODE>
 __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
     constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave (wave tile = BM/2 x BN/2)
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
     // ---- per-thread staging coordinates -------------------------------------------------------
     const int c4 = tid & 7;      // which float4 of the 32-float K row
     const int rbase = tid >> 3;  // 0..31
-    int a_pix[AR];               // (b*H + ih0)*W + iw0   (may be negative; only used when in range)
+    int a_pix[AR];               // (b*H + ih0)*W + iw0   (may be negative; only used when in range); MODE 2: b*H
     int a_ih0[AR], a_iw0[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
@@ -60,9 +61,15 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
         if (m < p.M) {
             const int b = m / p.HoWo, rem = m - b * p.HoWo;
             const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
-            a_ih0[i] = oh * p.stride - p.pad;
-            a_iw0[i] = ow * p.stride - p.pad;
-            a_pix[i] = (b * p.H + a_ih0[i]) * p.W + a_iw0[i];
+            if (MODE == 2) {
+                a_ih0[i] = oh + p.pad;
+                a_iw0[i] = ow + p.pad;
+                a_pix[i] = b * p.H;
+            } else {
+                a_ih0[i] = oh * p.stride - p.pad;
+                a_iw0[i] = ow * p.stride - p.pad;
+                a_pix[i] = (b * p.H + a_ih0[i]) * p.W + a_iw0[i];
+            }
         } else {
             a_ih0[i] = -(1 << 20);
             a_iw0[i] = -(1 << 20);
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
 
     // tap walker for MODE 0 (uniform across the block)
     int kh = 0, kw = 0, c0 = 0;
-    if (MODE == 0) {
+    if (MODE == 0 || MODE == 2) {
         const int k0 = kt_beg * BK;
         const int tap = k0 / p.Cin;
         c0 = k0 - tap * p.Cin;
@@ -96,6 +103,26 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
                 const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
                 if (ok) {
                     const float* src = p.in + (size_t)(a_pix[i] + tap_off) * p.Cin + c0 + c4 * 4;
+                    ra[i] = *reinterpret_cast<const f32x4*>(src);
+                } else {
+                    ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            c0 += BK;
+            if (c0 >= p.Cin) {
+                c0 = 0;
+                if (++kw == p.KW) { kw = 0; ++kh; }
+            }
+        } else if (MODE == 2) {
+            const int sh = p.stride >> 1;            // stride is 1 or 2
+            const int smask = p.stride - 1;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const int th = a_ih0[i] - kh, tw = a_iw0[i] - kw;
+                const int yh = th >> sh, yw = tw >> sh;
+                const bool ok = th >= 0 && tw >= 0 && ((th | tw) & smask) == 0 && yh < p.H && yw < p.W;
+                if (ok) {
+                    const float* src = p.in + ((size_t)(a_pix[i] + yh) * p.W + yw) * p.Cin + c0 + c4 * 4;
                     ra[i] = *reinterpret_cast<const f32x4*>(src);
                 } else {
                     ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -318,8 +345,15 @@ int make_plan(const ym_conv_desc* d, Plan* pl) {
     YM_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cout > 0, "conv: bad shape");
     YM_REQUIRE(d->Cin == 4 || d->Cin % 32 == 0, "conv: Cin must be 4 (stem) or a multiple of 32, got %d", d->Cin);
     YM_REQUIRE(d->k_pad % BK == 0 && d->k_pad >= d->KH * d->KW * d->Cin, "conv: k_pad %d invalid", d->k_pad);
-    YM_REQUIRE(d->Ho == (d->H + 2 * d->pad - d->KH) / d->stride + 1 && d->Wo == (d->W + 2 * d->pad - d->KW) / d->stride + 1,
-               "conv: Ho/Wo inconsistent with H/W/K/stride/pad");
+    if (d->transposed) {
+        YM_REQUIRE(d->stride == 1 || d->stride == 2, "conv(dgrad): stride must be 1 or 2");
+        YM_REQUIRE(d->Cin % 32 == 0 && d->kwaves == 0, "conv(dgrad): dy channels must be padded to a multiple of 32; workgroup kernel only");
+        YM_REQUIRE(d->H == (d->Ho + 2 * d->pad - d->KH) / d->stride + 1 && d->W == (d->Wo + 2 * d->pad - d->KW) / d->stride + 1,
+                   "conv(dgrad): H/W (dy) inconsistent with Ho/Wo (dx)");
+    } else {
+        YM_REQUIRE(d->Ho == (d->H + 2 * d->pad - d->KH) / d->stride + 1 && d->Wo == (d->W + 2 * d->pad - d->KW) / d->stride + 1,
+                   "conv: Ho/Wo inconsistent with H/W/K/stride/pad");
+    }
     YM_REQUIRE(d->nseg >= 1 && d->nseg <= 3, "conv: nseg must be 1..3");
     for (int s = 0; s < d->nseg; ++s)
         YM_REQUIRE(d->seg[s].out && d->seg[s].n_end > d->seg[s].n_begin && d->seg[s].n_end <= d->Cout,
@@ -424,7 +458,12 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
     hipStream_t st = (hipStream_t)s;
     if (d->kwaves > 0) return ym_launch_conv_wave(p, pl.bm, pl.bn, d->kwaves, st);
     const int grid = pl.tiles_m * pl.tiles_n * pl.ksplit;
-    if (d->Cin == 4) launch<128, 64, 1>(p, grid, st);
+    if (d->transposed) {
+        if (pl.bm == 128 && pl.bn == 128) launch<128, 128, 2>(p, grid, st);
+        else if (pl.bm == 128 && pl.bn == 64) launch<128, 64, 2>(p, grid, st);
+        else if (pl.bm == 64 && pl.bn == 128) launch<64, 128, 2>(p, grid, st);
+        else launch<64, 64, 2>(p, grid, st);
+    } else if (d->Cin == 4) launch<128, 64, 1>(p, grid, st);
     else if (pl.bm == 128 && pl.bn == 128) launch<128, 128, 0>(p, grid, st);
     else if (pl.bm == 128 && pl.bn == 64) launch<128, 64, 0>(p, grid, st);
     else if (pl.bm == 64 && pl.bn == 128) launch<64, 128, 0>(p, grid, st);

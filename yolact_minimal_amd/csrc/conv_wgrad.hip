@@ -1,0 +1,211 @@
+// Weight gradient of the fused convolution on the f32 MFMA pipe (gfx950).
+//
+//   dW[n][kk] = sum_m dY[m][n] * Xg[m][kk]      n = output channel, kk = (kh, kw, ci), m = output pixel (b, oh, ow)
+//
+// GEMM with the REDUCTION over pixels (M is 10^3..10^6) and a small output ([Cout][KH*KW*Cin]).  Both operands are
+// contiguous along the MFMA row/column index (dY rows are Cout floats, X rows are Cin floats of one tap), so the
+// 32x32x2 fragments are read from LDS as conflict-free ds_read_b32: lanes 0-31 = 32 consecutive n (or kk) of pixel
+// m, lanes 32-63 the same for pixel m+1.  Workgroup tile 128(n) x 128(kk), 4 waves 2x2 of 64x64, pixel step 32,
+// register-staged double-buffered LDS.  The pixel range is split across the grid (`msplit`), partial tiles go to
+// a caller-provided workspace and a reduce kernel sums them in fixed order and scatters into the OIHW gradient.
+#include "conv_common.h"
+
+using namespace ymk;
+
+namespace {
+
+constexpr int TBN = 128;   // n tile
+constexpr int TBK = 128;   // kk tile
+constexpr int TBM = 32;    // pixels per step
+constexpr int LP = 132;    // LDS row pitch (floats): 16-byte aligned rows, skewed banks for the float4 writes
+
+struct WgradP {
+    const float* x;     // NHWC [B][H][W][Cinp]
+    const float* dy;    // [M][Cout] (M = B*Ho*Wo)
+    float* ws;          // [msplit][Cout][Ktot]
+    int B, H, W, Cinp, Cout, KH, KW, stride, pad, Ho, Wo;
+    int M, HoWo, Ktot, tiles_n, tiles_k, msplit, m_per_split;
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradP p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ys = smem;                       // [2][TBM][LP]
+    float* Xs = smem + 2 * TBM * LP;        // [2][TBM][LP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1;
+
+    int id = ym_xcd_remap(blockIdx.x, gridDim.x);
+    const int ms = id % p.msplit;
+    id /= p.msplit;
+    const int tile_n = id / p.tiles_k, tile_k = id - tile_n * p.tiles_k;
+    const int n0 = tile_n * TBN, k0 = tile_k * TBK;
+    const int m_beg = ms * p.m_per_split, m_end = min(p.M, m_beg + p.m_per_split);
+
+    // staging: thread -> float4 column c4 (0..31) of rows r + 8*i
+    const int c4 = tid & 31, r0 = tid >> 5;
+    const int ncol = n0 + c4 * 4;
+    const bool n_ok = ncol < p.Cout;
+    const int kk = k0 + c4 * 4;
+    const bool k_ok = kk < p.Ktot;
+    const int tap = k_ok ? kk / p.Cinp : 0, ci = kk - tap * p.Cinp;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+
+    f32x4 ry[4], rx[4];
+    auto load = [&](int mt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = mt + r0 + 8 * i;
+            ry[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            rx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (m < m_end) {
+                if (n_ok) ry[i] = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.Cout + ncol);
+                if (k_ok) {
+                    const int b = m / p.HoWo, rem = m - b * p.HoWo;
+                    const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+                    const int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
+                    if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+                        rx[i] = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(b * p.H + ih) * p.W + iw) * p.Cinp + ci);
+                }
+            }
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(Ys + (buf * TBM + r0 + 8 * i) * LP + c4 * 4) = ry[i];
+            *reinterpret_cast<f32x4*>(Xs + (buf * TBM + r0 + 8 * i) * LP + c4 * 4) = rx[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int fr = lane & 31, khalf = lane >> 5;
+    if (m_beg < m_end) { load(m_beg); store(0); }
+    __syncthreads();
+    int cur = 0;
+    for (int mt = m_beg; mt < m_end; mt += TBM) {
+        const bool more = mt + TBM < m_end;
+        if (more) load(mt + TBM);
+        const float* ya = Ys + cur * TBM * LP + wn * 64 + fr;
+        const float* xb = Xs + cur * TBM * LP + wk * 64 + fr;
+#pragma unroll
+        for (int s = 0; s < TBM / 2; ++s) {
+            const int row = 2 * s + khalf;
+            const float a0 = ya[row * LP], a1 = ya[row * LP + 32];
+            const float b0 = xb[row * LP], b1 = xb[row * LP + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) store(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // D[i = n][j = kk]: col = lane&31 -> kk, row = (r&3) + 8*(r>>2) + 4*khalf -> n
+    float* wsb = p.ws + (size_t)ms * p.Cout * p.Ktot;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int kcol = k0 + wk * 64 + j * 32 + fr;
+        if (kcol >= p.Ktot) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * 64 + i * 32 + 4 * khalf + (r & 3) + 8 * (r >> 2);
+                if (n < p.Cout) wsb[(size_t)n * p.Ktot + kcol] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+// sum the msplit slabs in order and scatter [n][tap][ci] -> OIHW [n][ci][kh][kw] (ci < Cin_real)
+__global__ __launch_bounds__(256) void wgrad_reduce_unpack(const float* __restrict__ ws, float* __restrict__ dw_oihw, int msplit,
+                                                           int Cout_real, int Cout, int Ktot, int Cinp, int Cin_real, int KHW) {
+    const size_t total = (size_t)Cout_real * Ktot;
+    const size_t slab = (size_t)Cout * Ktot;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int n = (int)(e / Ktot), kk = (int)(e - (size_t)n * Ktot);
+        const int tap = kk / Cinp, ci = kk - tap * Cinp;
+        if (ci >= Cin_real) continue;
+        float v = 0.f;
+        for (int s = 0; s < msplit; ++s) v += ws[(size_t)s * slab + e];
+        dw_oihw[((size_t)n * Cin_real + ci) * KHW + tap] = v;
+    }
+}
+
+struct WPlan { int M, Ktot, tiles_n, tiles_k, msplit, m_per_split; };
+
+int wplan(const ym_wgrad_desc* d, WPlan* pl) {
+    YM_REQUIRE(d && d->x && d->dy && d->dw, "wgrad: null pointer");
+    YM_REQUIRE(d->Cin == 4 || d->Cin % 4 == 0, "wgrad: Cin (padded) must be a multiple of 4");
+    YM_REQUIRE(d->Cout % 4 == 0, "wgrad: dy channel pitch must be a multiple of 4 (pad it)");
+    YM_REQUIRE(d->Cin_real >= 1 && d->Cin_real <= d->Cin && d->Cout_real >= 1 && d->Cout_real <= d->Cout, "wgrad: real channel counts");
+    YM_REQUIRE(d->Ho == (d->H + 2 * d->pad - d->KH) / d->stride + 1 && d->Wo == (d->W + 2 * d->pad - d->KW) / d->stride + 1,
+               "wgrad: Ho/Wo inconsistent");
+    const long long M = (long long)d->B * d->Ho * d->Wo;
+    YM_REQUIRE(M * d->Cout < (1ll << 31) && (long long)d->B * d->H * d->W * d->Cin < (1ll << 31), "wgrad: tensor too large");
+    pl->M = (int)M;
+    pl->Ktot = d->KH * d->KW * d->Cin;
+    pl->tiles_n = ym_cdiv(d->Cout, TBN);
+    pl->tiles_k = ym_cdiv(pl->Ktot, TBK);
+    int ms = d->msplit;
+    if (ms <= 0) {
+        const int tiles = pl->tiles_n * pl->tiles_k;
+        ms = ym_cdiv(768, tiles);
+        const int max_ms = ym_cdiv(pl->M, 8 * TBM);      // at least 8 pixel steps per slice
+        if (ms > max_ms) ms = max_ms;
+        if (ms > 256) ms = 256;
+        if (ms < 1) ms = 1;
+    }
+    int per = ym_cdiv(pl->M, ms);
+    per = ym_cdiv(per, TBM) * TBM;
+    pl->m_per_split = per;
+    pl->msplit = ym_cdiv(pl->M, per);
+    return YM_OK;
+}
+
+}  // namespace
+
+extern "C" size_t ym_conv2d_wgrad_workspace_bytes(const ym_wgrad_desc* d) {
+    WPlan pl;
+    if (wplan(d, &pl) != YM_OK) return 0;
+    return (size_t)pl.msplit * d->Cout * pl.Ktot * sizeof(float);
+}
+
+extern "C" int ym_conv2d_wgrad(const ym_wgrad_desc* d, void* workspace, size_t workspace_bytes, ym_stream_t s) {
+    WPlan pl;
+    int rc = wplan(d, &pl);
+    if (rc != YM_OK) return rc;
+    const size_t need = (size_t)pl.msplit * d->Cout * pl.Ktot * sizeof(float);
+    if (!workspace || workspace_bytes < need) { ym_set_error("wgrad: workspace %zu B < %zu B", workspace_bytes, need); return YM_ENOSPC; }
+    WgradP p;
+    p.x = d->x; p.dy = d->dy; p.ws = (float*)workspace;
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Cinp = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW;
+    p.stride = d->stride; p.pad = d->pad; p.Ho = d->Ho; p.Wo = d->Wo;
+    p.M = pl.M; p.HoWo = d->Ho * d->Wo; p.Ktot = pl.Ktot; p.tiles_n = pl.tiles_n; p.tiles_k = pl.tiles_k;
+    p.msplit = pl.msplit; p.m_per_split = pl.m_per_split;
+    hipStream_t st = (hipStream_t)s;
+    const size_t lds = (size_t)4 * TBM * LP * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_f32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad_f32, dim3(pl.tiles_n * pl.tiles_k * pl.msplit), dim3(256), lds, st, p);
+    rc = ym_check_launch("conv_wgrad_f32");
+    if (rc != YM_OK) return rc;
+    const size_t total = (size_t)d->Cout_real * pl.Ktot;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_unpack, dim3(grid), dim3(256), 0, st, (const float*)workspace, d->dw, pl.msplit, d->Cout_real,
+                       d->Cout, pl.Ktot, d->Cin, d->Cin_real, d->KH * d->KW);
+    return ym_check_launch("wgrad_reduce_unpack");
+}

@@ -1,0 +1,406 @@
+// Training-side NHWC helpers for gfx950: batch-norm (batch statistics) forward/backward, activation backward,
+// per-channel column sums (bias gradients), max-pool and bilinear x2 backward, dgrad weight packing, SGD.
+// All tensors are [M][C] fp32 with C contiguous (M = B*H*W); every kernel is HBM-bound and uses 16-byte accesses.
+// Channel reductions accumulate in fp64 (MI355X has a full-rate fp64 vector pipe) so that var = E[x^2]-E[x]^2 is
+// safe and the result does not depend on the reduction tree shape beyond fp64 rounding.
+#include "ym_common.h"
+
+namespace {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+inline int rows_grid(long long M, int C4, int rows_per_block_hint = 64) {
+    // one block handles 256 threads = (256 / C4cols) row lanes; grid sized to cover M with ~64 rows per thread
+    (void)C4;
+    long long blocks = (M + rows_per_block_hint - 1) / rows_per_block_hint;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+// ---- column reductions ------------------------------------------------------------------------------------
+// Thread (cq, rl): channel quad cq = tid % CQ, row lane rl = tid / CQ, CQ = min(C/4, 256).  Each block walks rows
+// rl + k*RL of its row range; partials are combined through LDS and then one fp64 atomicAdd per (block, channel).
+// MODE 0: sum x, sum x^2           (bn forward statistics)
+// MODE 1: sum dz, sum dz*xhat      (bn backward; dz = dout masked by relu(out))
+// MODE 2: sum dz                   (bias gradient; dz = dy * act'(y))
+template <int MODE>
+__global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ a, const float* __restrict__ b,
+                                                     const float* __restrict__ c, const float* __restrict__ mean,
+                                                     const float* __restrict__ invstd, long long M, int C, int relu, int act,
+                                                     double* __restrict__ out0, double* __restrict__ out1) {
+    const int C4 = C >> 2;
+    const int CQ = C4 < 256 ? C4 : 256;
+    const int RL = 256 / CQ;
+    const int tid = threadIdx.x;
+    const int cq_l = tid % CQ, rl = tid / CQ;
+    __shared__ double red[2][256][4];
+    for (int cq0 = 0; cq0 < C4; cq0 += CQ) {
+        const int cq = cq0 + cq_l;
+        f64x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+        if (rl < RL && cq < C4) {
+            f32x4 mu = {0, 0, 0, 0}, is = {1, 1, 1, 1};
+            if (MODE == 1) { mu = *reinterpret_cast<const f32x4*>(mean + cq * 4); is = *reinterpret_cast<const f32x4*>(invstd + cq * 4); }
+            for (long long m = (long long)blockIdx.x * RL + rl; m < M; m += (long long)gridDim.x * RL) {
+                const size_t off = (size_t)m * C + cq * 4;
+                const f32x4 x = *reinterpret_cast<const f32x4*>(a + off);
+                if (MODE == 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const double v = x[e]; s0[e] += v; s1[e] += v * v; }
+                } else if (MODE == 1) {
+                    // a = dout, b = out (post-activation, for the relu mask), c = y_raw
+                    f32x4 dz = x;
+                    if (relu) {
+                        const f32x4 o = *reinterpret_cast<const f32x4*>(b + off);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dz[e] = o[e] > 0.f ? dz[e] : 0.f;
+                    }
+                    const f32x4 y = *reinterpret_cast<const f32x4*>(c + off);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const double d = dz[e]; s0[e] += d; s1[e] += d * (double)((y[e] - mu[e]) * is[e]); }
+                } else {
+                    // a = dy, b = y (post-activation)
+                    f32x4 dz = x;
+                    if (act) {
+                        const f32x4 y = *reinterpret_cast<const f32x4*>(b + off);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            dz[e] = act == YM_ACT_RELU ? (y[e] > 0.f ? dz[e] : 0.f) : dz[e] * (1.f - y[e] * y[e]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s0[e] += (double)dz[e];
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[0][tid][e] = s0[e]; red[1][tid][e] = s1[e]; }
+        __syncthreads();
+        if (rl == 0 && cq < C4) {
+            for (int r = 1; r < RL; ++r)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s0[e] += red[0][r * CQ + cq_l][e]; s1[e] += red[1][r * CQ + cq_l][e]; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                atomicAdd(out0 + cq * 4 + e, s0[e]);
+                if (MODE != 2) atomicAdd(out1 + cq * 4 + e, s1[e]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_bn_finalize(const double* sum, const double* sumsq, long long M, float eps, float momentum, float* mean,
+                              float* invstd, float* run_mean, float* run_var, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mu = sum[c] / (double)M;
+    double var = sumsq[c] / (double)M - mu * mu;
+    if (var < 0) var = 0;
+    mean[c] = (float)mu;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (run_mean) {
+        const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        run_mean[c] = (float)((1.0 - momentum) * (double)run_mean[c] + momentum * mu);
+        run_var[c] = (float)((1.0 - momentum) * (double)run_var[c] + momentum * unbiased);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ y, const float* __restrict__ mean,
+                                                   const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, const float* __restrict__ residual,
+                                                   int relu, float* __restrict__ out, long long M, int C) {
+    const int C4 = C >> 2;
+    const size_t total = (size_t)M * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int cq = (int)(i % C4);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + cq * 4), is = *reinterpret_cast<const f32x4*>(invstd + cq * 4);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + cq * 4), b = *reinterpret_cast<const f32x4*>(beta + cq * 4);
+        f32x4 v = *reinterpret_cast<const f32x4*>(y + i * 4);
+        v = (v - mu) * is * g + b;
+        if (residual) v += *reinterpret_cast<const f32x4*>(residual + i * 4);
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];
+        }
+        *reinterpret_cast<f32x4*>(out + i * 4) = v;
+    }
+}
+
+// dy_raw = gamma*invstd * (dz - dbeta/M - xhat * dgamma/M); dres = dz
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ dout, const float* __restrict__ out,
+                                                       const float* __restrict__ y, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                       const double* __restrict__ dbeta, const double* __restrict__ dgamma,
+                                                       int relu, float* __restrict__ dy, float* __restrict__ dres, long long M,
+                                                       int C) {
+    const int C4 = C >> 2;
+    const size_t total = (size_t)M * C4;
+    const float invM = 1.f / (float)M;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int cq = (int)(i % C4);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + cq * 4), is = *reinterpret_cast<const f32x4*>(invstd + cq * 4);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + cq * 4);
+        f32x4 dz = *reinterpret_cast<const f32x4*>(dout + i * 4);
+        if (relu) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(out + i * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dz[e] = o[e] > 0.f ? dz[e] : 0.f;
+        }
+        if (dres) *reinterpret_cast<f32x4*>(dres + i * 4) = dz;
+        const f32x4 yy = *reinterpret_cast<const f32x4*>(y + i * 4);
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (yy[e] - mu[e]) * is[e];
+            r[e] = g[e] * is[e] * (dz[e] - (float)dbeta[cq * 4 + e] * invM - xh * (float)dgamma[cq * 4 + e] * invM);
+        }
+        *reinterpret_cast<f32x4*>(dy + i * 4) = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ dy, const float* __restrict__ y, int act,
+                                                  float* __restrict__ dz, size_t total4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        f32x4 d = *reinterpret_cast<const f32x4*>(dy + i * 4);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(y + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = act == YM_ACT_RELU ? (v[e] > 0.f ? d[e] : 0.f) : d[e] * (1.f - v[e] * v[e]);
+        *reinterpret_cast<f32x4*>(dz + i * 4) = d;
+    }
+}
+
+__global__ void k_f64_to_f32(const double* in, float* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
+}
+
+// MaxPool2d(3,2,1) backward: every input pixel gathers from the (at most 4) windows that contain it and takes the
+// gradient of those whose FIRST maximum (scan order kh, kw — ATen's tie rule) is this pixel.
+__global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ x, const float* __restrict__ dy,
+                                                      float* __restrict__ dx, int B, int H, int W, int C4, int Ho, int Wo) {
+    const size_t total = (size_t)B * H * W * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        size_t t = i / C4;
+        const int iw = (int)(t % W); t /= W;
+        const int ih = (int)(t % H);
+        const int b = (int)(t / H);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i * 4);
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        // windows containing the pixel: oh*2-1 <= ih <= oh*2+1  <=>  ih/2 <= oh <= (ih+1)/2
+        for (int oh = ih / 2; oh <= (ih + 1) / 2 && oh < Ho; ++oh) {
+            for (int ow = iw / 2; ow <= (iw + 1) / 2 && ow < Wo; ++ow) {
+                // is (ih, iw) the first max of window (oh, ow)?
+                bool first[4] = {true, true, true, true};
+#pragma unroll
+                for (int dyy = 0; dyy < 3; ++dyy) {
+                    const int y2 = oh * 2 - 1 + dyy;
+                    if ((unsigned)y2 >= (unsigned)H) continue;
+#pragma unroll
+                    for (int dxx = 0; dxx < 3; ++dxx) {
+                        const int x2 = ow * 2 - 1 + dxx;
+                        if ((unsigned)x2 >= (unsigned)W) continue;
+                        if (y2 == ih && x2 == iw) continue;
+                        const f32x4 o = *reinterpret_cast<const f32x4*>(x + ((((size_t)b * H + y2) * W + x2) * C4 + c) * 4);
+                        const bool before = (y2 < ih) || (y2 == ih && x2 < iw);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            // another element wins if it is larger, or equal and earlier in scan order (NaN: ATen keeps NaN max)
+                            if (o[e] > xv[e] || (o[e] == xv[e] && before) || (o[e] != o[e] && !(xv[e] != xv[e]))) first[e] = false;
+                        }
+                    }
+                }
+                const f32x4 d = *reinterpret_cast<const f32x4*>(dy + ((((size_t)b * Ho + oh) * Wo + ow) * C4 + c) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] += first[e] ? d[e] : 0.f;
+            }
+        }
+        *reinterpret_cast<f32x4*>(dx + i * 4) = g;
+    }
+}
+
+__device__ __forceinline__ void bil_src(int dst, int in_sz, int out_sz, int align, int& i0, int& i1, float& l1) {
+    float src;
+    if (align) {
+        const float sc = out_sz > 1 ? (float)(in_sz - 1) / (float)(out_sz - 1) : 0.f;
+        src = sc * dst;
+    } else {
+        src = 0.5f * (dst + 0.5f) - 0.5f;
+        if (src < 0.f) src = 0.f;
+    }
+    i0 = (int)src;
+    if (i0 > in_sz - 1) i0 = in_sz - 1;
+    i1 = i0 + ((i0 < in_sz - 1) ? 1 : 0);
+    l1 = src - (float)i0;
+}
+
+// Bilinear x2 backward as a GATHER (deterministic): every input pixel sums the contributions of the <= 4x4 output
+// pixels whose interpolation footprint contains it.
+__global__ __launch_bounds__(256) void k_bilinear2x_bwd(const float* __restrict__ dy, float* __restrict__ dx, int B, int H,
+                                                         int W, int C4, int align) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const size_t total = (size_t)B * H * W * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        size_t t = i / C4;
+        const int iw = (int)(t % W); t /= W;
+        const int ih = (int)(t % H);
+        const int b = (int)(t / H);
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        const int oy_lo = max(0, 2 * ih - 3), oy_hi = min(Ho - 1, 2 * ih + 3);
+        const int ox_lo = max(0, 2 * iw - 3), ox_hi = min(Wo - 1, 2 * iw + 3);
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            int y0, y1; float ly;
+            bil_src(oy, H, Ho, align, y0, y1, ly);
+            const float wy = (y0 == ih ? 1.f - ly : 0.f) + (y1 == ih ? ly : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                int x0, x1; float lx;
+                bil_src(ox, W, Wo, align, x0, x1, lx);
+                const float wx = (x0 == iw ? 1.f - lx : 0.f) + (x1 == iw ? lx : 0.f);
+                if (wx == 0.f) continue;
+                const f32x4 d = *reinterpret_cast<const f32x4*>(dy + ((((size_t)b * Ho + oy) * Wo + ox) * C4 + c) * 4);
+                g += d * (wy * wx);
+            }
+        }
+        *reinterpret_cast<f32x4*>(dx + i * 4) = g;
+    }
+}
+
+// OIHW -> [Cin][KH][KW][cout_pad] (the "transposed" packing read by the dgrad gather), zero padded
+__global__ void k_pack_weight_dgrad(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int KH, int KW,
+                                    int cout_pad) {
+    const size_t total = (size_t)Cin * KH * KW * cout_pad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % cout_pad);
+        size_t t = i / cout_pad;
+        const int kw = (int)(t % KW); t /= KW;
+        const int kh = (int)(t % KH);
+        const int ci = (int)(t / KH);
+        out[i] = co < Cout ? w[(((size_t)co * Cin + ci) * KH + kh) * KW + kw] : 0.f;
+    }
+}
+
+// SGD with momentum and weight decay over a flat parameter buffer (torch.optim.SGD semantics, dampening 0, no nesterov):
+//   g = grad + wd * p ; buf = first ? g : mom * buf + g ; p -= lr * buf
+__global__ __launch_bounds__(256) void k_sgd(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                              size_t n, float lr, float mom, float wd, int first) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float gg = g[i] + wd * p[i];
+        const float b = first ? gg : mom * buf[i] + gg;
+        buf[i] = b;
+        p[i] -= lr * b;
+    }
+}
+
+inline int ew_grid(size_t total, int cap = 8192) {
+    size_t g = (total + 255) / 256;
+    if (g > (size_t)cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" int ym_bn_train_fwd(const float* y, int64_t M, int C, const float* gamma, const float* beta, float eps,
+                               float momentum, float* running_mean, float* running_var, const float* residual, int relu,
+                               float* out, float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes,
+                               ym_stream_t s) {
+    YM_REQUIRE(y && gamma && beta && out && save_mean && save_invstd && workspace, "bn_train_fwd: null pointer");
+    YM_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_train_fwd: C %% 4 != 0");
+    if (workspace_bytes < (size_t)C * 16) { ym_set_error("bn_train_fwd: workspace < %d B", C * 16); return YM_ENOSPC; }
+    hipStream_t st = (hipStream_t)s;
+    double* sum = (double*)workspace;
+    double* sumsq = sum + C;
+    (void)hipMemsetAsync(sum, 0, (size_t)C * 16, st);
+    const int CQ = (C / 4) < 256 ? (C / 4) : 256, RL = 256 / CQ;
+    int grid = (int)((M + (long long)RL * 32 - 1) / ((long long)RL * 32));
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_col_reduce<0>, dim3(grid), dim3(256), 0, st, y, nullptr, nullptr, nullptr, nullptr, (long long)M, C, 0,
+                       0, sum, sumsq);
+    hipLaunchKernelGGL(k_bn_finalize, dim3(ym_cdiv(C, 256)), dim3(256), 0, st, sum, sumsq, (long long)M, eps, momentum,
+                       save_mean, save_invstd, running_mean, running_var, C);
+    hipLaunchKernelGGL(k_bn_apply, dim3(ew_grid((size_t)M * (C / 4))), dim3(256), 0, st, y, save_mean, save_invstd, gamma, beta,
+                       residual, relu, out, (long long)M, C);
+    return ym_check_launch("bn_train_fwd");
+}
+
+extern "C" int ym_bn_train_bwd(const float* dout, const float* out, const float* y, int64_t M, int C, const float* gamma,
+                               const float* save_mean, const float* save_invstd, int relu, float* dy, float* dres,
+                               float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, ym_stream_t s) {
+    YM_REQUIRE(dout && y && gamma && save_mean && save_invstd && dy && dgamma && dbeta && workspace && (out || !relu),
+               "bn_train_bwd: null pointer");
+    YM_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_train_bwd: C %% 4 != 0");
+    if (workspace_bytes < (size_t)C * 16) { ym_set_error("bn_train_bwd: workspace < %d B", C * 16); return YM_ENOSPC; }
+    hipStream_t st = (hipStream_t)s;
+    double* db = (double*)workspace;
+    double* dg = db + C;
+    (void)hipMemsetAsync(db, 0, (size_t)C * 16, st);
+    const int CQ = (C / 4) < 256 ? (C / 4) : 256, RL = 256 / CQ;
+    int grid = (int)((M + (long long)RL * 32 - 1) / ((long long)RL * 32));
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_col_reduce<1>, dim3(grid), dim3(256), 0, st, dout, out, y, save_mean, save_invstd, (long long)M, C,
+                       relu, 0, db, dg);
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid((size_t)M * (C / 4))), dim3(256), 0, st, dout, out, y, save_mean,
+                       save_invstd, gamma, db, dg, relu, dy, dres, (long long)M, C);
+    hipLaunchKernelGGL(k_f64_to_f32, dim3(ym_cdiv(C, 256)), dim3(256), 0, st, db, dbeta, C);
+    hipLaunchKernelGGL(k_f64_to_f32, dim3(ym_cdiv(C, 256)), dim3(256), 0, st, dg, dgamma, C);
+    return ym_check_launch("bn_train_bwd");
+}
+
+extern "C" int ym_act_bias_bwd(const float* dy, const float* y, int64_t M, int C, int act, float* dz, float* dbias,
+                               void* workspace, size_t workspace_bytes, ym_stream_t s) {
+    YM_REQUIRE(dy && (y || act == YM_ACT_NONE) && M > 0 && C > 0 && C % 4 == 0, "act_bias_bwd: bad args");
+    hipStream_t st = (hipStream_t)s;
+    if (dz && act != YM_ACT_NONE)
+        hipLaunchKernelGGL(k_act_bwd, dim3(ew_grid((size_t)M * (C / 4))), dim3(256), 0, st, dy, y, act, dz, (size_t)M * (C / 4));
+    if (dbias) {
+        YM_REQUIRE(workspace, "act_bias_bwd: workspace");
+        if (workspace_bytes < (size_t)C * 8) { ym_set_error("act_bias_bwd: workspace < %d B", C * 8); return YM_ENOSPC; }
+        double* acc = (double*)workspace;
+        (void)hipMemsetAsync(acc, 0, (size_t)C * 8, st);
+        const int CQ = (C / 4) < 256 ? (C / 4) : 256, RL = 256 / CQ;
+        int grid = (int)((M + (long long)RL * 32 - 1) / ((long long)RL * 32));
+        if (grid > 2048) grid = 2048;
+        if (grid < 1) grid = 1;
+        hipLaunchKernelGGL(k_col_reduce<2>, dim3(grid), dim3(256), 0, st, dy, y, nullptr, nullptr, nullptr, (long long)M, C, 0,
+                           act, acc, nullptr);
+        hipLaunchKernelGGL(k_f64_to_f32, dim3(ym_cdiv(C, 256)), dim3(256), 0, st, acc, dbias, C);
+    }
+    return ym_check_launch("act_bias_bwd");
+}
+
+extern "C" int ym_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, ym_stream_t s) {
+    YM_REQUIRE(x && dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "maxpool_bwd: bad args");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(k_maxpool_bwd, dim3(ew_grid((size_t)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)s, x, dy, dx, B, H,
+                       W, C / 4, Ho, Wo);
+    return ym_check_launch("maxpool_bwd");
+}
+
+extern "C" int ym_bilinear2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, int align_corners, ym_stream_t s) {
+    YM_REQUIRE(dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "bilinear2x_bwd: bad args");
+    hipLaunchKernelGGL(k_bilinear2x_bwd, dim3(ew_grid((size_t)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)s, dy, dx, B, H,
+                       W, C / 4, align_corners ? 1 : 0);
+    return ym_check_launch("bilinear2x_bwd");
+}
+
+extern "C" int ym_pack_conv_weight_dgrad(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, int cout_pad,
+                                         ym_stream_t s) {
+    YM_REQUIRE(w_oihw && w_packed && Cout > 0 && Cin > 0 && cout_pad >= Cout && cout_pad % 32 == 0,
+               "pack_conv_weight_dgrad: bad args (cout_pad must be a multiple of 32)");
+    const size_t total = (size_t)Cin * KH * KW * cout_pad;
+    hipLaunchKernelGGL(k_pack_weight_dgrad, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)s, w_oihw, w_packed, Cout, Cin, KH,
+                       KW, cout_pad);
+    return ym_check_launch("pack_conv_weight_dgrad");
+}
+
+extern "C" int ym_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
+                           float weight_decay, int first_step, ym_stream_t s) {
+    YM_REQUIRE(param && grad && momentum_buf && n > 0, "sgd_step: bad args");
+    hipLaunchKernelGGL(k_sgd, dim3(ew_grid((size_t)n)), dim3(256), 0, (hipStream_t)s, param, grad, momentum_buf, (size_t)n, lr,
+                       momentum, weight_decay, first_step);
+    return ym_check_launch("sgd_step");
+}

@@ -22,6 +22,8 @@ ABI_SYMBOLS = (
     'ym_softmax_rows', 'ym_nms_workspace_bytes', 'ym_detect_fast_nms', 'ym_detect_greedy_nms',
     'ym_greedy_nms_workspace_bytes', 'ym_greedy_nms', 'ym_mask_assemble', 'ym_mask_resize_binarize',
     'ym_boxes_to_pixels',
+    'ym_pack_conv_weight_dgrad', 'ym_conv2d_wgrad_workspace_bytes', 'ym_conv2d_wgrad', 'ym_bn_train_fwd',
+    'ym_bn_train_bwd', 'ym_act_bias_bwd', 'ym_maxpool3x3s2_bwd', 'ym_bilinear2x_bwd', 'ym_sgd_step',
 )
 
 
@@ -38,7 +40,16 @@ class ConvDesc(ctypes.Structure):
                 ('stride', ctypes.c_int32), ('pad', ctypes.c_int32), ('Ho', ctypes.c_int32),
                 ('Wo', ctypes.c_int32), ('k_pad', ctypes.c_int32), ('nseg', ctypes.c_int32),
                 ('seg', ConvSeg * 3), ('tile_m', ctypes.c_int32), ('tile_n', ctypes.c_int32),
-                ('ksplit', ctypes.c_int32), ('kwaves', ctypes.c_int32)]
+                ('ksplit', ctypes.c_int32), ('kwaves', ctypes.c_int32), ('transposed', ctypes.c_int32),
+                ('reserved', ctypes.c_int32)]
+
+
+class WgradDesc(ctypes.Structure):
+    _fields_ = [('x', ctypes.c_void_p), ('dy', ctypes.c_void_p), ('dw', ctypes.c_void_p),
+                ('B', ctypes.c_int32), ('H', ctypes.c_int32), ('W', ctypes.c_int32), ('Cin', ctypes.c_int32),
+                ('Cin_real', ctypes.c_int32), ('Cout', ctypes.c_int32), ('Cout_real', ctypes.c_int32),
+                ('KH', ctypes.c_int32), ('KW', ctypes.c_int32), ('stride', ctypes.c_int32), ('pad', ctypes.c_int32),
+                ('Ho', ctypes.c_int32), ('Wo', ctypes.c_int32), ('msplit', ctypes.c_int32)]
 
 
 class NmsCfg(ctypes.Structure):
@@ -82,10 +93,20 @@ def lib():
         L.ym_mask_assemble.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
         L.ym_mask_resize_binarize.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
         L.ym_boxes_to_pixels.argtypes = [vp, vp, i32, f32, vp]
+        L.ym_pack_conv_weight_dgrad.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+        L.ym_conv2d_wgrad_workspace_bytes.argtypes = [ctypes.POINTER(WgradDesc)]
+        L.ym_conv2d_wgrad_workspace_bytes.restype = sz
+        L.ym_conv2d_wgrad.argtypes = [ctypes.POINTER(WgradDesc), vp, sz, vp]
+        L.ym_bn_train_fwd.argtypes = [vp, i64, i32, vp, vp, f32, f32, vp, vp, vp, i32, vp, vp, vp, vp, sz, vp]
+        L.ym_bn_train_bwd.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, sz, vp]
+        L.ym_act_bias_bwd.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp, sz, vp]
+        L.ym_maxpool3x3s2_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
+        L.ym_bilinear2x_bwd.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+        L.ym_sgd_step.argtypes = [vp, vp, vp, i64, f32, f32, f32, i32, vp]
         for name in ABI_SYMBOLS:
             fn = getattr(L, name)
             if name not in ('ym_last_error', 'ym_conv2d_workspace_bytes', 'ym_nms_workspace_bytes',
-                            'ym_greedy_nms_workspace_bytes'):
+                            'ym_greedy_nms_workspace_bytes', 'ym_conv2d_wgrad_workspace_bytes'):
                 fn.restype = ctypes.c_int
         _lib = L
     return _lib

@@ -153,5 +153,12 @@ class Yolact(nn.Module):
                                'there is no CPU fallback (the CPU restatement lives in oracle/ and is '
                                'test infrastructure).')
         if self.training:
-            raise NotImplementedError('training forward (SURVEY.md §8 rows a12-a17) is not built yet')
+            # train branch of the reference forward (:158-161): head logits + semantic-seg conv + compute_loss
+            from ..train_engine import train_features
+            from ..loss import compute_loss
+            if isinstance(self.anchors, list):
+                self.anchors = torch.tensor(self.anchors, device=img.device).reshape(-1, 4)    # like reference :171-172
+            class_p, box_p, coef_p, proto_p, seg_p = train_features(self, img)
+            self.mark_weights_changed()          # the optimizer is about to change them; eval engines must repack
+            return compute_loss(self.cfg, self.anchors, class_p, box_p, coef_p, proto_p, seg_p, box_classes, masks_gt)
         return self._engine(img).forward(img)

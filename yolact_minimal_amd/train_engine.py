@@ -1,0 +1,287 @@
+"""Training forward/backward of YOLACT on MI355X.
+
+Reference: `Yolact.forward` train branch + `compute_loss` (`/root/reference/modules/yolact.py:141-203`) and the
+step in `train.py:116-130` (`loss.backward()` through autograd/ATen/cuDNN, `optimizer.step()`).
+
+Here every convolution (forward, data gradient, weight gradient), every train-mode BatchNorm (batch statistics,
+running-stat update, backward), max-pool / bilinear backward and the SGD update run as hand-written HIP kernels
+behind the C-ABI (`include/yolact_hip.h`); tensors stay NHWC fp32 between them.  `torch.autograd.Function` is
+used only as the tape that orders those kernels and hands parameter gradients to `torch.distributed` (DDP /
+RCCL) — no ATen convolution, batch-norm or pooling kernel is ever called.  The loss bookkeeping on the [B,N,*]
+head outputs (matching, OHEM ranking, cross-entropy, smooth-L1, mask BCE) is `yolact_minimal_amd/loss.py`.
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from . import hip
+from .hip import ConvDesc, WgradDesc, ACT_NONE, ACT_RELU, ACT_TANH
+
+_scratch = {}
+
+
+def scratch(device, nbytes):
+    """Stream-ordered scratch: one buffer per device, grown on demand (kernels on one stream never overlap)."""
+    buf = _scratch.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _scratch[device] = buf
+    return buf
+
+
+def _ru(x, m):
+    return (x + m - 1) // m * m
+
+
+def _pack_fwd(weight, cin_pad, cout_pad):
+    cout, cin, kh, kw = weight.shape
+    k_pad = _ru(kh * kw * cin_pad, 32)
+    if cout_pad == cout:
+        return hip.pack_conv_weight(weight.detach(), cin_pad, k_pad), k_pad
+    wp = torch.zeros(cout_pad, k_pad, device=weight.device, dtype=torch.float32)
+    hip.check(hip.lib().ym_pack_conv_weight(hip.ptr(weight.detach().contiguous()), hip.ptr(wp), cout, cin, kh, kw, cin_pad,
+                                            k_pad, hip.stream_ptr()), 'ym_pack_conv_weight')
+    return wp, k_pad
+
+
+def _conv_forward(x, wp, k_pad, cout_pad, kh, kw, stride, pad, shift, act, residual=None):
+    b, h, w, cin = x.shape
+    ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+    y = torch.empty(b, ho, wo, cout_pad, device=x.device, dtype=torch.float32)
+    d = ConvDesc()
+    d.inp, d.weight = x.data_ptr(), wp.data_ptr()
+    d.shift = shift.data_ptr() if shift is not None else None
+    d.residual = residual.data_ptr() if residual is not None else None
+    d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW = b, h, w, cin, cout_pad, kh, kw
+    d.stride, d.pad, d.Ho, d.Wo, d.k_pad, d.nseg = stride, pad, ho, wo, k_pad, 1
+    d.seg[0].n_begin, d.seg[0].n_end, d.seg[0].out = 0, cout_pad, y.data_ptr()
+    d.seg[0].batch_stride, d.seg[0].pitch, d.seg[0].act = ho * wo * cout_pad, cout_pad, act
+    ws = scratch(x.device, hip.conv_workspace_bytes(d))
+    hip.conv2d_fwd(d, ws)
+    return y
+
+
+def _conv_dgrad(dz, weight, cout_pad, x_shape, stride, pad):
+    """dx [B,H,W,Cin] from dz [B,Ho,Wo,cout_pad] (cout_pad % 32 == 0) and the OIHW weight."""
+    cout, cin, kh, kw = weight.shape
+    b, h, w, cin_x = x_shape
+    assert cin_x == cin and cout_pad % 32 == 0
+    wd = torch.empty(cin, kh * kw * cout_pad, device=dz.device, dtype=torch.float32)
+    hip.check(hip.lib().ym_pack_conv_weight_dgrad(hip.ptr(weight.detach().contiguous()), hip.ptr(wd), cout, cin, kh, kw,
+                                                  cout_pad, hip.stream_ptr()), 'ym_pack_conv_weight_dgrad')
+    dx = torch.empty(b, h, w, cin, device=dz.device, dtype=torch.float32)
+    d = ConvDesc()
+    d.inp, d.weight = dz.data_ptr(), wd.data_ptr()
+    d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW = b, dz.shape[1], dz.shape[2], cout_pad, cin, kh, kw
+    d.stride, d.pad, d.Ho, d.Wo, d.k_pad, d.nseg = stride, pad, h, w, kh * kw * cout_pad, 1
+    d.seg[0].n_begin, d.seg[0].n_end, d.seg[0].out = 0, cin, dx.data_ptr()
+    d.seg[0].batch_stride, d.seg[0].pitch, d.seg[0].act = h * w * cin, cin, ACT_NONE
+    d.transposed = 1
+    ws = scratch(dz.device, hip.conv_workspace_bytes(d))
+    hip.conv2d_fwd(d, ws)
+    return dx
+
+
+def _conv_wgrad(x, dz, weight_shape, stride, pad):
+    cout, cin, kh, kw = weight_shape
+    b, h, w, cin_p = x.shape
+    dw = torch.empty(cout, cin, kh, kw, device=x.device, dtype=torch.float32)
+    d = WgradDesc()
+    d.x, d.dy, d.dw = x.data_ptr(), dz.data_ptr(), dw.data_ptr()
+    d.B, d.H, d.W, d.Cin, d.Cin_real, d.Cout, d.Cout_real = b, h, w, cin_p, cin, dz.shape[3], cout
+    d.KH, d.KW, d.stride, d.pad, d.Ho, d.Wo, d.msplit = kh, kw, stride, pad, dz.shape[1], dz.shape[2], 0
+    nbytes = hip.lib().ym_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
+    if nbytes == 0:
+        raise RuntimeError('ym_conv2d_wgrad_workspace_bytes: ' + hip.lib().ym_last_error().decode())
+    ws = scratch(x.device, nbytes)
+    hip.check(hip.lib().ym_conv2d_wgrad(ctypes.byref(d), ctypes.c_void_p(ws.data_ptr()), ws.numel(), hip.stream_ptr()),
+              'ym_conv2d_wgrad')
+    return dw
+
+
+class ConvBias(torch.autograd.Function):
+    """y = act(conv(x, W) + b) on NHWC; output channels zero-padded to `cout_pad` (multiple of 32 when a data
+    gradient is needed).  Replaces conv+bias+ReLU/tanh of FPN / ProtoNet / head (modules/yolact.py:18-30,37-47,62-68)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, act, cout_pad, residual=None):
+        cout, cin, kh, kw = weight.shape
+        wp, k_pad = _pack_fwd(weight, x.shape[-1], cout_pad)
+        shift = None
+        if bias is not None:
+            shift = bias.detach() if cout_pad == cout else F.pad(bias.detach(), (0, cout_pad - cout))
+            shift = shift.contiguous()
+        y = _conv_forward(x, wp, k_pad, cout_pad, kh, kw, stride, pad, shift, act,
+                          residual.contiguous() if residual is not None else None)
+        ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
+        ctx.meta = (stride, pad, act, cout_pad, bias is not None, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        stride, pad, act, cout_pad, has_bias, has_res = ctx.meta
+        dy = dy.contiguous()
+        m, c = dy.numel() // cout_pad, cout_pad
+        dz = torch.empty_like(dy) if act != ACT_NONE else dy
+        dbias = torch.empty(c, device=dy.device, dtype=torch.float32) if has_bias else None
+        ws = scratch(dy.device, c * 16)
+        hip.check(hip.lib().ym_act_bias_bwd(hip.ptr(dy), hip.ptr(y) if y is not None else None, m, c, act,
+                                            hip.ptr(dz) if act != ACT_NONE else None, hip.ptr(dbias), ctypes.c_void_p(ws.data_ptr()),
+                                            ws.numel(), hip.stream_ptr()), 'ym_act_bias_bwd')
+        dx = _conv_dgrad(dz, weight, cout_pad, x.shape, stride, pad) if ctx.needs_input_grad[0] else None
+        dw = _conv_wgrad(x, dz, weight.shape, stride, pad)
+        if dbias is not None and cout_pad != weight.shape[0]:
+            dbias = dbias[:weight.shape[0]].contiguous()
+        return dx, dw, dbias, None, None, None, None, (dz if has_res else None)
+
+
+class ConvBn(torch.autograd.Function):
+    """out = relu?(BN_train(conv(x, W)) + residual?) — one Bottleneck stage (modules/resnet.py:23-38) in train mode."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, residual, stride, pad, relu, momentum, eps):
+        cout, cin, kh, kw = weight.shape
+        wp, k_pad = _pack_fwd(weight, x.shape[-1], cout)
+        y = _conv_forward(x, wp, k_pad, cout, kh, kw, stride, pad, None, ACT_NONE)
+        m = y.numel() // cout
+        out = torch.empty_like(y)
+        mean = torch.empty(cout, device=x.device, dtype=torch.float32)
+        invstd = torch.empty_like(mean)
+        ws = scratch(x.device, cout * 16)
+        hip.check(hip.lib().ym_bn_train_fwd(hip.ptr(y), m, cout, hip.ptr(gamma.detach()), hip.ptr(beta.detach()), eps, momentum,
+                                            hip.ptr(running_mean), hip.ptr(running_var),
+                                            hip.ptr(residual.contiguous()) if residual is not None else None, int(relu),
+                                            hip.ptr(out), hip.ptr(mean), hip.ptr(invstd), ctypes.c_void_p(ws.data_ptr()),
+                                            ws.numel(), hip.stream_ptr()), 'ym_bn_train_fwd')
+        ctx.save_for_backward(x, weight, gamma, y, out if relu else None, mean, invstd)
+        ctx.meta = (stride, pad, relu, residual is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight, gamma, y, out, mean, invstd = ctx.saved_tensors
+        stride, pad, relu, has_res = ctx.meta
+        dout = dout.contiguous()
+        cout = weight.shape[0]
+        m = y.numel() // cout
+        dy = torch.empty_like(y)
+        dres = torch.empty_like(y) if has_res else None
+        dgamma = torch.empty(cout, device=y.device, dtype=torch.float32)
+        dbeta = torch.empty_like(dgamma)
+        ws = scratch(y.device, cout * 16)
+        hip.check(hip.lib().ym_bn_train_bwd(hip.ptr(dout), hip.ptr(out) if relu else None, hip.ptr(y), m, cout,
+                                            hip.ptr(gamma.detach()), hip.ptr(mean), hip.ptr(invstd), int(relu), hip.ptr(dy),
+                                            hip.ptr(dres) if has_res else None, hip.ptr(dgamma), hip.ptr(dbeta),
+                                            ctypes.c_void_p(ws.data_ptr()), ws.numel(), hip.stream_ptr()), 'ym_bn_train_bwd')
+        need_dx = ctx.needs_input_grad[0]
+        if need_dx and cout % 32 != 0:
+            raise RuntimeError('ConvBn dgrad needs Cout % 32 == 0')
+        dx = _conv_dgrad(dy, weight, cout, x.shape, stride, pad) if need_dx else None
+        dw = _conv_wgrad(x, dy, weight.shape, stride, pad)
+        return dx, dw, dgamma, dbeta, None, None, dres, None, None, None, None, None
+
+
+class MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        b, h, w, c = x.shape
+        out = torch.empty(b, (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1, c, device=x.device, dtype=torch.float32)
+        hip.maxpool3x3s2(x, out)
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        b, h, w, c = x.shape
+        dx = torch.empty_like(x)
+        hip.check(hip.lib().ym_maxpool3x3s2_bwd(hip.ptr(x), hip.ptr(dy.contiguous()), hip.ptr(dx), b, h, w, c, hip.stream_ptr()),
+                  'ym_maxpool3x3s2_bwd')
+        return dx
+
+
+class Bilinear2x(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, align):
+        b, h, w, c = x.shape
+        out = torch.empty(b, 2 * h, 2 * w, c, device=x.device, dtype=torch.float32)
+        hip.bilinear2x(x, out, align)
+        ctx.meta = (x.shape, align)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (b, h, w, c), align = ctx.meta
+        dx = torch.empty(b, h, w, c, device=dy.device, dtype=torch.float32)
+        hip.check(hip.lib().ym_bilinear2x_bwd(hip.ptr(dy.contiguous()), hip.ptr(dx), b, h, w, c, int(align), hip.stream_ptr()),
+                  'ym_bilinear2x_bwd')
+        return dx, None
+
+
+def _conv_bn(x, conv, bn, relu=True, residual=None):
+    out = ConvBn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, conv.stride[0],
+                       conv.padding[0], relu, float(bn.momentum), float(bn.eps))
+    bn.num_batches_tracked += 1
+    return out
+
+
+def _conv_bias(x, conv, act=ACT_NONE, cout_pad=None, residual=None):
+    cout = conv.out_channels
+    return ConvBias.apply(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], act, cout_pad or cout, residual)
+
+
+def train_features(net, img):
+    """Train-mode network forward (HIP kernels), returns (class logits [B,N,C], box [B,N,4], coef [B,N,32] (tanh),
+    proto [B,Hp,Wp,32], seg logits [B,C-1,H3,W3]) with an autograd tape attached."""
+    b, _, h, w = img.shape
+    x = torch.empty(b, h, w, 4, device=img.device, dtype=torch.float32)
+    hip.nchw_to_nhwc4(img.contiguous().float(), x)
+    bb = net.backbone
+    x = _conv_bn(x, bb.conv1, bb.bn1)
+    x = MaxPool.apply(x)
+    outs = []
+    for stage in bb.layers:
+        for blk in stage:
+            y = _conv_bn(x, blk.conv1, blk.bn1)
+            y = _conv_bn(y, blk.conv2, blk.bn2)
+            skip = _conv_bn(x, blk.downsample[0], blk.downsample[1], relu=False) if blk.downsample is not None else x
+            x = _conv_bn(y, blk.conv3, blk.bn3, relu=True, residual=skip)
+        outs.append(x)
+    c3, c4, c5 = outs[1:4]
+    fpn = net.fpn
+    p5_1 = _conv_bias(c5, fpn.lat_layers[2])
+    p4_1 = _conv_bias(c4, fpn.lat_layers[1], residual=Bilinear2x.apply(p5_1, False))     # top-down add fused
+    p3_1 = _conv_bias(c3, fpn.lat_layers[0], residual=Bilinear2x.apply(p4_1, False))
+    p5 = _conv_bias(p5_1, fpn.pred_layers[2][0], ACT_RELU)
+    p4 = _conv_bias(p4_1, fpn.pred_layers[1][0], ACT_RELU)
+    p3 = _conv_bias(p3_1, fpn.pred_layers[0][0], ACT_RELU)
+    p6 = _conv_bias(p5, fpn.downsample_layers[0][0], ACT_RELU)
+    p7 = _conv_bias(p6, fpn.downsample_layers[1][0], ACT_RELU)
+    levels = [p3, p4, p5, p6, p7]
+
+    pn = net.proto_net
+    y = p3
+    for i in (0, 2, 4):
+        y = _conv_bias(y, pn.proto1[i], ACT_RELU)
+    y = Bilinear2x.apply(y, True)
+    y = _conv_bias(y, pn.proto2[0], ACT_RELU)
+    proto = _conv_bias(y, pn.proto2[2], ACT_RELU)                 # NHWC [B,Hp,Wp,32] == proto_out layout
+
+    hd = net.prediction_layers
+    nc, cd, na = net.cfg.num_classes, net.coef_dim, len(net.cfg.aspect_ratios)
+    c_conf, c_box, c_coef = na * nc, na * 4, na * cd
+    w_head = torch.cat([hd.conf_layer.weight, hd.bbox_layer.weight, hd.coef_layer[0].weight], 0)
+    b_head = torch.cat([hd.conf_layer.bias, hd.bbox_layer.bias, hd.coef_layer[0].bias], 0)
+    head_pad = _ru(c_conf + c_box + c_coef, 32)
+    confs, boxes, coefs = [], [], []
+    for lv in levels:
+        xh = _conv_bias(lv, hd.upfeature[0], ACT_RELU)
+        o = ConvBias.apply(xh, w_head, b_head, 1, 1, ACT_NONE, head_pad, None)    # [B,H,W,352]
+        bsz = o.shape[0]
+        confs.append(o[..., :c_conf].reshape(bsz, -1, nc))
+        boxes.append(o[..., c_conf:c_conf + c_box].reshape(bsz, -1, 4))
+        coefs.append(torch.tanh(o[..., c_conf + c_box:c_conf + c_box + c_coef]).reshape(bsz, -1, cd))
+    seg = _conv_bias(p3, net.semantic_seg_conv, ACT_NONE, _ru(nc - 1, 32))[..., :nc - 1].permute(0, 3, 1, 2)
+    return torch.cat(confs, 1), torch.cat(boxes, 1), torch.cat(coefs, 1), proto, seg
