@@ -42,6 +42,11 @@ def parse():
     ap.add_argument('--no-post', action='store_true', help='time the network forward only')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the bs=8 side measurements')
+    ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
+                    help="what `value` reports; the other mode's numbers still appear under extra")
+    ap.add_argument('--train-batch', type=int, default=8, help='images per GPU per training step')
+    ap.add_argument('--train-steps', type=int, default=6)
+    ap.add_argument('--no-train', action='store_true', help='skip the DDP training measurement')
     ap.add_argument('--local_rank', type=int, default=None)
     return ap.parse_args()
 
@@ -132,6 +137,42 @@ def conv_roofline(engine, img, iters=5):
     return flops, secs, len(convs), layers
 
 
+def train_bench(cfg_name, img_size, batch, steps, warmup, world, local_rank, device, barrier):
+    """DDP training: one step = forward + loss + backward (+ RCCL gradient all-reduce overlapped by DDP hooks) +
+    SGD step on `batch` synthetic images per GPU (targets: 4 boxes + rectangular masks per image)."""
+    from oracle.yolact_ref import synth_targets          # input generator only
+    from yolact_minimal_amd.config import build_cfg
+    from yolact_minimal_amd.modules.yolact import Yolact
+    from yolact_minimal_amd.trainer import Trainer, reduce_max
+    cfg = build_cfg(cfg_name, 'train', img_size, train_bs=batch * world, bs_per_gpu=batch)
+    torch.manual_seed(0)
+    net = Yolact(cfg)
+    tr = Trainer(net, cfg, device, world, local_rank)
+    rank = int(os.environ.get('RANK', '0'))
+    g = torch.Generator().manual_seed(100 + rank)
+    img = torch.randn(batch, 3, img_size, img_size, generator=g).to(device)
+    boxes, masks = synth_targets(batch, img_size, seed=1000 * rank)
+    boxes, masks = [b.to(device) for b in boxes], [m.to(device) for m in masks]
+    losses = None
+    for _ in range(warmup):
+        losses = tr.step(img, boxes, masks)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses = tr.step(img, boxes, masks)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = reduce_max(time.perf_counter() - t0, device)
+    flops_img = 3.0 * (157.2e9 if cfg_name.startswith('res101') else 113.4e9)
+    img_s = batch * world * steps / elapsed
+    return dict(img_s=round(img_s, 2), ms_per_step=round(elapsed / steps * 1e3, 2), steps=steps, warmup=warmup,
+                batch_per_gpu=batch, global_batch=batch * world, parallelism=f'ddp{world} (RCCL all-reduce, 25 MB buckets)',
+                tflops_per_gpu=round(img_s / world * flops_img / 1e12, 2),
+                frac_f32_mfma_peak=round(img_s / world * flops_img / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                last_losses=[round(float(l.detach()), 4) for l in losses], finite=all(bool(torch.isfinite(l)) for l in losses))
+
+
 def cpu_baseline(cfg_name, img_size):
     """The CPU oracle (plain PyTorch-CPU restatement of the reference) timed on this host's cores, bounded sample."""
     from oracle import yolact_ref as R
@@ -188,6 +229,12 @@ def main():
         elapsed = float(t.item())
     imgs = args.batch * args.steps * world
     value = imgs / elapsed
+    del wl
+    train = None
+    if not args.no_train:
+        net._engines.clear()
+        torch.cuda.empty_cache()
+        train = train_bench(args.cfg, args.img_size, args.train_batch, args.train_steps, 2, world, local_rank, device, barrier)
 
     out = None
     if rank == 0:
@@ -221,10 +268,15 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.cfg, args.img_size)
+        extra['train'] = train
+        primary_train = args.mode == 'train' and train is not None
         out = {
-            'metric': f'img/s {args.cfg} 544x544 inference (bs={args.batch}/GPU)',
-            'value': round(value, 2), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'metric': (f'img/s {args.cfg} 544x544 DDP training (bs={args.train_batch}/GPU)' if primary_train else
+                       f'img/s {args.cfg} 544x544 inference (bs={args.batch}/GPU)'),
+            'value': train['img_s'] if primary_train else round(value, 2), 'unit': 'img/s', 'n_gpus': world,
+            'steps': train['steps'] if primary_train else args.steps, 'warmup': train['warmup'] if primary_train else args.warmup,
+            'ms_per_step': train['ms_per_step'] if primary_train else round(elapsed / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'{args.cfg} 544x544 (the reference\'s "550-class" size) bs={args.batch} inference: '
                                    f'forward + nms + after_nms(480x640) per image' if not args.no_post else

@@ -1,0 +1,79 @@
+"""world_size-2 gloo tests (CPU) of the multi-process host logic: batch sharding, max-over-ranks timing, the loss
+all-reduce, and the DDP identity the trainer relies on (mean of per-shard gradients == single-process gradient of
+the per-shard-normalised losses' mean) checked with the CPU oracle's autograd."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from yolact_minimal_amd import trainer
+    r, w, lr = trainer.init_distributed(backend='gloo')
+    assert (r, w) == (rank, world) and dist.get_backend() == 'gloo'
+    # sharding: disjoint, complete
+    mine = list(trainer.shard_batch(8, rank, world))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    assert sorted(sum(gathered, [])) == list(range(8))
+    # timing: MAX over ranks
+    assert trainer.reduce_max(1.0 + rank) == float(world)
+    # loss logging all-reduce (SUM, like train.py:122)
+    t = torch.tensor([1.0, 2.0, 3.0, 4.0]) * (rank + 1)
+    dist.all_reduce(t)
+    assert torch.equal(t, torch.tensor([1.0, 2.0, 3.0, 4.0]) * sum(range(1, world + 1)))
+    # DDP identity on a tiny conv net: averaged per-shard grads == grad of mean of per-shard losses
+    torch.manual_seed(0)
+    w_ = torch.randn(4, 3, 3, 3, requires_grad=True)
+    x = torch.randn(8, 3, 9, 9)
+    y = torch.nn.functional.conv2d(x[mine], w_, padding=1).pow(2).mean()
+    y.backward()
+    g = w_.grad.clone()
+    dist.all_reduce(g)
+    g /= world
+    w2 = w_.detach().clone().requires_grad_()
+    full = sum(torch.nn.functional.conv2d(x[list(trainer.shard_batch(8, k, world))], w2, padding=1).pow(2).mean()
+               for k in range(world)) / world
+    full.backward()
+    torch.testing.assert_close(g, w2.grad, rtol=1e-5, atol=1e-6)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, 'ok'))
+
+
+def test_two_rank_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(q.get(timeout=5)[0] for _ in range(2)) == [0, 1]
+
+
+def test_lr_schedule_matches_reference_formula():
+    from yolact_minimal_amd.config import build_cfg
+    from yolact_minimal_amd.trainer import lr_at
+    cfg = build_cfg('res101_coco', 'train', 544, train_bs=16, bs_per_gpu=8)
+    assert cfg.lr == pytest.approx(0.002) and cfg.lr_steps[1] == 140000
+    assert lr_at(cfg, 0) == pytest.approx(cfg.warmup_init)
+    assert lr_at(cfg, 250) == pytest.approx((cfg.lr - cfg.warmup_init) * 0.5 + cfg.warmup_init)
+    assert lr_at(cfg, 501) == pytest.approx(cfg.lr)
+    assert lr_at(cfg, 140000) == pytest.approx(cfg.lr * 0.1)
+    assert lr_at(cfg, 280001) == pytest.approx(cfg.lr * 0.01)
