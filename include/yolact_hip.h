@@ -82,6 +82,9 @@ typedef struct {
                                 `weight` comes from ym_pack_conv_weight_dgrad.  Autograd counterpart of every
                                 nn.Conv2d on the path (loss_total.backward(), reference train.py:126). */
     int32_t reserved;
+    double* bn_sum;          /* optional [Cout] fp64 accumulators (zeroed by the caller): the epilogue adds the */
+    double* bn_sumsq;        /* per-channel sum / sum of squares of the conv OUTPUT (train-mode BN statistics).  */
+                             /* Only when ym_conv2d_fuses_bn_stats(desc) == 1 (plain NHWC output, no K split).   */
 } ym_conv_desc;
 
 /* y = act(conv(x, w) * scale + shift + residual), one launch (plus a reduce launch if K is split).
@@ -90,6 +93,7 @@ typedef struct {
  * with three segments, the bbox/conf/coef convs + tanh + permute/reshape/cat of
  * PredictionModule.forward + Yolact.forward (modules/yolact.py:27-30,155-157). */
 size_t ym_conv2d_workspace_bytes(const ym_conv_desc* d);
+int ym_conv2d_fuses_bn_stats(const ym_conv_desc* d);
 int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t workspace_bytes, ym_stream_t s);
 
 /* ---- training: weight gradient, batch-norm with batch statistics, small backward ops, SGD -------------------
@@ -117,6 +121,11 @@ int ym_conv2d_wgrad(const ym_wgrad_desc* d, void* workspace, size_t workspace_by
 int ym_bn_train_fwd(const float* y, int64_t M, int C, const float* gamma, const float* beta, float eps, float momentum,
                     float* running_mean, float* running_var, const float* residual, int relu, float* out,
                     float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes, ym_stream_t s);
+/* Same, but the first 16*C bytes of `workspace` already hold the fp64 sum[C] | sumsq[C] of y (accumulated by
+ * ym_conv2d_fwd through ym_conv_desc.bn_sum / bn_sumsq): skips the statistics pass over y. */
+int ym_bn_train_fwd_stats(const float* y, int64_t M, int C, const float* gamma, const float* beta, float eps,
+                          float momentum, float* running_mean, float* running_var, const float* residual, int relu,
+                          float* out, float* save_mean, float* save_invstd, const void* stats, ym_stream_t s);
 
 /* Backward of the above: dz = dout * (out > 0 if relu); dres (optional) = dz; dgamma/dbeta [C];
  * dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)).  workspace >= 16*C bytes. */

@@ -19,6 +19,8 @@ struct ConvP {
     const float* shift;
     const float* residual;
     float* ws;  // split-K partials [ksplit][M][Cout] (only when ksplit > 1)
+    double* bn_sum;    // optional fused per-channel sum / sum of squares of the OUTPUT (train-mode BatchNorm)
+    double* bn_sumsq;
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, Kpad;
     int M, HoWo, nkt, ksplit, kt_per_split, tiles_m, tiles_n;
     int nseg;

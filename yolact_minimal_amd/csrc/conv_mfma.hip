@@ -231,6 +231,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
         __syncthreads();
         const int col4 = tid % C4, row0 = tid / C4;
         const int n = n0 + col4 * 4;
+        double bsum[4] = {0.0, 0.0, 0.0, 0.0}, bsq[4] = {0.0, 0.0, 0.0, 0.0};   // fp64: var = E[x^2]-E[x]^2 must not cancel in fp32
         if (n < p.Cout) {
             if (p.ksplit > 1) {
                 float* wsb = p.ws + (size_t)ks * p.M * p.Cout + n;
@@ -257,8 +258,31 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = ym_apply_act(v[e], act);
                         *reinterpret_cast<f32x4*>(outb + (size_t)m * p.Cout) = v;
+                        if (p.bn_sum) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { const double dv = v[e]; bsum[e] += dv; bsq[e] += dv * dv; }
+                        }
                     }
                 }
+            }
+        }
+        if (p.bn_sum && p.ksplit == 1) {
+            // train-mode BatchNorm statistics of THIS conv output, fused: per-workgroup column sums of the tile
+            // (fp64), then one fp64 atomic per channel per workgroup.
+            __syncthreads();                       // every lane is done reading the staged tile
+            double* R = reinterpret_cast<double*>(smem);   // [RPP][BN][2] doubles (<= 16 KB)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                R[((row0 * BN) + col4 * 4 + e) * 2 + 0] = bsum[e];
+                R[((row0 * BN) + col4 * 4 + e) * 2 + 1] = bsq[e];
+            }
+            __syncthreads();
+            if (tid < BN && n0 + tid < p.Cout) {
+                double S = 0.0, Q = 0.0;
+#pragma unroll
+                for (int r = 0; r < RPP; ++r) { S += R[(r * BN + tid) * 2]; Q += R[(r * BN + tid) * 2 + 1]; }
+                atomicAdd(p.bn_sum + n0 + tid, S);
+                atomicAdd(p.bn_sumsq + n0 + tid, Q);
             }
         }
         return;
@@ -424,6 +448,15 @@ extern "C" size_t ym_conv2d_workspace_bytes(const ym_conv_desc* d) {
     return pl.ksplit > 1 ? (size_t)pl.ksplit * pl.M * d->Cout * sizeof(float) : 0;
 }
 
+extern "C" int ym_conv2d_fuses_bn_stats(const ym_conv_desc* d) {
+    Plan pl;
+    if (make_plan(d, &pl) != YM_OK) return 0;
+    const ym_conv_seg& g = d->seg[0];
+    const bool plain = d->nseg == 1 && g.n_begin == 0 && g.n_end == d->Cout && g.pitch == d->Cout &&
+                       g.batch_stride == (int64_t)d->Ho * d->Wo * d->Cout && d->Cout % 4 == 0;
+    return (plain && pl.ksplit == 1 && d->kwaves == 0) ? 1 : 0;
+}
+
 extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t workspace_bytes, ym_stream_t s) {
     Plan pl;
     int rc = make_plan(d, &pl);
@@ -454,6 +487,11 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
                                (uintptr_t)workspace) & 15) == 0;
         p.vec = (d->nseg == 1 && g.n_begin == 0 && g.n_end == d->Cout && g.pitch == d->Cout &&
                  g.batch_stride == (int64_t)d->Ho * d->Wo * d->Cout && d->Cout % 4 == 0 && aligned) ? 1 : 0;
+    }
+    p.bn_sum = d->bn_sum; p.bn_sumsq = d->bn_sumsq;
+    if (d->bn_sum) {
+        YM_REQUIRE(d->bn_sumsq && p.vec && pl.ksplit == 1 && d->kwaves == 0,
+                   "conv: bn_sum given but this configuration cannot fuse the statistics (ask ym_conv2d_fuses_bn_stats)");
     }
     hipStream_t st = (hipStream_t)s;
     if (d->kwaves > 0) return ym_launch_conv_wave(p, pl.bm, pl.bn, d->kwaves, st);

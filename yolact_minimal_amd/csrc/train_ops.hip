@@ -41,7 +41,40 @@ __global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ a,
         if (rl < RL && cq < C4) {
             f32x4 mu = {0, 0, 0, 0}, is = {1, 1, 1, 1};
             if (MODE == 1) { mu = *reinterpret_cast<const f32x4*>(mean + cq * 4); is = *reinterpret_cast<const f32x4*>(invstd + cq * 4); }
-            for (long long m = (long long)blockIdx.x * RL + rl; m < M; m += (long long)gridDim.x * RL) {
+            const long long stride = (long long)gridDim.x * RL;
+            long long m = (long long)blockIdx.x * RL + rl;
+            if (MODE == 0) {
+                // 4 independent rows in flight per lane
+                for (; m + 3 * stride < M; m += 4 * stride) {
+                    f32x4 x[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const f32x4*>(a + (size_t)(m + u * stride) * C + cq * 4);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const double v = x[u][e]; s0[e] += v; s1[e] += v * v; }
+                }
+            } else if (MODE == 1) {
+                for (; m + 1 * stride < M; m += 2 * stride) {
+                    f32x4 d[2], o[2], y[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const size_t off = (size_t)(m + u * stride) * C + cq * 4;
+                        d[u] = *reinterpret_cast<const f32x4*>(a + off);
+                        y[u] = *reinterpret_cast<const f32x4*>(c + off);
+                        o[u] = relu ? *reinterpret_cast<const f32x4*>(b + off) : f32x4{1.f, 1.f, 1.f, 1.f};
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const double dd = o[u][e] > 0.f ? d[u][e] : 0.f;
+                            s0[e] += dd;
+                            s1[e] += dd * (double)((y[u][e] - mu[e]) * is[e]);
+                        }
+                }
+            }
+            for (; m < M; m += stride) {
                 const size_t off = (size_t)m * C + cq * 4;
                 const f32x4 x = *reinterpret_cast<const f32x4*>(a + off);
                 if (MODE == 0) {
@@ -314,7 +347,7 @@ extern "C" int ym_bn_train_fwd(const float* y, int64_t M, int C, const float* ga
     double* sumsq = sum + C;
     (void)hipMemsetAsync(sum, 0, (size_t)C * 16, st);
     const int CQ = (C / 4) < 256 ? (C / 4) : 256, RL = 256 / CQ;
-    int grid = (int)((M + (long long)RL * 32 - 1) / ((long long)RL * 32));
+    int grid = (int)((M + (long long)RL * 16 - 1) / ((long long)RL * 16));
     if (grid > 2048) grid = 2048;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(k_col_reduce<0>, dim3(grid), dim3(256), 0, st, y, nullptr, nullptr, nullptr, nullptr, (long long)M, C, 0,
@@ -324,6 +357,21 @@ extern "C" int ym_bn_train_fwd(const float* y, int64_t M, int C, const float* ga
     hipLaunchKernelGGL(k_bn_apply, dim3(ew_grid((size_t)M * (C / 4))), dim3(256), 0, st, y, save_mean, save_invstd, gamma, beta,
                        residual, relu, out, (long long)M, C);
     return ym_check_launch("bn_train_fwd");
+}
+
+extern "C" int ym_bn_train_fwd_stats(const float* y, int64_t M, int C, const float* gamma, const float* beta, float eps,
+                                     float momentum, float* running_mean, float* running_var, const float* residual,
+                                     int relu, float* out, float* save_mean, float* save_invstd, const void* stats,
+                                     ym_stream_t s) {
+    YM_REQUIRE(y && gamma && beta && out && save_mean && save_invstd && stats, "bn_train_fwd_stats: null pointer");
+    YM_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_train_fwd_stats: C %% 4 != 0");
+    hipStream_t st = (hipStream_t)s;
+    const double* sum = (const double*)stats;
+    hipLaunchKernelGGL(k_bn_finalize, dim3(ym_cdiv(C, 256)), dim3(256), 0, st, sum, sum + C, (long long)M, eps, momentum,
+                       save_mean, save_invstd, running_mean, running_var, C);
+    hipLaunchKernelGGL(k_bn_apply, dim3(ew_grid((size_t)M * (C / 4))), dim3(256), 0, st, y, save_mean, save_invstd, gamma, beta,
+                       residual, relu, out, (long long)M, C);
+    return ym_check_launch("bn_train_fwd_stats");
 }
 
 extern "C" int ym_bn_train_bwd(const float* dout, const float* out, const float* y, int64_t M, int C, const float* gamma,
@@ -338,7 +386,7 @@ extern "C" int ym_bn_train_bwd(const float* dout, const float* out, const float*
     double* dg = db + C;
     (void)hipMemsetAsync(db, 0, (size_t)C * 16, st);
     const int CQ = (C / 4) < 256 ? (C / 4) : 256, RL = 256 / CQ;
-    int grid = (int)((M + (long long)RL * 32 - 1) / ((long long)RL * 32));
+    int grid = (int)((M + (long long)RL * 16 - 1) / ((long long)RL * 16));
     if (grid > 2048) grid = 2048;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(k_col_reduce<1>, dim3(grid), dim3(256), 0, st, dout, out, y, save_mean, save_invstd, (long long)M, C,

@@ -11,6 +11,7 @@ RCCL) — no ATen convolution, batch-norm or pooling kernel is ever called.  The
 head outputs (matching, OHEM ranking, cross-entropy, smooth-L1, mask BCE) is `yolact_minimal_amd/loss.py`.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn.functional as F
@@ -19,6 +20,88 @@ from . import hip
 from .hip import ConvDesc, WgradDesc, ACT_NONE, ACT_RELU, ACT_TANH
 
 _scratch = {}
+
+# ---- per-shape kernel configuration (measured on MI355X; same JSON as the inference engine) ---------------------
+_TUNING = os.environ.get('YM_TUNE_TRAIN', '0') == '1'     # sweep unseen shapes inline and remember the winner
+_new_entries = {}
+
+
+def _table():
+    from .engine import tuned_table
+    return tuned_table()
+
+
+def _time_launch(fn, iters=5):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn(); fn()
+    best = 1e30
+    for _ in range(2):
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / iters)
+    return best
+
+
+def _configure_conv(d, key):
+    """Set tile/ksplit/kwaves of a ConvDesc from the tuned table (or sweep it when YM_TUNE_TRAIN=1)."""
+    hit = _table().get(key)
+    if hit is None and _TUNING:
+        M, nkt = d.B * d.Ho * d.Wo, d.k_pad // 32
+        big = scratch(torch.device('cuda', torch.cuda.current_device()), 1 << 28)
+        cands = [((0, 0), 0, 0)]
+        for tm, tn in ((128, 128), (128, 64), (64, 128), (64, 64)):
+            wgs = -(-M // tm) * -(-d.Cout // tn)
+            for ks in (1, 2, 3, 4, 6, 8, 12, 16):
+                if ks > 1 and (wgs >= 1024 or ks * 2 > nkt or wgs * ks > 8192):
+                    continue
+                cands.append(((tm, tn), ks, 0))
+        best = (1e30, (0, 0), 0, 0)
+        for tile, ks, kwv in cands:
+            d.tile_m, d.tile_n, d.ksplit, d.kwaves = tile[0], tile[1], ks, kwv
+            if hip.conv_workspace_bytes(d) > big.numel():
+                continue
+            try:
+                t = _time_launch(lambda: hip.conv2d_fwd(d, big))
+            except RuntimeError:
+                continue
+            if t < best[0] * 0.98:
+                best = (t, tile, ks, kwv)
+        hit = [best[1][0], best[1][1], best[2], best[3]]
+        _table()[key] = hit
+        _new_entries[key] = hit
+    if hit is not None:
+        d.tile_m, d.tile_n, d.ksplit = hit[0], hit[1], hit[2]
+        d.kwaves = hit[3] if len(hit) > 3 else 0
+
+
+def _configure_wgrad(d, key):
+    hit = _table().get(key)
+    if hit is None and _TUNING:
+        big = scratch(torch.device('cuda', torch.cuda.current_device()), 1 << 28)
+        best = (1e30, 0)
+        for ms in (0, 1, 2, 4, 8, 16, 32, 64, 128, 256):
+            d.msplit = ms
+            need = hip.lib().ym_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
+            if need == 0 or need > big.numel():
+                continue
+            t = _time_launch(lambda: hip.check(hip.lib().ym_conv2d_wgrad(ctypes.byref(d), ctypes.c_void_p(big.data_ptr()),
+                                                                        big.numel(), hip.stream_ptr()), 'wgrad'))
+            if t < best[0] * 0.98:
+                best = (t, ms)
+        hit = [best[1]]
+        _table()[key] = hit
+        _new_entries[key] = hit
+    if hit is not None:
+        d.msplit = hit[0]
+
+
+def dump_new_entries(path):
+    import json
+    with open(path, 'w') as f:
+        json.dump(_new_entries, f, indent=0, sort_keys=True)
 
 
 def scratch(device, nbytes):
@@ -45,7 +128,7 @@ def _pack_fwd(weight, cin_pad, cout_pad):
     return wp, k_pad
 
 
-def _conv_forward(x, wp, k_pad, cout_pad, kh, kw, stride, pad, shift, act, residual=None):
+def _conv_forward(x, wp, k_pad, cout_pad, kh, kw, stride, pad, shift, act, residual=None, bn_stats=None):
     b, h, w, cin = x.shape
     ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
     y = torch.empty(b, ho, wo, cout_pad, device=x.device, dtype=torch.float32)
@@ -57,8 +140,17 @@ def _conv_forward(x, wp, k_pad, cout_pad, kh, kw, stride, pad, shift, act, resid
     d.stride, d.pad, d.Ho, d.Wo, d.k_pad, d.nseg = stride, pad, ho, wo, k_pad, 1
     d.seg[0].n_begin, d.seg[0].n_end, d.seg[0].out = 0, cout_pad, y.data_ptr()
     d.seg[0].batch_stride, d.seg[0].pitch, d.seg[0].act = ho * wo * cout_pad, cout_pad, act
+    if cin != 4:
+        _configure_conv(d, f'M{b * ho * wo}_N{cout_pad}_C{cin}_k{kh}_s{stride}_seg1_r{int(residual is not None)}')
+    fused = False
+    if bn_stats is not None and hip.lib().ym_conv2d_fuses_bn_stats(ctypes.byref(d)) == 1:
+        bn_stats.zero_()
+        d.bn_sum, d.bn_sumsq = bn_stats.data_ptr(), bn_stats.data_ptr() + cout_pad * 8
+        fused = True
     ws = scratch(x.device, hip.conv_workspace_bytes(d))
     hip.conv2d_fwd(d, ws)
+    if bn_stats is not None:
+        return y, fused
     return y
 
 
@@ -78,6 +170,7 @@ def _conv_dgrad(dz, weight, cout_pad, x_shape, stride, pad):
     d.seg[0].n_begin, d.seg[0].n_end, d.seg[0].out = 0, cin, dx.data_ptr()
     d.seg[0].batch_stride, d.seg[0].pitch, d.seg[0].act = h * w * cin, cin, ACT_NONE
     d.transposed = 1
+    _configure_conv(d, f'T_M{b * h * w}_N{cin}_C{cout_pad}_k{kh}_s{stride}')
     ws = scratch(dz.device, hip.conv_workspace_bytes(d))
     hip.conv2d_fwd(d, ws)
     return dx
@@ -91,6 +184,7 @@ def _conv_wgrad(x, dz, weight_shape, stride, pad):
     d.x, d.dy, d.dw = x.data_ptr(), dz.data_ptr(), dw.data_ptr()
     d.B, d.H, d.W, d.Cin, d.Cin_real, d.Cout, d.Cout_real = b, h, w, cin_p, cin, dz.shape[3], cout
     d.KH, d.KW, d.stride, d.pad, d.Ho, d.Wo, d.msplit = kh, kw, stride, pad, dz.shape[1], dz.shape[2], 0
+    _configure_wgrad(d, f'W_M{b * dz.shape[1] * dz.shape[2]}_N{dz.shape[3]}_C{cin_p}_k{kh}_s{stride}')
     nbytes = hip.lib().ym_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
     if nbytes == 0:
         raise RuntimeError('ym_conv2d_wgrad_workspace_bytes: ' + hip.lib().ym_last_error().decode())
@@ -144,17 +238,23 @@ class ConvBn(torch.autograd.Function):
     def forward(ctx, x, weight, gamma, beta, running_mean, running_var, residual, stride, pad, relu, momentum, eps):
         cout, cin, kh, kw = weight.shape
         wp, k_pad = _pack_fwd(weight, x.shape[-1], cout)
-        y = _conv_forward(x, wp, k_pad, cout, kh, kw, stride, pad, None, ACT_NONE)
+        stats = torch.empty(2 * cout, device=x.device, dtype=torch.float64)
+        y, fused = _conv_forward(x, wp, k_pad, cout, kh, kw, stride, pad, None, ACT_NONE, bn_stats=stats)
         m = y.numel() // cout
         out = torch.empty_like(y)
         mean = torch.empty(cout, device=x.device, dtype=torch.float32)
         invstd = torch.empty_like(mean)
-        ws = scratch(x.device, cout * 16)
-        hip.check(hip.lib().ym_bn_train_fwd(hip.ptr(y), m, cout, hip.ptr(gamma.detach()), hip.ptr(beta.detach()), eps, momentum,
-                                            hip.ptr(running_mean), hip.ptr(running_var),
-                                            hip.ptr(residual.contiguous()) if residual is not None else None, int(relu),
-                                            hip.ptr(out), hip.ptr(mean), hip.ptr(invstd), ctypes.c_void_p(ws.data_ptr()),
-                                            ws.numel(), hip.stream_ptr()), 'ym_bn_train_fwd')
+        res_ptr = hip.ptr(residual.contiguous()) if residual is not None else None
+        if fused:
+            hip.check(hip.lib().ym_bn_train_fwd_stats(hip.ptr(y), m, cout, hip.ptr(gamma.detach()), hip.ptr(beta.detach()), eps,
+                                                      momentum, hip.ptr(running_mean), hip.ptr(running_var), res_ptr, int(relu),
+                                                      hip.ptr(out), hip.ptr(mean), hip.ptr(invstd),
+                                                      ctypes.c_void_p(stats.data_ptr()), hip.stream_ptr()), 'ym_bn_train_fwd_stats')
+        else:
+            hip.check(hip.lib().ym_bn_train_fwd(hip.ptr(y), m, cout, hip.ptr(gamma.detach()), hip.ptr(beta.detach()), eps, momentum,
+                                                hip.ptr(running_mean), hip.ptr(running_var), res_ptr, int(relu),
+                                                hip.ptr(out), hip.ptr(mean), hip.ptr(invstd), ctypes.c_void_p(stats.data_ptr()),
+                                                stats.numel() * 8, hip.stream_ptr()), 'ym_bn_train_fwd')
         ctx.save_for_backward(x, weight, gamma, y, out if relu else None, mean, invstd)
         ctx.meta = (stride, pad, relu, residual is not None)
         return out
