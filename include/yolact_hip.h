@@ -29,6 +29,7 @@ extern "C" {
 #define YM_ACT_NONE 0
 #define YM_ACT_RELU 1
 #define YM_ACT_TANH 2
+#define YM_ACT_GELU 3   /* exact erf GELU (Swin Mlp, modules/swin_transformer.py:88) — forward only */
 
 typedef void* ym_stream_t; /* hipStream_t */
 
@@ -155,6 +156,24 @@ int ym_bilinear2x_fwd(const float* in, float* out, int B, int H, int W, int C, i
 
 /* softmax over the last dim of [rows][C] (F.softmax(class_pred, -1), modules/yolact.py:163). in may equal out. */
 int ym_softmax_rows(const float* in, float* out, int64_t rows, int C, ym_stream_t s);
+
+/* ---- Swin-T blocks (modules/swin_transformer.py); Linear layers are 1x1 ym_conv2d_fwd on [tokens][C] ---------- */
+
+/* nn.LayerNorm over the last dim of [M][C] (C % 4 == 0, C <= 1536); in-place allowed. (:225,228,297,425,:470) */
+int ym_layernorm(const float* x, const float* gamma, const float* beta, float eps, float* out, int64_t M, int C,
+                 ym_stream_t s);
+
+/* PatchMerging gather + norm (:299-323): x NHWC [B][H][W][C] -> out [B*ceil(H/2)*ceil(W/2)][4C] =
+ * LayerNorm(concat(x[2i,2j], x[2i+1,2j], x[2i,2j+1], x[2i+1,2j+1])), zero padded for odd H/W. */
+int ym_patch_merge_layernorm(const float* x, int B, int H, int W, int C, const float* gamma, const float* beta, float eps,
+                             float* out, ym_stream_t s);
+
+/* (Shifted-)window multi-head self-attention, everything between the qkv and proj Linears of one block
+ * (WindowAttention.forward :172-199 + pad/roll/window_partition/window_reverse/un-roll/crop of :249-283):
+ * qkv [B*H*W][3C] (q|k|v, head-major inside each), qkv_bias [3C] (value of padded tokens), rel_bias_table
+ * [(2*window-1)^2][heads]; window must be 7 and C/heads == 32; shift 0 or window/2.  out [B*H*W][C]. */
+int ym_swin_window_attention(const float* qkv, const float* qkv_bias, const float* rel_bias_table, int B, int H, int W, int C,
+                             int heads, int window, int shift, float* out, ym_stream_t s);
 
 /* ---- detection post-processing (utils/output_utils.py) ---------------------------------------------- */
 

@@ -500,3 +500,141 @@ def synth_targets(batch, img_size, n_gt=4, num_classes=80, seed=0):
             m[j, y1:y2, x1:x2] = 1.0
         masks.append(m)
     return boxes, masks
+
+
+# ------------------------------------------------------------------------------------------------
+# Swin-T backbone (modules/swin_transformer.py), eval mode
+# ------------------------------------------------------------------------------------------------
+def _ln(x, sd, name):
+    return F.layer_norm(x, (x.shape[-1],), sd[name + '.weight'], sd[name + '.bias'], 1e-5)
+
+
+def _lin(x, sd, name):
+    return F.linear(x, sd[name + '.weight'], sd.get(name + '.bias'))
+
+
+def swin_windows(x, ws):
+    """window_partition (:99-111): [B,H,W,C] -> [B*nW, ws*ws, C]."""
+    b, h, w, c = x.shape
+    x = x.view(b, h // ws, ws, w // ws, ws, c).permute(0, 1, 3, 2, 4, 5).contiguous()
+    return x.view(-1, ws * ws, c)
+
+
+def swin_unwindows(win, ws, h, w):
+    """window_reverse (:114-128)."""
+    b = win.shape[0] // ((h // ws) * (w // ws))
+    x = win.view(b, h // ws, w // ws, ws, ws, -1).permute(0, 1, 3, 2, 4, 5).contiguous()
+    return x.view(b, h, w, -1)
+
+
+def swin_shift_mask(hp, wp, ws, shift):
+    """BasicLayer.forward :366-383 — region ids -> 0 / -100 additive mask [nW, N, N]."""
+    img = torch.zeros(1, hp, wp, 1)
+    cnt = 0
+    for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+        for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            img[:, hs, wsl, :] = cnt
+            cnt += 1
+    mw = swin_windows(img, ws).view(-1, ws * ws)
+    m = mw.unsqueeze(1) - mw.unsqueeze(2)
+    return m.masked_fill(m != 0, -100.0).masked_fill(m == 0, 0.0)
+
+
+def swin_rel_index(ws):
+    """WindowAttention.__init__ :152-162."""
+    coords = torch.stack(torch.meshgrid([torch.arange(ws), torch.arange(ws)], indexing='ij')).flatten(1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += ws - 1
+    rel[:, :, 1] += ws - 1
+    rel[:, :, 0] *= 2 * ws - 1
+    return rel.sum(-1)
+
+
+def swin_attention(xw, sd, p, heads, ws, mask):
+    """WindowAttention.forward :172-200."""
+    bw, n, c = xw.shape
+    qkv = _lin(xw, sd, p + '.qkv').reshape(bw, n, 3, heads, c // heads).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] * (c // heads) ** -0.5, qkv[1], qkv[2]
+    attn = q @ k.transpose(-2, -1)
+    bias = sd[p + '.relative_position_bias_table'][sd[p + '.relative_position_index'].view(-1)]
+    attn = attn + bias.view(n, n, -1).permute(2, 0, 1).contiguous().unsqueeze(0)
+    if mask is not None:
+        nw = mask.shape[0]
+        attn = (attn.view(bw // nw, nw, heads, n, n) + mask.unsqueeze(1).unsqueeze(0)).view(-1, heads, n, n)
+    attn = F.softmax(attn, -1)
+    return _lin((attn @ v).transpose(1, 2).reshape(bw, n, c), sd, p + '.proj')
+
+
+def swin_block(x, h, w, sd, p, heads, ws, shift, mask):
+    """SwinTransformerBlock.forward :234-289 (eval: DropPath is the identity)."""
+    b, l, c = x.shape
+    short = x
+    y = _ln(x, sd, p + '.norm1').view(b, h, w, c)
+    pr, pb = (ws - w % ws) % ws, (ws - h % ws) % ws
+    y = F.pad(y, (0, 0, 0, pr, 0, pb))
+    hp, wp = y.shape[1:3]
+    if shift > 0:
+        y = torch.roll(y, shifts=(-shift, -shift), dims=(1, 2))
+    a = swin_attention(swin_windows(y, ws), sd, p + '.attn', heads, ws, mask if shift > 0 else None)
+    y = swin_unwindows(a, ws, hp, wp)
+    if shift > 0:
+        y = torch.roll(y, shifts=(shift, shift), dims=(1, 2))
+    y = y[:, :h, :w, :].contiguous().view(b, h * w, c)
+    x = short + y
+    m = _lin(F.gelu(_lin(_ln(x, sd, p + '.norm2'), sd, p + '.mlp.fc1')), sd, p + '.mlp.fc2')
+    return x + m
+
+
+def swin_merge(x, h, w, sd, p):
+    """PatchMerging.forward :299-325."""
+    b, l, c = x.shape
+    x = x.view(b, h, w, c)
+    if h % 2 or w % 2:
+        x = F.pad(x, (0, 0, 0, w % 2, 0, h % 2))
+    x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1)
+    x = x.view(b, -1, 4 * c)
+    return _lin(_ln(x, sd, p + '.norm'), sd, p + '.reduction')
+
+
+def swin_backbone(img, sd, p='backbone', depths=(2, 2, 6, 2), heads=(3, 6, 12, 24), ws=7):
+    """SwinTransformer.forward :500-518 — returns the 4 stage maps NCHW (stages 1-3 layer-normed)."""
+    b, _, hh, ww = img.shape
+    if ww % 4:
+        img = F.pad(img, (0, 4 - ww % 4))
+    if hh % 4:
+        img = F.pad(img, (0, 0, 0, 4 - hh % 4))
+    x = F.conv2d(img, sd[p + '.patch_embed.proj.weight'], sd[p + '.patch_embed.proj.bias'], stride=4)
+    h, w = x.shape[2:]
+    x = _ln(x.flatten(2).transpose(1, 2), sd, p + '.patch_embed.norm')
+    outs = []
+    for li, depth in enumerate(depths):
+        hp, wp = math.ceil(h / ws) * ws, math.ceil(w / ws) * ws
+        mask = swin_shift_mask(hp, wp, ws, ws // 2)
+        for bi in range(depth):
+            x = swin_block(x, h, w, sd, f'{p}.layers.{li}.blocks.{bi}', heads[li], ws, 0 if bi % 2 == 0 else ws // 2, mask)
+        xo = x
+        if li in (1, 2, 3):
+            xo = _ln(xo, sd, f'{p}.norm{li}')
+        outs.append(xo.view(b, h, w, -1).permute(0, 3, 1, 2).contiguous())
+        if li < len(depths) - 1:
+            x = swin_merge(x, h, w, sd, f'{p}.layers.{li}.downsample')
+            h, w = (h + 1) // 2, (w + 1) // 2
+    return outs
+
+
+def features_any(img, sd):
+    """Backbone-agnostic version of `features` (ResNet or Swin-T, chosen from the state-dict keys)."""
+    if 'backbone.patch_embed.proj.weight' in sd:
+        outs = swin_backbone(img, sd)
+    else:
+        outs = resnet(img, sd, resnet_layers_from_sd(sd))
+    levels = fpn(outs[1], outs[2], outs[3], sd)
+    proto = protonet(levels[0], sd).permute(0, 2, 3, 1).contiguous()
+    num_classes = sd['prediction_layers.conf_layer.weight'].shape[0] // 3
+    confs, boxes, coefs = zip(*(head(lv, sd, num_classes) for lv in levels))
+    return torch.cat(confs, 1), torch.cat(boxes, 1), torch.cat(coefs, 1), proto
+
+
+def forward_eval_any(img, sd):
+    conf, box, coef, proto = features_any(img, sd)
+    return F.softmax(conf, -1), box, coef, proto

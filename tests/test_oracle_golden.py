@@ -116,3 +116,32 @@ def test_degenerate_case_hits_nan_path(golden_dir):
     assert int((area == 0).sum()) >= 2
     iou = R.pairwise_iou(boxes[None], boxes[None])
     assert bool(torch.isnan(iou).any())
+
+
+def test_swin_seeded_state_dict_matches_reference(golden_dir):
+    """Same keys / shapes / creation order / initialisers as the reference's swin_tiny_coco Yolact.  erfinv_ (inside
+    trunc_normal_) is vectorised differently per host ISA, so values are compared to 1e-5 instead of bit-exactly."""
+    g = np.load(os.path.join(golden_dir, 'state_swin.npz'))
+    cfg = build_cfg('swin_tiny_coco', 'val', 64)
+    torch.manual_seed(int(g['seed']))
+    sd = Yolact(cfg).state_dict()
+    assert list(sd.keys()) == list(g['keys'])
+    mine = np.stack([_digest(sd[k].float()) for k in sd])
+    np.testing.assert_allclose(mine, g['digest'], rtol=1e-5, atol=1e-9)
+
+
+def test_swin_oracle_forward_matches_golden(golden_dir):
+    from oracle.make_golden_swin import randomize_swin_
+    g = np.load(os.path.join(golden_dir, 'forward_swin_tiny_coco_128_b2.npz'))
+    seed = int(g['seed'])
+    cfg = build_cfg('swin_tiny_coco', 'val', 128)
+    torch.manual_seed(seed)
+    net = Yolact(cfg).eval()
+    sd = net.state_dict()
+    randomize_swin_(sd, seed + 100)
+    R.randomize_bias_(sd, seed + 200)
+    img = torch.randn(2, 3, 128, 128, generator=torch.Generator().manual_seed(seed + 300))
+    with torch.no_grad():
+        out = R.forward_eval_any(img, sd)
+    for t, key in zip(out, ('class_pred', 'box_pred', 'coef_pred', 'proto_out')):
+        np.testing.assert_allclose(t.numpy(), g[key], rtol=5e-4, atol=5e-6, err_msg=key)

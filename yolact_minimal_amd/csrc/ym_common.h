@@ -40,5 +40,6 @@ __device__ __forceinline__ int ym_xcd_remap(int bid, int nwg) {
 __device__ __forceinline__ float ym_apply_act(float v, int act) {
     if (act == YM_ACT_RELU) return v < 0.f ? 0.f : v;   // NaN stays NaN, like torch.relu
     if (act == YM_ACT_TANH) return tanhf(v);
+    if (act == YM_ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
     return v;
 }

@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .hip import ConvDesc, ACT_NONE, ACT_RELU, ACT_TANH
+from .hip import ConvDesc, ACT_NONE, ACT_RELU, ACT_TANH, ACT_GELU
 
 
 def _round_up(x, m):
@@ -43,6 +43,23 @@ def tuned_table():
             with open(TUNED_PATH) as f:
                 _tuned = json.load(f)
     return _tuned
+
+
+class _LinearAsConv:
+    """nn.Linear viewed as a 1x1 convolution of the [tokens][C] (= NHWC) tensor."""
+
+    def __init__(self, lin):
+        self.lin = lin
+        self.in_channels, self.out_channels = lin.in_features, lin.out_features
+        self.kernel_size, self.stride, self.padding = (1, 1), (1, 1), (0, 0)
+
+    @property
+    def weight(self):
+        return self.lin.weight.reshape(self.out_channels, self.in_channels, 1, 1)
+
+    @property
+    def bias(self):
+        return self.lin.bias
 
 
 class _Conv:
@@ -166,11 +183,56 @@ class InferEngine:
         self.ops.append(('conv', layer))
         return out
 
+    def _build_swin(self):
+        """Swin-T backbone (reference modules/swin_transformer.py:500-518): returns the stage-1..3 maps, layer-normed, NHWC."""
+        net, B = self.net, self.B
+        bb = net.backbone
+        ws = bb.window_size
+        assert self.H % 4 == 0 and self.W % 4 == 0
+        pe = bb.patch_embed
+        x = self._conv(_Conv('backbone.patch_embed.proj', pe.proj, act=ACT_NONE, stem=True), self.x_in)     # [B,H/4,W/4,96]
+        self.ops.append(('layernorm', (x, pe.norm, x)))
+        feats = []
+        for li, layer in enumerate(bb.layers):
+            _, h, w, c = x.shape
+            heads = bb.heads[li]
+            for bi, blk in enumerate(layer.blocks):
+                p = f'backbone.layers.{li}.blocks.{bi}'
+                n1 = self._buf(B, h, w, c)
+                self.ops.append(('layernorm', (x, blk.norm1, n1)))
+                qkv = self._conv(_Conv(p + '.attn.qkv', _LinearAsConv(blk.attn.qkv)), n1)
+                att = self._buf(B, h, w, c)
+                self.ops.append(('attn', (qkv, blk.attn, att, (B, h, w, c, heads, ws, blk.shift_size))))
+                x = self._conv(_Conv(p + '.attn.proj', _LinearAsConv(blk.attn.proj)), att, residual=x)
+                n2 = self._buf(B, h, w, c)
+                self.ops.append(('layernorm', (x, blk.norm2, n2)))
+                hid = self._conv(_Conv(p + '.mlp.fc1', _LinearAsConv(blk.mlp.fc1), act=ACT_GELU), n2)
+                x = self._conv(_Conv(p + '.mlp.fc2', _LinearAsConv(blk.mlp.fc2)), hid, residual=x)
+            if li in bb.out_norm_indices:
+                f = self._buf(B, h, w, c)
+                self.ops.append(('layernorm', (x, getattr(bb, f'norm{li}'), f)))
+                feats.append(f)
+            if layer.downsample is not None:
+                ho, wo = (h + 1) // 2, (w + 1) // 2
+                merged = self._buf(B, ho, wo, 4 * c)
+                self.ops.append(('merge_ln', (x, layer.downsample.norm, merged)))
+                x = self._conv(_Conv(f'backbone.layers.{li}.downsample.reduction', _LinearAsConv(layer.downsample.reduction)), merged)
+        return feats
+
     def _build(self):
         net, B, H, W = self.net, self.B, self.H, self.W
         bb = net.backbone
         self.x_in = self._buf(B, H, W, 4)
         self.static_img = None
+        if hasattr(bb, 'patch_embed'):
+            c3, c4, c5 = self._build_swin()
+        else:
+            c3, c4, c5 = self._build_resnet()
+        self._build_neck_and_heads(c3, c4, c5)
+
+    def _build_resnet(self):
+        net, B, H, W = self.net, self.B, self.H, self.W
+        bb = net.backbone
 
         # stem + maxpool
         stem = _Conv('backbone.conv1', bb.conv1, bb.bn1, ACT_RELU, stem=True)
@@ -193,8 +255,10 @@ class InferEngine:
                     skip = x
                 x = self._conv(_Conv(p + '.conv3', blk.conv3, blk.bn3, ACT_RELU), y, residual=skip)
             stage_outs.append(x)
-        c3, c4, c5 = stage_outs[1:4]
+        return stage_outs[1:4]
 
+    def _build_neck_and_heads(self, c3, c4, c5):
+        net, B = self.net, self.B
         # FPN (top-down adds fused as the lateral conv's residual)
         fpn = net.fpn
         p5_1 = self._conv(_Conv('fpn.lat_layers.2', fpn.lat_layers[2]), c5)
@@ -352,6 +416,14 @@ class InferEngine:
                 hip.bilinear2x(arg[0], arg[1], arg[2])
             elif kind == 'softmax':
                 hip.softmax_rows(arg[0], arg[1])
+            elif kind == 'layernorm':
+                hip.layernorm(arg[0], arg[1].weight.detach(), arg[1].bias.detach(), arg[1].eps, arg[2])
+            elif kind == 'merge_ln':
+                hip.patch_merge_layernorm(arg[0], arg[1].weight.detach(), arg[1].bias.detach(), arg[1].eps, arg[2])
+            elif kind == 'attn':
+                qkv, attn, out, (b, h, w, c, heads, win, shift) = arg
+                hip.swin_window_attention(qkv, attn.qkv.bias.detach(), attn.relative_position_bias_table.detach(), b, h, w, c,
+                                          heads, win, shift, out)
 
     def run(self, img):
         """Launch the plan; results land in the engine-owned buffers (no allocation, no sync)."""

@@ -13,7 +13,7 @@ import torch
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libyolact_hip.so')
 
-ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_GELU = 0, 1, 2, 3
 
 # every symbol include/yolact_hip.h declares (checked by tests/test_abi.py without a GPU)
 ABI_SYMBOLS = (
@@ -23,6 +23,7 @@ ABI_SYMBOLS = (
     'ym_greedy_nms_workspace_bytes', 'ym_greedy_nms', 'ym_mask_assemble', 'ym_mask_resize_binarize',
     'ym_boxes_to_pixels',
     'ym_pack_conv_weight_dgrad', 'ym_conv2d_wgrad_workspace_bytes', 'ym_conv2d_wgrad', 'ym_bn_train_fwd',
+    'ym_layernorm', 'ym_patch_merge_layernorm', 'ym_swin_window_attention',
     'ym_bn_train_bwd', 'ym_act_bias_bwd', 'ym_conv2d_fuses_bn_stats', 'ym_bn_train_fwd_stats', 'ym_maxpool3x3s2_bwd', 'ym_bilinear2x_bwd', 'ym_sgd_step',
 )
 
@@ -98,6 +99,9 @@ def lib():
         L.ym_conv2d_wgrad_workspace_bytes.restype = sz
         L.ym_conv2d_wgrad.argtypes = [ctypes.POINTER(WgradDesc), vp, sz, vp]
         L.ym_bn_train_fwd.argtypes = [vp, i64, i32, vp, vp, f32, f32, vp, vp, vp, i32, vp, vp, vp, vp, sz, vp]
+        L.ym_layernorm.argtypes = [vp, vp, vp, f32, vp, i64, i32, vp]
+        L.ym_patch_merge_layernorm.argtypes = [vp, i32, i32, i32, i32, vp, vp, f32, vp, vp]
+        L.ym_swin_window_attention.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
         L.ym_conv2d_fuses_bn_stats.argtypes = [ctypes.POINTER(ConvDesc)]
         L.ym_bn_train_fwd_stats.argtypes = [vp, i64, i32, vp, vp, f32, f32, vp, vp, vp, i32, vp, vp, vp, vp, vp]
         L.ym_bn_train_bwd.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, sz, vp]
@@ -180,6 +184,22 @@ def softmax_rows(x, out):
     c = x.shape[-1]
     rows = x.numel() // c
     check(lib().ym_softmax_rows(ptr(x), ptr(out), rows, c, stream_ptr()), 'ym_softmax_rows')
+
+
+def layernorm(x, gamma, beta, eps, out):
+    c = x.shape[-1]
+    check(lib().ym_layernorm(ptr(x), ptr(gamma), ptr(beta), float(eps), ptr(out), x.numel() // c, c, stream_ptr()), 'ym_layernorm')
+
+
+def patch_merge_layernorm(x, gamma, beta, eps, out):
+    b, h, w, c = x.shape
+    check(lib().ym_patch_merge_layernorm(ptr(x), b, h, w, c, ptr(gamma), ptr(beta), float(eps), ptr(out), stream_ptr()),
+          'ym_patch_merge_layernorm')
+
+
+def swin_window_attention(qkv, qkv_bias, table, b, h, w, c, heads, window, shift, out):
+    check(lib().ym_swin_window_attention(ptr(qkv), ptr(qkv_bias), ptr(table), b, h, w, c, heads, window, shift, ptr(out),
+                                         stream_ptr()), 'ym_swin_window_attention')
 
 
 def mask_assemble(proto, coefs, boxes, out, do_crop=True):

@@ -83,8 +83,9 @@ class Yolact(nn.Module):
             self.backbone = ResNet(layers=(3, 4, 6, 3))
             self.fpn = FPN(in_channels=(512, 1024, 2048))
         elif name.startswith('swin_tiny'):
-            raise NotImplementedError(
-                'swin_tiny_* (SURVEY.md §8 row a18) is not built yet; res50_* / res101_* are.')
+            from .swin_transformer import SwinTransformer
+            self.backbone = SwinTransformer()
+            self.fpn = FPN(in_channels=(192, 384, 768))
         else:
             raise ValueError(f'cannot derive a backbone from cfg class {name!r}')
 
