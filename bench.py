@@ -255,13 +255,15 @@ def main():
         slow = sorted(layers, key=lambda l: -l['ms'])[:5]
         extra['slowest_convs'] = [dict(name=l['name'], ms=round(l['ms'], 4), tflops=round(l['gflop'] / l['ms'], 1)) for l in slow]
         if not args.no_extra and world == 1:
-            for name, b in ((args.cfg, 8), ('res50_coco', 8)):
+            for name, b in ((args.cfg, 8), ('res50_coco', 8), ('swin_tiny_coco', 8)):
                 n2, c2 = (net, cfg) if name == args.cfg else build_net(name, args.img_size, device)
                 w2 = Workload(n2, c2, b, args.img_size, device, with_post=not args.no_post)
                 t2 = timed(w2, 8, 2, lambda: None)
                 f2 = Workload(n2, c2, b, args.img_size, device, with_post=False)
                 tf2 = timed(f2, 8, 2, lambda: None) / 8
                 fl2 = f2.engine.total_flops
+                if name.startswith('swin'):
+                    fl2 += 1.8e9 * b          # attention matmuls (QK^T, PV), not run by the conv kernel
                 extra[f'{name}_bs{b}'] = dict(img_s=round(b * 8 / t2, 1), forward_only_img_s=round(b / tf2, 1),
                                               forward_tflops=round(fl2 / tf2 / 1e12, 2),
                                               frac_f32_mfma_peak=round(fl2 / tf2 / 1e12 / F32_MFMA_PEAK_TFLOPS, 4))
