@@ -212,7 +212,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get('YM_FORCE_DIST', '0') == '1':
         import torch.distributed as dist
         dist.init_process_group(backend='nccl', init_method='env://')   # nccl == RCCL on ROCm
 

@@ -248,3 +248,22 @@ def test_trainer_steps_reduce_loss_and_refresh_eval_engine():
         a = net(img)
         ref = R.forward_eval(img.cpu(), {k: v.cpu() for k, v in net.state_dict().items()})
     torch.testing.assert_close(a[1].cpu(), ref[1], rtol=1e-3, atol=1e-3)
+
+
+def test_bench_under_torchrun_with_rccl_single_rank(tmp_path):
+    """The driver launches bench.py through torch.distributed.run; exercise that launch, the RCCL process group, the
+    barrier/all-reduce timing path and DDP's gradient hooks around the HIP autograd Functions with one rank."""
+    import json
+    import subprocess
+    import sys
+    from tests.conftest import REPO
+    env = dict(os.environ, YM_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--cfg',
+           'res50_coco', '--no-extra', '--no-cpu-baseline', '--train-batch', '2', '--train-steps', '2']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 1 and d['value'] > 0 and d['extra']['train']['finite'] and d['extra']['train']['img_s'] > 0
+    assert 'ddp' in d['extra']['train']['parallelism']
