@@ -50,6 +50,10 @@ struct TopkShared {
     int sel_digit, remaining, eq_total, cnt_gt, cnt_eq, running;
 };
 
+// (Measured: LDS atomics on a hot bin are NOT the bottleneck here — a ballot-aggregated histogram was 1.5x slower.
+//  The serial 256-bin walk by one thread was: ~8 us per radix pass of dependent LDS reads -> done by one wave below.)
+constexpr int KCACHE = 24;   // keys cached per thread: lists up to KCACHE*NT = 24576 entries are read from HBM once
+
 template <int CAP, typename KeyAt>
 __device__ int block_topk_sorted(KeyAt key_at, int L, int R, TopkShared<CAP>& sh) {
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -61,26 +65,71 @@ __device__ int block_topk_sorted(KeyAt key_at, int L, int R, TopkShared<CAP>& sh
         for (int i = tid; i < L; i += nt) { sh.keys[i] = key_at(i); sh.idx[i] = i; }
         cnt = L;
     } else {
+        // The radix passes re-scan the list 5+ times; every scan used to be a round of dependent global loads
+        // (latency-bound: ~20 rounds x 5 passes).  Read the keys ONCE into registers when the list fits.
+        const bool cached = L <= KCACHE * nt;
+        uint32_t ck[KCACHE];
+        if (cached) {
+#pragma unroll
+            for (int j = 0; j < KCACHE; ++j) {
+                const int i = tid + j * nt;
+                ck[j] = i < L ? key_at(i) : 0u;
+            }
+        }
         uint32_t prefix = 0u, mask = 0u;
         int remaining = R;
         for (int shift = 24; shift >= 0; shift -= 8) {
             for (int i = tid; i < 256; i += nt) sh.hist[i] = 0u;
             __syncthreads();
-            for (int i = tid; i < L; i += nt) {
-                const uint32_t k = key_at(i);
-                if ((k & mask) == prefix) atomicAdd(&sh.hist[(k >> shift) & 255u], 1u);
+            if (cached) {
+#pragma unroll
+                for (int j = 0; j < KCACHE; ++j) {
+                    const int i = tid + j * nt;
+                    if (i < L && ck[j] != 0u && (ck[j] & mask) == prefix) atomicAdd(&sh.hist[(ck[j] >> shift) & 255u], 1u);
+                }
+            } else {
+                for (int base = 0; base < L; base += nt) {
+                    const int i = base + tid;
+                    const uint32_t k = i < L ? key_at(i) : 0u;
+                    if (i < L && k != 0u && (k & mask) == prefix) atomicAdd(&sh.hist[(k >> shift) & 255u], 1u);
+                }
             }
             __syncthreads();
-            if (tid == 0) {
-                int acc = 0, d = 255;
-                for (; d > 0; --d) {
-                    const int h = (int)sh.hist[d];
-                    if (acc + h >= remaining) break;
-                    acc += h;
+            if (tid < 64) {
+                // key 0 marks an absent entry and is never counted: with fewer than R real keys the walk ends at
+                // digit 0 and T becomes 0, i.e. "take every real key" (the callers drop key-0 slots afterwards).
+                // Walk the 256 bins from the top with ONE WAVE: lane l owns digits 255-4l .. 252-4l.
+                int c[4], lane_total = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { c[j] = (int)sh.hist[255 - (4 * tid + j)]; lane_total += c[j]; }
+                int incl = lane_total;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v = __shfl_up(incl, o);
+                    if (tid >= o) incl += v;
                 }
-                sh.sel_digit = d;
-                sh.remaining = remaining - acc;
-                sh.eq_total = (int)sh.hist[d];
+                int run = incl - lane_total, found_r = -1, acc_before = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (found_r < 0 && run + c[j] >= remaining) { found_r = 4 * tid + j; acc_before = run; }
+                    run += c[j];
+                }
+                const unsigned long long hit = __ballot(found_r >= 0);
+                const int total = __shfl(incl, 63);
+                if (hit) {
+                    const int leader = __ffsll((long long)hit) - 1;
+                    if (tid == leader) {
+                        int d = 255 - found_r, acc = acc_before;
+                        if (d == 0) { d = 0; }      // reached the last bin normally
+                        sh.sel_digit = d;
+                        sh.remaining = remaining - acc;
+                        sh.eq_total = (int)sh.hist[d];
+                    }
+                } else if (tid == 0) {
+                    sh.sel_digit = 0;                                  // fewer real keys than requested
+                    sh.remaining = remaining - (total - (int)sh.hist[0]);
+                    sh.eq_total = (int)sh.hist[0];
+                }
             }
             __syncthreads();
             prefix |= (uint32_t)sh.sel_digit << shift;
@@ -90,18 +139,27 @@ __device__ int block_topk_sorted(KeyAt key_at, int L, int R, TopkShared<CAP>& sh
         }
         const uint32_t T = prefix;
         const int r_eq = remaining, n_gt = R - r_eq, eq_total = sh.eq_total;
-        for (int i = tid; i < L; i += nt) {
-            const uint32_t k = key_at(i);
+        auto collect = [&](uint32_t k, int i) {
             if (k > T) {
                 const int p = atomicAdd(&sh.cnt_gt, 1);
                 sh.keys[p] = k; sh.idx[p] = i;
-            } else if (k == T && eq_total == r_eq) {
+            } else if (k == T && eq_total == r_eq && T != 0u) {
                 const int p = atomicAdd(&sh.cnt_eq, 1);
                 sh.keys[n_gt + p] = k; sh.idx[n_gt + p] = i;
             }
+        };
+        if (cached) {
+#pragma unroll
+            for (int j = 0; j < KCACHE; ++j) {
+                const int i = tid + j * nt;
+                if (i < L) collect(ck[j], i);
+            }
+        } else {
+            for (int i = tid; i < L; i += nt) collect(key_at(i), i);
         }
-        if (eq_total != r_eq) {
-            // more ties at the cut than slots: take the r_eq LOWEST indices (ordered block scan)
+        if (eq_total != r_eq && T != 0u) {
+            // more ties at the cut than slots: take the r_eq LOWEST indices (ordered block scan); T == 0 means fewer
+            // than R real keys exist — the remaining slots stay empty (key 0)
             const int lane = tid & 63, wv = tid >> 6;
             for (int base = 0; base < L; base += nt) {
                 const int i = base + tid;
@@ -192,28 +250,51 @@ __global__ __launch_bounds__(256) void k_score_flag(const float* __restrict__ cl
     }
 }
 
+// Ordered compaction in ONE pass: every thread owns a contiguous run of flags (<= 32), one block-wide exclusive scan.
 __global__ __launch_bounds__(NT) void k_compact(const uint8_t* __restrict__ flag, int N, int* __restrict__ keep_idx,
                                                 int* __restrict__ counters) {
     __shared__ int wave_tot[NT / 64];
-    __shared__ int running;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) running = 0;
-    __syncthreads();
-    for (int base = 0; base < N; base += NT) {
-        const int i = base + tid;
-        const bool f = i < N && flag[i];
-        const unsigned long long bal = __ballot(f);
-        const int pre = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_tot[wv] = __popcll(bal);
+    int total_before = 0;
+    for (int chunk0 = 0; chunk0 < N; chunk0 += NT * 32) {            // one trip for N <= 32768
+        const int beg = chunk0 + tid * 32;
+        uint32_t bits = 0u;
+        if (beg < N) {
+            if (beg + 32 <= N && ((uintptr_t)(flag + beg) & 15) == 0) {
+                const uint4 a = *reinterpret_cast<const uint4*>(flag + beg), b = *reinterpret_cast<const uint4*>(flag + beg + 16);
+                const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bits |= ((w[q] >> (8 * e)) & 0xFFu) ? (1u << (q * 4 + e)) : 0u;
+            } else {
+                for (int e = 0; e < 32 && beg + e < N; ++e) bits |= flag[beg + e] ? (1u << e) : 0u;
+            }
+        }
+        const int mine = __popc(bits);
+        int incl = mine;                                               // wave inclusive scan
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) wave_tot[wv] = incl;
         __syncthreads();
-        int off = running;
-        for (int w = 0; w < wv; ++w) off += wave_tot[w];
-        if (f) keep_idx[off + pre] = i;
-        __syncthreads();
-        if (tid == 0) { int t = 0; for (int w = 0; w < NT / 64; ++w) t += wave_tot[w]; running += t; }
+        int off = total_before + incl - mine;
+        int chunk_total = 0;
+        for (int w = 0; w < NT / 64; ++w) {
+            if (w < wv) off += wave_tot[w];
+            chunk_total += wave_tot[w];
+        }
+        while (bits) {
+            const int e = __ffs(bits) - 1;
+            bits &= bits - 1;
+            keep_idx[off++] = beg + e;
+        }
+        total_before += chunk_total;
         __syncthreads();
     }
-    if (tid == 0) counters[0] = running;
+    if (tid == 0) counters[0] = total_before;
 }
 
 __global__ __launch_bounds__(256) void k_decode_transpose(const float* __restrict__ cls, const float* __restrict__ box,

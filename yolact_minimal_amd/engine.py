@@ -154,7 +154,14 @@ class InferEngine:
             use_graph = os.environ.get('YM_GRAPH', '1') != '0'
         self.use_graph = use_graph
         self.graph = None
-        self.ops = []          # list of zero-arg callables (one C-ABI launch each)
+        self.ops = []          # (kind, arg): one C-ABI launch each, in a valid sequential order
+        self.op_stream = {}    # op index -> branch stream id (0 = the caller's stream)
+        self.op_deps = {}      # op index -> indices of producer ops on OTHER streams (fork/join edges of the graph)
+        self._producers = {}   # buffer data_ptr -> [op indices that write it]
+        self._cur_stream = 0
+        self._side_streams = {}
+        self._events = {}
+        self.use_branches = os.environ.get('YM_BRANCHES', '0') == '1'   # measured neutral on ROCm 7.2 hipGraph: off by default
         self.convs = []        # every _Conv, for weight refresh / flop accounting
         self._weights_epoch = -1
         self._bufs = []
@@ -168,7 +175,25 @@ class InferEngine:
         self._bufs.append(t)
         return t
 
-    def _conv(self, layer, x, out=None, residual=None, segs=None):
+    def _add_op(self, kind, arg, inputs, outputs):
+        idx = len(self.ops)
+        self.ops.append((kind, arg))
+        sid = self._cur_stream if self.use_branches else 0
+        self.op_stream[idx] = sid
+        deps = []
+        for t in inputs:
+            if t is None:
+                continue
+            for j in self._producers.get(t.data_ptr(), ()):
+                if self.op_stream[j] != sid and j not in deps:
+                    deps.append(j)
+        if deps:
+            self.op_deps[idx] = deps
+        for t in outputs:
+            self._producers.setdefault(t.data_ptr(), []).append(idx)
+        return idx
+
+    def _conv(self, layer, x, out=None, residual=None, segs=None, seg_outputs=None):
         """Register a fused conv launch; returns its NHWC output buffer."""
         b, h, w, _ = x.shape
         ho = (h + 2 * layer.pad - layer.kh) // layer.stride + 1
@@ -180,7 +205,7 @@ class InferEngine:
         layer.refresh()
         layer.bind(x, segs, residual)
         self.convs.append(layer)
-        self.ops.append(('conv', layer))
+        self._add_op('conv', layer, [x, residual], seg_outputs if seg_outputs is not None else [out])
         return out
 
     def _build_swin(self):
@@ -191,7 +216,7 @@ class InferEngine:
         assert self.H % 4 == 0 and self.W % 4 == 0
         pe = bb.patch_embed
         x = self._conv(_Conv('backbone.patch_embed.proj', pe.proj, act=ACT_NONE, stem=True), self.x_in)     # [B,H/4,W/4,96]
-        self.ops.append(('layernorm', (x, pe.norm, x)))
+        self._add_op('layernorm', (x, pe.norm, x), [x], [x])
         feats = []
         for li, layer in enumerate(bb.layers):
             _, h, w, c = x.shape
@@ -199,23 +224,23 @@ class InferEngine:
             for bi, blk in enumerate(layer.blocks):
                 p = f'backbone.layers.{li}.blocks.{bi}'
                 n1 = self._buf(B, h, w, c)
-                self.ops.append(('layernorm', (x, blk.norm1, n1)))
+                self._add_op('layernorm', (x, blk.norm1, n1), [x], [n1])
                 qkv = self._conv(_Conv(p + '.attn.qkv', _LinearAsConv(blk.attn.qkv)), n1)
                 att = self._buf(B, h, w, c)
-                self.ops.append(('attn', (qkv, blk.attn, att, (B, h, w, c, heads, ws, blk.shift_size))))
+                self._add_op('attn', (qkv, blk.attn, att, (B, h, w, c, heads, ws, blk.shift_size)), [qkv], [att])
                 x = self._conv(_Conv(p + '.attn.proj', _LinearAsConv(blk.attn.proj)), att, residual=x)
                 n2 = self._buf(B, h, w, c)
-                self.ops.append(('layernorm', (x, blk.norm2, n2)))
+                self._add_op('layernorm', (x, blk.norm2, n2), [x], [n2])
                 hid = self._conv(_Conv(p + '.mlp.fc1', _LinearAsConv(blk.mlp.fc1), act=ACT_GELU), n2)
                 x = self._conv(_Conv(p + '.mlp.fc2', _LinearAsConv(blk.mlp.fc2)), hid, residual=x)
             if li in bb.out_norm_indices:
                 f = self._buf(B, h, w, c)
-                self.ops.append(('layernorm', (x, getattr(bb, f'norm{li}'), f)))
+                self._add_op('layernorm', (x, getattr(bb, f'norm{li}'), f), [x], [f])
                 feats.append(f)
             if layer.downsample is not None:
                 ho, wo = (h + 1) // 2, (w + 1) // 2
                 merged = self._buf(B, ho, wo, 4 * c)
-                self.ops.append(('merge_ln', (x, layer.downsample.norm, merged)))
+                self._add_op('merge_ln', (x, layer.downsample.norm, merged), [x], [merged])
                 x = self._conv(_Conv(f'backbone.layers.{li}.downsample.reduction', _LinearAsConv(layer.downsample.reduction)), merged)
         return feats
 
@@ -239,7 +264,7 @@ class InferEngine:
         x = self._conv(stem, self.x_in)
         hp, wp = (x.shape[1] + 2 - 3) // 2 + 1, (x.shape[2] + 2 - 3) // 2 + 1
         pooled = self._buf(B, hp, wp, 64)
-        self.ops.append(('maxpool', (x, pooled)))
+        self._add_op('maxpool', (x, pooled), [x], [pooled])
         x = pooled
 
         # residual stages
@@ -263,18 +288,25 @@ class InferEngine:
         fpn = net.fpn
         p5_1 = self._conv(_Conv('fpn.lat_layers.2', fpn.lat_layers[2]), c5)
         u5 = self._buf(B, p5_1.shape[1] * 2, p5_1.shape[2] * 2, 256)
-        self.ops.append(('bilinear', (p5_1, u5, False)))
+        self._add_op('bilinear', (p5_1, u5, False), [p5_1], [u5])
         assert u5.shape[1:3] == c4.shape[1:3], 'img_size must be divisible by 32 (reference config.py:75)'
         p4_1 = self._conv(_Conv('fpn.lat_layers.1', fpn.lat_layers[1]), c4, residual=u5)
         u4 = self._buf(B, p4_1.shape[1] * 2, p4_1.shape[2] * 2, 256)
-        self.ops.append(('bilinear', (p4_1, u4, False)))
+        self._add_op('bilinear', (p4_1, u4, False), [p4_1], [u4])
         p3_1 = self._conv(_Conv('fpn.lat_layers.0', fpn.lat_layers[0]), c3, residual=u4)
+        # Independent branches run on side streams (fork/join edges come from the data flow, see _add_op):
+        #   stream 0: P3 + ProtoNet (the long chain)    stream 1: P5, P6, P7 + their heads
+        #   stream 2: P4 + its head                       stream 3: the P3 head
+        self._cur_stream = 1
         p5 = self._conv(_Conv('fpn.pred_layers.2', fpn.pred_layers[2][0], act=ACT_RELU), p5_1)
-        p4 = self._conv(_Conv('fpn.pred_layers.1', fpn.pred_layers[1][0], act=ACT_RELU), p4_1)
-        p3 = self._conv(_Conv('fpn.pred_layers.0', fpn.pred_layers[0][0], act=ACT_RELU), p3_1)
         p6 = self._conv(_Conv('fpn.downsample_layers.0', fpn.downsample_layers[0][0], act=ACT_RELU), p5)
         p7 = self._conv(_Conv('fpn.downsample_layers.1', fpn.downsample_layers[1][0], act=ACT_RELU), p6)
+        self._cur_stream = 2
+        p4 = self._conv(_Conv('fpn.pred_layers.1', fpn.pred_layers[1][0], act=ACT_RELU), p4_1)
+        self._cur_stream = 0
+        p3 = self._conv(_Conv('fpn.pred_layers.0', fpn.pred_layers[0][0], act=ACT_RELU), p3_1)
         levels = [p3, p4, p5, p6, p7]
+        level_stream = [3, 2, 1, 1, 1]
 
         # ProtoNet
         pn = net.proto_net
@@ -282,7 +314,7 @@ class InferEngine:
         for i in (0, 2, 4):
             y = self._conv(_Conv(f'proto_net.proto1.{i}', pn.proto1[i], act=ACT_RELU), y)
         up = self._buf(B, y.shape[1] * 2, y.shape[2] * 2, 256)
-        self.ops.append(('bilinear', (y, up, True)))
+        self._add_op('bilinear', (y, up, True), [y], [up])
         y = self._conv(_Conv('proto_net.proto2.0', pn.proto2[0], act=ACT_RELU), up)
         self.proto_out = self._conv(_Conv('proto_net.proto2.2', pn.proto2[2], act=ACT_RELU), y)  # NHWC = [B,Hp,Wp,32]
 
@@ -298,6 +330,7 @@ class InferEngine:
         self.coef_pred = self._buf(B, n_total, cd)
         off = 0
         for li, lv in enumerate(levels):
+            self._cur_stream = level_stream[li]
             xh = self._conv(_Conv(f'prediction_layers.upfeature@P{li + 3}', hd.upfeature[0], act=ACT_RELU), lv)
             fused = _Conv(f'prediction_layers.conf|bbox|coef@P{li + 3}', [hd.conf_layer, hd.bbox_layer, hd.coef_layer[0]])
             c_conf, c_box, c_coef = na * nc, na * 4, na * cd
@@ -308,14 +341,27 @@ class InferEngine:
                 (c_conf + c_box, c_conf + c_box + c_coef, self.coef_pred.data_ptr() + off * cd * es, n_total * cd,
                  c_coef, ACT_TANH),
             ]
-            self._conv(fused, xh, segs=segs)
+            self._conv(fused, xh, segs=segs, seg_outputs=[self.class_logits, self.box_pred, self.coef_pred])
             off += lv.shape[1] * lv.shape[2] * na
-        self.ops.append(('softmax', (self.class_logits, self.class_pred)))
+        self._cur_stream = 0
+        self._add_op('softmax', (self.class_logits, self.class_pred), [self.class_logits], [self.class_pred])
 
-        ws_bytes = max([hip.conv_workspace_bytes(c.desc) for c in self.convs] + [256])
-        self.workspace = torch.empty(ws_bytes, device=self.device, dtype=torch.uint8)
+        self._alloc_workspaces()
         self.total_flops = sum(c.flops for c in self.convs)
         self._weights_epoch = self.net._weights_epoch
+
+    def _alloc_workspaces(self):
+        """Split-K scratch: one buffer per branch stream (concurrent branches must not share it)."""
+        need = {}
+        for i, (kind, arg) in enumerate(self.ops):
+            if kind == 'conv':
+                sid = self.op_stream.get(i, 0)
+                need[sid] = max(need.get(sid, 256), hip.conv_workspace_bytes(arg.desc))
+        need[0] = max(need.values())          # stream 0's buffer also serves sequential (eager / profiling) replays
+        old = getattr(self, 'workspaces', {})
+        self.workspaces = {sid: (old[sid] if sid in old and old[sid].numel() >= nb else
+                                 torch.empty(nb, device=self.device, dtype=torch.uint8)) for sid, nb in need.items()}
+        self.workspace = self.workspaces[0]
 
     # ---- execution ---------------------------------------------------------------------------
     def refresh_weights(self):
@@ -330,9 +376,7 @@ class InferEngine:
             c.desc.tile_m, c.desc.tile_n = c.tile
             c.desc.ksplit = c.ksplit
             c.desc.kwaves = c.kwaves
-        ws_bytes = max([hip.conv_workspace_bytes(c.desc) for c in self.convs] + [256])
-        if ws_bytes > self.workspace.numel():
-            self.workspace = torch.empty(ws_bytes, device=self.device, dtype=torch.uint8)
+        self._alloc_workspaces()
         self.graph = None
 
     def autotune(self, iters=10, verbose=False):
@@ -404,26 +448,54 @@ class InferEngine:
         self.retune()
         return results
 
+    def _launch_one(self, kind, arg, ws):
+        if kind == 'conv':
+            hip.conv2d_fwd(arg.desc, ws)
+        elif kind == 'maxpool':
+            hip.maxpool3x3s2(arg[0], arg[1])
+        elif kind == 'bilinear':
+            hip.bilinear2x(arg[0], arg[1], arg[2])
+        elif kind == 'softmax':
+            hip.softmax_rows(arg[0], arg[1])
+        elif kind == 'layernorm':
+            hip.layernorm(arg[0], arg[1].weight.detach(), arg[1].bias.detach(), arg[1].eps, arg[2])
+        elif kind == 'merge_ln':
+            hip.patch_merge_layernorm(arg[0], arg[1].weight.detach(), arg[1].bias.detach(), arg[1].eps, arg[2])
+        elif kind == 'attn':
+            qkv, attn, out, (b, h, w, c, heads, win, shift) = arg
+            hip.swin_window_attention(qkv, attn.qkv.bias.detach(), attn.relative_position_bias_table.detach(), b, h, w, c,
+                                      heads, win, shift, out)
+
     def _launch_all(self, img):
+        """Replay the plan.  Ops tagged with a branch stream run on side streams; cross-stream producer->consumer edges
+        become event waits (inside hipGraph capture they become graph edges, so independent branches overlap)."""
         hip.nchw_to_nhwc4(img, self.x_in)
-        ws = self.workspace
-        for kind, arg in self.ops:
-            if kind == 'conv':
-                hip.conv2d_fwd(arg.desc, ws)
-            elif kind == 'maxpool':
-                hip.maxpool3x3s2(arg[0], arg[1])
-            elif kind == 'bilinear':
-                hip.bilinear2x(arg[0], arg[1], arg[2])
-            elif kind == 'softmax':
-                hip.softmax_rows(arg[0], arg[1])
-            elif kind == 'layernorm':
-                hip.layernorm(arg[0], arg[1].weight.detach(), arg[1].bias.detach(), arg[1].eps, arg[2])
-            elif kind == 'merge_ln':
-                hip.patch_merge_layernorm(arg[0], arg[1].weight.detach(), arg[1].bias.detach(), arg[1].eps, arg[2])
-            elif kind == 'attn':
-                qkv, attn, out, (b, h, w, c, heads, win, shift) = arg
-                hip.swin_window_attention(qkv, attn.qkv.bias.detach(), attn.relative_position_bias_table.detach(), b, h, w, c,
-                                          heads, win, shift, out)
+        main = torch.cuda.current_stream()
+        needs_event = {j for deps in self.op_deps.values() for j in deps}
+        used = set()
+        for i, (kind, arg) in enumerate(self.ops):
+            sid = self.op_stream.get(i, 0)
+            if sid == 0:
+                st = main
+            else:
+                st = self._side_streams.get(sid)
+                if st is None:
+                    st = self._side_streams[sid] = torch.cuda.Stream(device=self.device)
+                used.add(sid)
+            for j in self.op_deps.get(i, ()):
+                st.wait_event(self._events[j])
+            if sid == 0:
+                self._launch_one(kind, arg, self.workspaces[0])
+            else:
+                with torch.cuda.stream(st):
+                    self._launch_one(kind, arg, self.workspaces[sid])
+            if i in needs_event:
+                ev = self._events.get(i)
+                if ev is None:
+                    ev = self._events[i] = torch.cuda.Event()
+                ev.record(st)
+        for sid in used:
+            main.wait_stream(self._side_streams[sid])
 
     def run(self, img):
         """Launch the plan; results land in the engine-owned buffers (no allocation, no sync)."""
