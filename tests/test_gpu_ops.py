@@ -12,7 +12,7 @@ def _dev():
     return torch.device('cuda:0')
 
 
-def run_conv(x_nchw, w, scale=None, shift=None, residual=None, stride=1, pad=0, act=0, tile=(0, 0), ksplit=0, kwaves=0):
+def run_conv(x_nchw, w, scale=None, shift=None, residual=None, stride=1, pad=0, act=0, tile=(0, 0), ksplit=0, kwaves=0, stages=0):
     """Runs ym_conv2d_fwd on NHWC data; returns NCHW cpu tensor."""
     from yolact_minimal_amd import hip
     dev = _dev()
@@ -45,6 +45,7 @@ def run_conv(x_nchw, w, scale=None, shift=None, residual=None, stride=1, pad=0, 
     d.tile_m, d.tile_n = tile
     d.ksplit = ksplit
     d.kwaves = kwaves
+    d.stages = stages
     nbytes = hip.conv_workspace_bytes(d)
     ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
     hip.conv2d_fwd(d, ws)
@@ -97,6 +98,31 @@ def test_conv_parity(case):
     assert not torch.isnan(got).any()
     # tolerance: fp32 accumulation-order differences only
     torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('case', [
+    # b, cin, h, w, cout, k, stride, pad, act, residual, tile, ksplit   (all with the 3-deep LDS ring)
+    (1, 64, 17, 17, 64, 1, 1, 0, 1, False, (64, 64), 1),        # 2 K tiles
+    (1, 32, 9, 9, 64, 1, 1, 0, 0, False, (64, 64), 1),          # 1 K tile
+    (2, 96, 12, 10, 128, 1, 1, 0, 1, True, (64, 64), 1),        # 3 K tiles
+    (1, 256, 34, 34, 256, 3, 1, 1, 1, False, (64, 64), 6),      # split-K, 12 tiles per slice
+    (1, 128, 19, 19, 128, 3, 2, 1, 1, False, (128, 64), 1),
+    (1, 256, 9, 9, 96, 3, 1, 1, 2, False, (64, 128), 2),
+    (1, 1024, 13, 13, 256, 1, 1, 0, 1, True, (64, 64), 5),      # uneven slices (32 tiles / 5)
+])
+def test_conv_three_stage_ring_parity(case):
+    b, cin, h, w, cout, k, stride, pad, act, use_res, tile, ksplit = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    res = torch.randn(b, cout, ho, wo, generator=g) if use_res else None
+    got = run_conv(x, wt, scale, shift, res, stride, pad, act, tile, ksplit, 0, 3)
+    base = run_conv(x, wt, scale, shift, res, stride, pad, act, tile, ksplit, 0, 2)
+    assert torch.equal(got, base)          # same summation order as the 2-stage kernel -> bit-identical
+    torch.testing.assert_close(got, ref_conv(x, wt, scale, shift, res, stride, pad, act), rtol=1e-4, atol=1e-5)
 
 
 WAVE_CASES = [

@@ -16,7 +16,7 @@ from bench import build_net  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default='gpurun_out/tuned_gfx950.json')
-    ap.add_argument('--cfgs', default='res101_coco,res50_coco')
+    ap.add_argument('--cfgs', default='res101_coco,res50_coco,swin_tiny_coco')
     ap.add_argument('--batches', default='1,8')
     ap.add_argument('--iters', type=int, default=10)
     args = ap.parse_args()
@@ -30,15 +30,15 @@ def main():
             res = eng.autotune(args.iters, verbose=True)
             for k, v in res.items():
                 if k not in table:
-                    table[k] = v[:4]
+                    table[k] = v[:5]
                     detail[k] = v
             net._engines.clear()
             torch.cuda.empty_cache()
     os.makedirs(os.path.dirname(args.out) or '.', exist_ok=True)
     json.dump(table, open(args.out, 'w'), indent=0, sort_keys=True)
     json.dump(detail, open(args.out.replace('.json', '_detail.json'), 'w'), indent=0, sort_keys=True)
-    tot_b = sum(v[5] for v in detail.values())
-    tot_a = sum(v[4] for v in detail.values())
+    tot_b = sum(v[6] for v in detail.values())
+    tot_a = sum(v[5] for v in detail.values())
     print(f'{len(table)} shapes; sum of per-shape best {tot_a:.0f} us vs default {tot_b:.0f} us')
 
 

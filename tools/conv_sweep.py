@@ -42,17 +42,19 @@ def main():
         M, nkt = b * d.Ho * d.Wo, d.k_pad // 32
         flops = 2.0 * M * cout * d.k_pad
         rows = []
-        cands = [((0, 0), 0, 0)]
+        cands = [((0, 0), 0, 0, 0)]
         for t in ((128, 128), (128, 64), (64, 128), (64, 64)):
             for ks in (1, 2, 3, 4, 6, 8, 12, 16, 24):
                 if ks <= nkt:
-                    cands.append((t, ks, 0))
+                    cands.append((t, ks, 0, 2))
+                    if t != (128, 128):
+                        cands.append((t, ks, 0, 3))
         for t in ((32, 32), (64, 32), (32, 64), (64, 64)):
             for kw in (1, 2, 4, 8):
                 if not (kw == 8 and t == (64, 64)):
-                    cands.append((t, 1, kw))
-        for tile, ks, kw in cands:
-            d.tile_m, d.tile_n, d.ksplit, d.kwaves = tile[0], tile[1], ks, kw
+                    cands.append((t, 1, kw, 0))
+        for tile, ks, kw, stg in cands:
+            d.tile_m, d.tile_n, d.ksplit, d.kwaves, d.stages = tile[0], tile[1], ks, kw, stg
             if hip.conv_workspace_bytes(d) > ws.numel():
                 continue
             try:
@@ -68,11 +70,11 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 best = min(best, e0.elapsed_time(e1) / args.iters * 1e3)
-            rows.append((best, tile, ks, kw))
+            rows.append((best, tile, ks, kw, stg))
         rows.sort()
         print(f'== M={M} N={cout} K={d.k_pad} k={k} s={stride} res={res}: {flops / 1e9:.2f} GFLOP')
-        for t, tile, ks, kw in rows[:12]:
-            print(f'   {"wave" if kw else "wg  "} tile={tile} ksplit={ks} kwaves={kw}: {t:7.1f} us  {flops / t / 1e6:6.1f} TF')
+        for t, tile, ks, kw, stg in rows[:12]:
+            print(f'   {"wave" if kw else "wg  "} tile={tile} ksplit={ks} kwaves={kw} stages={stg}: {t:7.1f} us  {flops / t / 1e6:6.1f} TF')
         worst = [r for r in rows if r[3] > 0][:6]
         print('   best wave-kernel variants:', [(f'{r[0]:.1f}', r[1], r[3]) for r in worst])
 

@@ -23,6 +23,7 @@ struct ConvP {
     double* bn_sumsq;
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, Kpad;
     int M, HoWo, nkt, ksplit, kt_per_split, tiles_m, tiles_n;
+    unsigned in_bytes, w_bytes;   // sizes of `in` / `w` for the raw-buffer descriptors (out-of-range reads return 0)
     int nseg;
     int vec;   // 1: single segment, plain NHWC [M][Cout], Cout % 4 == 0, 16-byte aligned -> vectorised epilogue
     SegDev seg[3];

@@ -19,6 +19,7 @@
 // is MFMA-issue bound, LDS and the global->LDS staging (register prefetch, double-buffered) sit
 // far below their limits.  Grid: one block per (tile, k-slice), XCD-aware remap so the N-tiles
 // sharing an A panel run on the same XCD L2.
+#include <type_traits>
 #include "conv_common.h"
 
 using namespace ymk;
@@ -27,19 +28,32 @@ namespace {
 
 constexpr int PITCH = 36;  // floats
 
+// Branch-free operand fetch: raw buffer loads return 0 for offsets beyond the descriptor's range, so padding taps,
+// rows past M / Cout and the K tail need no control flow (and hipcc can keep COUNTED vmcnt waits across the K loop —
+// with `if (ok) load` it drained vmcnt(0) before every LDS write, defeating any prefetch depth > 1).
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0xFFFFFFF0u;
+__device__ __forceinline__ f32x4 buf_ld16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+
 // MODE 0: Cin % 32 == 0 (every K tile lies inside one filter tap).  MODE 1: Cin == 4 (stem; one tap per float4).
 // MODE 2: data gradient (transposed conv): output pixel (ih,iw) gathers dY[(ih+pad-kh)/s][(iw+pad-kw)/s] where divisible.
-template <int BM, int BN, int MODE>
+// NS: LDS ring depth.  2 = load(t+1) overlaps compute(t).  3 = loads run TWO tiles ahead (small tiles with one workgroup per
+// CU measured 2250 cycles per K tile against 1024 cycles of MFMA with NS=2: one L2 round trip was exposed per tile).
+template <int BM, int BN, int MODE, int NS>
 __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
     constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave (wave tile = BM/2 x BN/2)
     constexpr int AR = BM / 32, BR = BN / 32;   // staging rows per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                         // [2][BM][PITCH]
-    float* Bs = smem + 2 * BM * PITCH;        // [2][BN][PITCH]
+    float* As = smem;                         // [NS][BM][PITCH]
+    float* Bs = smem + NS * BM * PITCH;       // [NS][BN][PITCH]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
 
     int id = ym_xcd_remap(blockIdx.x, gridDim.x);
     const int ks = id % p.ksplit;
@@ -76,11 +90,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
             a_pix[i] = 0;
         }
     }
-    const float* wrow[BR];
+    unsigned wrow[BR];           // byte offset of this thread's float4 in weight row n (OOB -> zeros)
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
         const int n = n0 + rbase + 32 * i;
-        wrow[i] = (n < p.Cout) ? p.w + (size_t)n * p.Kpad + c4 * 4 : nullptr;
+        wrow[i] = (n < p.Cout) ? (unsigned)((n * p.Kpad + c4 * 4) * 4) : OOB;
     }
 
     // tap walker for MODE 0 (uniform across the block)
@@ -93,20 +107,22 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
         kw = tap - kh * p.KW;
     }
 
-    f32x4 ra[AR], rb[BR];
-    auto load_tile = [&](int kt) {
+    constexpr int NSET = NS == 3 ? 2 : 1;
+    f32x4 rA[NSET][AR], rB[NSET][BR];
+    auto load_tile = [&](int kt, auto set_c) {
+        constexpr int SET = decltype(set_c)::value;
+        f32x4 (&ra)[AR] = rA[SET];
+        f32x4 (&rb)[BR] = rB[SET];
+        const bool live = kt < kt_end;      // prefetches past the end are issued anyway (OOB -> zeros, never stored):
+                                            // an UNCONDITIONAL load count is what lets hipcc emit counted vmcnt waits
         if (MODE == 0) {
             const int tap_off = (kh * p.W + kw);
 #pragma unroll
             for (int i = 0; i < AR; ++i) {
                 const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
                 const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-                if (ok) {
-                    const float* src = p.in + (size_t)(a_pix[i] + tap_off) * p.Cin + c0 + c4 * 4;
-                    ra[i] = *reinterpret_cast<const f32x4*>(src);
-                } else {
-                    ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
+                const unsigned off = (unsigned)(((a_pix[i] + tap_off) * p.Cin + c0 + c4 * 4) * 4);
+                ra[i] = buf_ld16(rs_in, (ok && live) ? off : OOB);
             }
             c0 += BK;
             if (c0 >= p.Cin) {
@@ -121,12 +137,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
                 const int th = a_ih0[i] - kh, tw = a_iw0[i] - kw;
                 const int yh = th >> sh, yw = tw >> sh;
                 const bool ok = th >= 0 && tw >= 0 && ((th | tw) & smask) == 0 && yh < p.H && yw < p.W;
-                if (ok) {
-                    const float* src = p.in + ((size_t)(a_pix[i] + yh) * p.W + yw) * p.Cin + c0 + c4 * 4;
-                    ra[i] = *reinterpret_cast<const f32x4*>(src);
-                } else {
-                    ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
+                const unsigned off = (unsigned)((((a_pix[i] + yh) * p.W + yw) * p.Cin + c0 + c4 * 4) * 4);
+                ra[i] = buf_ld16(rs_in, (ok && live) ? off : OOB);
             }
             c0 += BK;
             if (c0 >= p.Cin) {
@@ -141,21 +153,17 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
             for (int i = 0; i < AR; ++i) {
                 const int ih = a_ih0[i] + th, iw = a_iw0[i] + tw;
                 const bool ok = tap_ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-                if (ok) {
-                    const float* src = p.in + (size_t)(a_pix[i] + th * p.W + tw) * 4;
-                    ra[i] = *reinterpret_cast<const f32x4*>(src);
-                } else {
-                    ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
+                const unsigned off = (unsigned)((a_pix[i] + th * p.W + tw) * 16);
+                ra[i] = buf_ld16(rs_in, (ok && live) ? off : OOB);
             }
         }
 #pragma unroll
-        for (int i = 0; i < BR; ++i) {
-            if (wrow[i]) rb[i] = *reinterpret_cast<const f32x4*>(wrow[i] + (size_t)kt * BK);
-            else rb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int i = 0; i < BR; ++i) rb[i] = buf_ld16(rs_w, (wrow[i] == OOB || !live) ? OOB : wrow[i] + (unsigned)(kt * BK * 4));
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, auto set_c) {
+        constexpr int SET = decltype(set_c)::value;
+        const f32x4 (&ra)[AR] = rA[SET];
+        const f32x4 (&rb)[BR] = rB[SET];
         float* a = As + buf * BM * PITCH;
         float* b = Bs + buf * BN * PITCH;
 #pragma unroll
@@ -178,19 +186,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
     const int a_frag_off = (wm * (BM / 2) + frag_row) * PITCH + khalf * 4;
     const int b_frag_off = (wn * (BN / 2) + frag_row) * PITCH + khalf * 4;
 
-    if (kt_beg < kt_end) {
-        load_tile(kt_beg);
-        store_tile(0);
-    }
-    __syncthreads();
-
-    for (int kt = kt_beg; kt < kt_end; ++kt) {
-        const int cur = (kt - kt_beg) & 1;
-        const bool more = (kt + 1) < kt_end;
-        if (more) load_tile(kt + 1);
-
-        const float* a = As + cur * BM * PITCH + a_frag_off;
-        const float* b = Bs + cur * BN * PITCH + b_frag_off;
+    auto compute = [&](int buf) {
+        const float* a = As + buf * BM * PITCH + a_frag_off;
+        const float* b = Bs + buf * BN * PITCH + b_frag_off;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 fa[TM], fb[TN];
@@ -206,9 +204,43 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
         }
-
-        if (more) store_tile(cur ^ 1);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, NS == 3 ? 1 : 0>;
+    if constexpr (NS == 3) {
+        // register sets alternate; tile t+2 is requested while tile t is computed and tile t+1 moves registers -> LDS
+        const int nt = kt_end - kt_beg;
+        load_tile(kt_beg, I0{});
+        store_tile(0, I0{});
+        load_tile(kt_beg + 1, I1{});
         __syncthreads();
+        int buf = 0;
+        for (int t = 0; t < nt; t += 2) {
+            load_tile(kt_beg + t + 2, I0{});
+            compute(buf);
+            int nb = buf == 2 ? 0 : buf + 1;
+            store_tile(nb, I1{});            // past-the-end tiles are zeros: harmless, keeps the body branch-free
+            __syncthreads();
+            buf = nb;
+            if (t + 1 >= nt) break;
+            load_tile(kt_beg + t + 3, I1{});
+            compute(buf);
+            nb = buf == 2 ? 0 : buf + 1;
+            store_tile(nb, I0{});
+            __syncthreads();
+            buf = nb;
+        }
+    } else {
+        load_tile(kt_beg, I0{});
+        store_tile(0, I0{});
+        __syncthreads();
+        for (int kt = kt_beg; kt < kt_end; ++kt) {
+            const int cur = (kt - kt_beg) & 1;
+            load_tile(kt + 1, I0{});
+            compute(cur);
+            store_tile(cur ^ 1, I0{});
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) --
@@ -428,16 +460,16 @@ int make_plan(const ym_conv_desc* d, Plan* pl) {
     return YM_OK;
 }
 
-template <int BM, int BN, int MODE>
+template <int BM, int BN, int MODE, int NS = 2>
 void launch(const ConvP& p, int grid, hipStream_t st) {
-    const size_t lds = (size_t)2 * (BM + BN) * PITCH * sizeof(float);
+    const size_t lds = (size_t)NS * (BM + BN) * PITCH * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_f32<BM, BN, MODE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_f32<BM, BN, MODE, NS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, MODE>), dim3(grid), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, MODE, NS>), dim3(grid), dim3(256), lds, st, p);
 }
 
 }  // namespace
@@ -471,6 +503,11 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
     p.ws = (float*)workspace;
     p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW;
     p.stride = d->stride; p.pad = d->pad; p.Ho = d->Ho; p.Wo = d->Wo; p.Kpad = d->k_pad;
+    {
+        const unsigned long long ib = (unsigned long long)d->B * d->H * d->W * d->Cin * 4ull, wb = (unsigned long long)d->Cout * d->k_pad * 4ull;
+        YM_REQUIRE(ib < 0xFFFFFFF0ull && wb < 0xFFFFFFF0ull, "conv: input / weight tensor must be < 4 GiB (32-bit buffer offsets)");
+        p.in_bytes = (unsigned)ib; p.w_bytes = (unsigned)wb;
+    }
     p.M = pl.M; p.HoWo = d->Ho * d->Wo; p.nkt = pl.nkt; p.ksplit = pl.ksplit; p.kt_per_split = pl.kt_per_split;
     p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.nseg = d->nseg;
     for (int i = 0; i < 3; ++i) {
@@ -500,12 +537,12 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
         if (pl.bm == 128 && pl.bn == 128) launch<128, 128, 2>(p, grid, st);
         else if (pl.bm == 128 && pl.bn == 64) launch<128, 64, 2>(p, grid, st);
         else if (pl.bm == 64 && pl.bn == 128) launch<64, 128, 2>(p, grid, st);
-        else launch<64, 64, 2>(p, grid, st);
+        else { if (d->stages == 3) launch<64, 64, 2, 3>(p, grid, st); else launch<64, 64, 2>(p, grid, st); }
     } else if (d->Cin == 4) launch<128, 64, 1>(p, grid, st);
     else if (pl.bm == 128 && pl.bn == 128) launch<128, 128, 0>(p, grid, st);
-    else if (pl.bm == 128 && pl.bn == 64) launch<128, 64, 0>(p, grid, st);
-    else if (pl.bm == 64 && pl.bn == 128) launch<64, 128, 0>(p, grid, st);
-    else launch<64, 64, 0>(p, grid, st);
+    else if (pl.bm == 128 && pl.bn == 64) { if (d->stages == 3) launch<128, 64, 0, 3>(p, grid, st); else launch<128, 64, 0>(p, grid, st); }
+    else if (pl.bm == 64 && pl.bn == 128) { if (d->stages == 3) launch<64, 128, 0, 3>(p, grid, st); else launch<64, 128, 0>(p, grid, st); }
+    else { if (d->stages == 3) launch<64, 64, 0, 3>(p, grid, st); else launch<64, 64, 0>(p, grid, st); }
     rc = ym_check_launch("conv_igemm_f32");
     if (rc != YM_OK) return rc;
     if (pl.ksplit > 1) {

@@ -84,6 +84,7 @@ class _Conv:
         self.tile = (0, 0)
         self.ksplit = 0
         self.kwaves = 0
+        self.stages = 0
 
     def refresh(self):
         """(Re)pack parameters from the nn.Modules into the kernel layout, on device."""
@@ -130,6 +131,7 @@ class _Conv:
         d.tile_m, d.tile_n = self.tile
         d.ksplit = self.ksplit
         d.kwaves = self.kwaves
+        d.stages = self.stages
         self.desc = d
         self._bind_params()
         self.out_hw = (ho, wo)
@@ -138,7 +140,8 @@ class _Conv:
         hit = tuned_table().get(self.sig)
         if hit and self.tile == (0, 0) and self.ksplit == 0 and self.kwaves == 0:
             self.tile, self.ksplit, self.kwaves = (hit[0], hit[1]), hit[2], (hit[3] if len(hit) > 3 else 0)
-            d.tile_m, d.tile_n, d.ksplit, d.kwaves = hit[0], hit[1], hit[2], self.kwaves
+            self.stages = hit[4] if len(hit) > 4 else 0
+            d.tile_m, d.tile_n, d.ksplit, d.kwaves, d.stages = hit[0], hit[1], hit[2], self.kwaves, self.stages
         return ho, wo
 
 
@@ -376,6 +379,7 @@ class InferEngine:
             c.desc.tile_m, c.desc.tile_n = c.tile
             c.desc.ksplit = c.ksplit
             c.desc.kwaves = c.kwaves
+            c.desc.stages = c.stages
         self._alloc_workspaces()
         self.graph = None
 
@@ -386,9 +390,9 @@ class InferEngine:
         big_ws = torch.empty(1 << 28, device=self.device, dtype=torch.uint8)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-        def time_cfg(c, tile, ks, kwv=0):
+        def time_cfg(c, tile, ks, kwv=0, stg=0):
             d = c.desc
-            d.tile_m, d.tile_n, d.ksplit, d.kwaves = tile[0], tile[1], ks, kwv
+            d.tile_m, d.tile_n, d.ksplit, d.kwaves, d.stages = tile[0], tile[1], ks, kwv, stg
             need = hip.conv_workspace_bytes(d)
             if need > big_ws.numel():
                 return None
@@ -410,7 +414,7 @@ class InferEngine:
         seen = {}
         for c in self.convs:
             if c.sig in seen:
-                c.tile, c.ksplit, c.kwaves = seen[c.sig]
+                c.tile, c.ksplit, c.kwaves, c.stages = seen[c.sig]
                 continue
             d = c.desc
             M, nkt = d.B * d.Ho * d.Wo, d.k_pad // 32
@@ -422,7 +426,9 @@ class InferEngine:
                 for ks in (1, 2, 3, 4, 6, 8, 12, 16, 24):
                     if ks > 1 and (wgs >= 1024 or ks * 2 > nkt or wgs * ks > 8192):
                         continue
-                    cands.append(((tm, tn), ks, 0))
+                    cands.append(((tm, tn), ks, 0, 2))
+                    if (tm, tn) != (128, 128) and nkt // ks >= 3:
+                        cands.append(((tm, tn), ks, 0, 3))
             if not c.stem:
                 for tm, tn in ((32, 32), (64, 32), (32, 64), (64, 64)):
                     waves = -(-M // tm) * -(-d.Cout // tn)
@@ -433,17 +439,17 @@ class InferEngine:
                             continue
                         if waves * kwv > 65536:
                             continue
-                        cands.append(((tm, tn), 1, kwv))
-            best = (base, (0, 0), 0, 0)
-            for tile, ks, kwv in cands:
-                t = time_cfg(c, tile, ks, kwv)
+                        cands.append(((tm, tn), 1, kwv, 0))
+            best = (base, (0, 0), 0, 0, 0)
+            for tile, ks, kwv, stg in cands:
+                t = time_cfg(c, tile, ks, kwv, stg)
                 if t is not None and t < best[0] * 0.98:
-                    best = (t, tile, ks, kwv)
-            c.tile, c.ksplit, c.kwaves = best[1], best[2], best[3]
-            seen[c.sig] = (c.tile, c.ksplit, c.kwaves)
-            results[c.sig] = [best[1][0], best[1][1], best[2], best[3], round(best[0], 2), round(base, 2)]
+                    best = (t, tile, ks, kwv, stg)
+            c.tile, c.ksplit, c.kwaves, c.stages = best[1], best[2], best[3], best[4]
+            seen[c.sig] = (c.tile, c.ksplit, c.kwaves, c.stages)
+            results[c.sig] = [best[1][0], best[1][1], best[2], best[3], best[4], round(best[0], 2), round(base, 2)]
             if verbose:
-                print(f'{c.sig:44s} default {base:8.1f} us -> {best[1]} ks={best[2]} kw={best[3]} {best[0]:8.1f} us', flush=True)
+                print(f'{c.sig:44s} default {base:8.1f} us -> {best[1]} ks={best[2]} kw={best[3]} st={best[4]} {best[0]:8.1f} us', flush=True)
         del big_ws
         self.retune()
         return results

@@ -11,7 +11,7 @@ import os
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, 'libyolact_hip.so')
+LIB_PATH = os.environ.get('YM_LIB_PATH') or os.path.join(_PKG, 'libyolact_hip.so')   # override: debug builds only
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_GELU = 0, 1, 2, 3
 
@@ -42,7 +42,7 @@ class ConvDesc(ctypes.Structure):
                 ('Wo', ctypes.c_int32), ('k_pad', ctypes.c_int32), ('nseg', ctypes.c_int32),
                 ('seg', ConvSeg * 3), ('tile_m', ctypes.c_int32), ('tile_n', ctypes.c_int32),
                 ('ksplit', ctypes.c_int32), ('kwaves', ctypes.c_int32), ('transposed', ctypes.c_int32),
-                ('reserved', ctypes.c_int32), ('bn_sum', ctypes.c_void_p), ('bn_sumsq', ctypes.c_void_p)]
+                ('stages', ctypes.c_int32), ('bn_sum', ctypes.c_void_p), ('bn_sumsq', ctypes.c_void_p)]
 
 
 class WgradDesc(ctypes.Structure):

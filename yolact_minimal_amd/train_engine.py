@@ -51,16 +51,18 @@ def _configure_conv(d, key):
     if hit is None and _TUNING:
         M, nkt = d.B * d.Ho * d.Wo, d.k_pad // 32
         big = scratch(torch.device('cuda', torch.cuda.current_device()), 1 << 28)
-        cands = [((0, 0), 0, 0)]
+        cands = [((0, 0), 0, 0, 0)]
         for tm, tn in ((128, 128), (128, 64), (64, 128), (64, 64)):
             wgs = -(-M // tm) * -(-d.Cout // tn)
             for ks in (1, 2, 3, 4, 6, 8, 12, 16):
                 if ks > 1 and (wgs >= 1024 or ks * 2 > nkt or wgs * ks > 8192):
                     continue
-                cands.append(((tm, tn), ks, 0))
-        best = (1e30, (0, 0), 0, 0)
-        for tile, ks, kwv in cands:
-            d.tile_m, d.tile_n, d.ksplit, d.kwaves = tile[0], tile[1], ks, kwv
+                cands.append(((tm, tn), ks, 0, 2))
+                if (tm, tn) == (64, 64) and nkt // ks >= 3:
+                    cands.append(((tm, tn), ks, 0, 3))
+        best = (1e30, (0, 0), 0, 0, 0)
+        for tile, ks, kwv, stg in cands:
+            d.tile_m, d.tile_n, d.ksplit, d.kwaves, d.stages = tile[0], tile[1], ks, kwv, stg
             if hip.conv_workspace_bytes(d) > big.numel():
                 continue
             try:
@@ -68,13 +70,14 @@ def _configure_conv(d, key):
             except RuntimeError:
                 continue
             if t < best[0] * 0.98:
-                best = (t, tile, ks, kwv)
-        hit = [best[1][0], best[1][1], best[2], best[3]]
+                best = (t, tile, ks, kwv, stg)
+        hit = [best[1][0], best[1][1], best[2], best[3], best[4]]
         _table()[key] = hit
         _new_entries[key] = hit
     if hit is not None:
         d.tile_m, d.tile_n, d.ksplit = hit[0], hit[1], hit[2]
         d.kwaves = hit[3] if len(hit) > 3 else 0
+        d.stages = hit[4] if len(hit) > 4 else 0
 
 
 def _configure_wgrad(d, key):
