@@ -243,8 +243,15 @@ def main():
         t_fwd = timed(fw, args.steps, 2, lambda: None) / args.steps
         flops, conv_secs, launches, layers = conv_roofline(fw.engine, fw.img)
         achieved = flops / conv_secs / 1e12
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(REPO, 'profiles', 'r01_pmc_hbm_infer_bs1_res101.json')
+        if args.cfg == 'res101_coco' and args.batch == 1 and os.path.exists(pmc_path):
+            # HBM-side bytes per conv launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2
+            # gfx950 correction + WRITE_SIZE); not re-measured live (bench.py cannot wrap itself in rocprofv3)
+            traffic = round(json.load(open(pmc_path))['conv_kernels']['traffic_bytes_per_launch'])
+            traffic_src = 'profiles/r01_pmc_hbm_infer_bs1_res101.json'
         roofline = dict(bound='mfma', achieved=round(achieved, 2), peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-                        frac=round(achieved / F32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                        frac=round(achieved / F32_MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
                         kernel='conv_igemm_f32 (all instantiations)', launches_per_step=launches,
                         flops_per_launch=round(flops / launches), avg_launch_us=round(conv_secs / launches * 1e6, 2),
                         conv_ms_per_step=round(conv_secs * 1e3, 3))
