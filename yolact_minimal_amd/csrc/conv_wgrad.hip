@@ -25,7 +25,16 @@ struct WgradP {
     float* ws;          // [msplit][Cout][Ktot]
     int B, H, W, Cinp, Cout, KH, KW, stride, pad, Ho, Wo;
     int M, HoWo, Ktot, tiles_n, tiles_k, msplit, m_per_split;
+    unsigned x_bytes, dy_bytes;
+    unsigned mg_howo, sh_howo, mg_wo, sh_wo;   // division by invariant integers (q = (mulhi(m, mg) + m) >> sh)
 };
+
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0xFFFFFFF0u;
+__device__ __forceinline__ f32x4 buf_ld16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+__device__ __forceinline__ unsigned fastdiv(unsigned m, unsigned mg, unsigned sh) { return (__umulhi(m, mg) + m) >> sh; }
 
 __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -50,23 +59,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradP p) {
     const int tap = k_ok ? kk / p.Cinp : 0, ci = kk - tap * p.Cinp;
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
 
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
     f32x4 ry[4], rx[4];
+    // branch-free: raw buffer loads return zeros beyond the descriptor (rows past the slice, padding taps, tile tails),
+    // and the prefetch is issued unconditionally so the compiler keeps counted vmcnt waits.
     auto load = [&](int mt) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = mt + r0 + 8 * i;
-            ry[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            rx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (m < m_end) {
-                if (n_ok) ry[i] = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.Cout + ncol);
-                if (k_ok) {
-                    const int b = m / p.HoWo, rem = m - b * p.HoWo;
-                    const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
-                    const int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
-                    if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-                        rx[i] = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(b * p.H + ih) * p.W + iw) * p.Cinp + ci);
-                }
-            }
+            const bool live = m < m_end;
+            ry[i] = buf_ld16(rs_y, (live && n_ok) ? (unsigned)((m * p.Cout + ncol) * 4) : OOB);
+            const unsigned b = fastdiv((unsigned)m, p.mg_howo, p.sh_howo);
+            const unsigned rem = (unsigned)m - b * p.HoWo;
+            const unsigned oh = fastdiv(rem, p.mg_wo, p.sh_wo);
+            const unsigned ow = rem - oh * p.Wo;
+            const int ih = (int)oh * p.stride - p.pad + kh, iw = (int)ow * p.stride - p.pad + kw;
+            const bool ok = live && k_ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            rx[i] = buf_ld16(rs_x, ok ? (unsigned)(((((int)b * p.H + ih) * p.W + iw) * p.Cinp + ci) * 4) : OOB);
         }
     };
     auto store = [&](int buf) {
@@ -86,12 +96,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradP p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int fr = lane & 31, khalf = lane >> 5;
-    if (m_beg < m_end) { load(m_beg); store(0); }
+    load(m_beg);
+    store(0);
     __syncthreads();
     int cur = 0;
     for (int mt = m_beg; mt < m_end; mt += TBM) {
-        const bool more = mt + TBM < m_end;
-        if (more) load(mt + TBM);
+        load(mt + TBM);
         const float* ya = Ys + cur * TBM * LP + wn * 64 + fr;
         const float* xb = Xs + cur * TBM * LP + wk * 64 + fr;
 #pragma unroll
@@ -104,7 +114,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradP p) {
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
-        if (more) store(cur ^ 1);
+        store(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
@@ -142,6 +152,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_unpack(const float* __restri
 }
 
 struct WPlan { int M, Ktot, tiles_n, tiles_k, msplit, m_per_split; };
+
+void fastdiv_make(unsigned d, unsigned* mg, unsigned* sh) {
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    *sh = s;
+    *mg = (unsigned)(((1ull << 32) * ((1ull << s) - d)) / d + 1);
+}
 
 int wplan(const ym_wgrad_desc* d, WPlan* pl) {
     YM_REQUIRE(d && d->x && d->dy && d->dw, "wgrad: null pointer");
@@ -192,6 +209,13 @@ extern "C" int ym_conv2d_wgrad(const ym_wgrad_desc* d, void* workspace, size_t w
     p.stride = d->stride; p.pad = d->pad; p.Ho = d->Ho; p.Wo = d->Wo;
     p.M = pl.M; p.HoWo = d->Ho * d->Wo; p.Ktot = pl.Ktot; p.tiles_n = pl.tiles_n; p.tiles_k = pl.tiles_k;
     p.msplit = pl.msplit; p.m_per_split = pl.m_per_split;
+    {
+        const unsigned long long xb = (unsigned long long)d->B * d->H * d->W * d->Cin * 4ull, yb = (unsigned long long)pl.M * d->Cout * 4ull;
+        YM_REQUIRE(xb < 0xFFFFFFF0ull && yb < 0xFFFFFFF0ull, "wgrad: x / dy must be < 4 GiB (32-bit buffer offsets)");
+        p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)yb;
+        fastdiv_make((unsigned)p.HoWo, &p.mg_howo, &p.sh_howo);
+        fastdiv_make((unsigned)d->Wo, &p.mg_wo, &p.sh_wo);
+    }
     hipStream_t st = (hipStream_t)s;
     const size_t lds = (size_t)4 * TBM * LP * sizeof(float);
     static bool attr_set = false;

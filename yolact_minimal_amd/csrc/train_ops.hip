@@ -165,10 +165,12 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        const double* __restrict__ dbeta, const double* __restrict__ dgamma,
                                                        int relu, float* __restrict__ dy, float* __restrict__ dres, long long M,
-                                                       int C) {
+                                                       int C, float* __restrict__ dgamma_f, float* __restrict__ dbeta_f) {
     const int C4 = C >> 2;
     const size_t total = (size_t)M * C4;
     const float invM = 1.f / (float)M;
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < C; c += 256) { dgamma_f[c] = (float)dgamma[c]; dbeta_f[c] = (float)dbeta[c]; }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int cq = (int)(i % C4);
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + cq * 4), is = *reinterpret_cast<const f32x4*>(invstd + cq * 4);
@@ -348,7 +350,7 @@ extern "C" int ym_bn_train_fwd(const float* y, int64_t M, int C, const float* ga
     (void)hipMemsetAsync(sum, 0, (size_t)C * 16, st);
     const int CQ = (C / 4) < 256 ? (C / 4) : 256, RL = 256 / CQ;
     int grid = (int)((M + (long long)RL * 16 - 1) / ((long long)RL * 16));
-    if (grid > 2048) grid = 2048;
+    if (grid > 512) grid = 512;       // every block ends with 2*C contended fp64 atomics: keep the block count low
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(k_col_reduce<0>, dim3(grid), dim3(256), 0, st, y, nullptr, nullptr, nullptr, nullptr, (long long)M, C, 0,
                        0, sum, sumsq);
@@ -387,14 +389,12 @@ extern "C" int ym_bn_train_bwd(const float* dout, const float* out, const float*
     (void)hipMemsetAsync(db, 0, (size_t)C * 16, st);
     const int CQ = (C / 4) < 256 ? (C / 4) : 256, RL = 256 / CQ;
     int grid = (int)((M + (long long)RL * 16 - 1) / ((long long)RL * 16));
-    if (grid > 2048) grid = 2048;
+    if (grid > 512) grid = 512;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(k_col_reduce<1>, dim3(grid), dim3(256), 0, st, dout, out, y, save_mean, save_invstd, (long long)M, C,
                        relu, 0, db, dg);
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid((size_t)M * (C / 4))), dim3(256), 0, st, dout, out, y, save_mean,
-                       save_invstd, gamma, db, dg, relu, dy, dres, (long long)M, C);
-    hipLaunchKernelGGL(k_f64_to_f32, dim3(ym_cdiv(C, 256)), dim3(256), 0, st, db, dbeta, C);
-    hipLaunchKernelGGL(k_f64_to_f32, dim3(ym_cdiv(C, 256)), dim3(256), 0, st, dg, dgamma, C);
+                       save_invstd, gamma, db, dg, relu, dy, dres, (long long)M, C, dgamma, dbeta);
     return ym_check_launch("bn_train_bwd");
 }
 

@@ -179,10 +179,21 @@ def _conv_dgrad(dz, weight, cout_pad, x_shape, stride, pad):
     return dx
 
 
-def _conv_wgrad(x, dz, weight_shape, stride, pad):
+def _grad_slot(param, shape):
+    """Gradient destination: the parameter's slice of the optimizer's flat gradient buffer when the trainer installed
+    one (`FlatSGD` sets `param._ym_grad_slot`), so autograd adopts the view and no gather copy is needed; else fresh."""
+    slot = getattr(param, '_ym_grad_slot', None) if param is not None else None
+    if slot is not None and getattr(param, '_ym_slot_free', False):
+        param._ym_slot_free = False           # a second use in the same step must accumulate into a fresh tensor
+        return slot
+    return torch.empty(shape, device=param.device if param is not None else None, dtype=torch.float32)
+
+
+def _conv_wgrad(x, dz, weight_shape, stride, pad, weight_param=None):
     cout, cin, kh, kw = weight_shape
     b, h, w, cin_p = x.shape
-    dw = torch.empty(cout, cin, kh, kw, device=x.device, dtype=torch.float32)
+    dw = _grad_slot(weight_param, (cout, cin, kh, kw)) if weight_param is not None else \
+        torch.empty(cout, cin, kh, kw, device=x.device, dtype=torch.float32)
     d = WgradDesc()
     d.x, d.dy, d.dw = x.data_ptr(), dz.data_ptr(), dw.data_ptr()
     d.B, d.H, d.W, d.Cin, d.Cin_real, d.Cout, d.Cout_real = b, h, w, cin_p, cin, dz.shape[3], cout
@@ -228,7 +239,7 @@ class ConvBias(torch.autograd.Function):
                                             hip.ptr(dz) if act != ACT_NONE else None, hip.ptr(dbias), ctypes.c_void_p(ws.data_ptr()),
                                             ws.numel(), hip.stream_ptr()), 'ym_act_bias_bwd')
         dx = _conv_dgrad(dz, weight, cout_pad, x.shape, stride, pad) if ctx.needs_input_grad[0] else None
-        dw = _conv_wgrad(x, dz, weight.shape, stride, pad)
+        dw = _conv_wgrad(x, dz, weight.shape, stride, pad, weight)
         if dbias is not None and cout_pad != weight.shape[0]:
             dbias = dbias[:weight.shape[0]].contiguous()
         return dx, dw, dbias, None, None, None, None, (dz if has_res else None)
@@ -282,7 +293,7 @@ class ConvBn(torch.autograd.Function):
         if need_dx and cout % 32 != 0:
             raise RuntimeError('ConvBn dgrad needs Cout % 32 == 0')
         dx = _conv_dgrad(dy, weight, cout, x.shape, stride, pad) if need_dx else None
-        dw = _conv_wgrad(x, dy, weight.shape, stride, pad)
+        dw = _conv_wgrad(x, dy, weight.shape, stride, pad, weight)
         return dx, dw, dgamma, dbeta, None, None, dres, None, None, None, None, None
 
 

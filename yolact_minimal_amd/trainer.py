@@ -76,18 +76,26 @@ class FlatSGD:
             off += k
         self.buf = torch.zeros_like(self.flat)
         self.grad = torch.empty_like(self.flat)
+        off = 0
+        for p in self.params:                       # the HIP wgrad kernels write straight into these views
+            k = p.numel()
+            p._ym_grad_slot = self.grad[off:off + k].view_as(p.data)
+            p._ym_slot_free = True
+            off += k
         self.steps = 0
 
     def zero_grad(self):
         for p in self.params:
             p.grad = None
+            p._ym_slot_free = True
 
     def step(self):
-        off = 0
-        for p in self.params:                       # gather gradients (device-to-device copies)
-            k = p.numel()
-            self.grad[off:off + k].copy_(p.grad.reshape(-1))
-            off += k
+        for p in self.params:                       # gather only gradients that did not land in their slot
+            g = p.grad
+            if g is None:
+                p._ym_grad_slot.zero_()
+            elif g.data_ptr() != p._ym_grad_slot.data_ptr():
+                p._ym_grad_slot.copy_(g)
         hip.check(hip.lib().ym_sgd_step(hip.ptr(self.flat), hip.ptr(self.grad), hip.ptr(self.buf), self.flat.numel(),
                                         float(self.lr), float(self.momentum), float(self.weight_decay),
                                         int(self.steps == 0), hip.stream_ptr()), 'ym_sgd_step')
