@@ -175,6 +175,14 @@ int ym_patch_merge_layernorm(const float* x, int B, int H, int W, int C, const f
 int ym_swin_window_attention(const float* qkv, const float* qkv_bias, const float* rel_bias_table, int B, int H, int W, int C,
                              int heads, int window, int shift, float* out, ym_stream_t s);
 
+/* ---- pre-processing (SURVEY.md §8f "next" row 1) ------------------------------------------------------------- */
+
+/* `val_aug(img, val_size)` (utils/augmentations.py:219-227 = pad_to_square :138-165 + cv2.resize :188 +
+ * normalize_and_toRGB :212-216) on the device: HWC BGR image (uint8 if is_uint8 else float32, DEVICE pointer) ->
+ * out [3][S][S] float32 RGB, (x - mean) / std.  mean_bgr / std_bgr are HOST pointers to 3 floats (config.py:66-67). */
+int ym_val_preprocess(const void* img_hwc_bgr, int is_uint8, int H, int W, int S, const float* mean_bgr,
+                      const float* std_bgr, float* out_chw_rgb, ym_stream_t s);
+
 /* ---- detection post-processing (utils/output_utils.py) ---------------------------------------------- */
 
 typedef struct {

@@ -638,3 +638,23 @@ def features_any(img, sd):
 def forward_eval_any(img, sd):
     conf, box, coef, proto = features_any(img, sd)
     return F.softmax(conf, -1), box, coef, proto
+
+
+# ------------------------------------------------------------------------------------------------
+# pre-processing (utils/augmentations.py:219-227)
+# ------------------------------------------------------------------------------------------------
+def val_aug(img_hwc_bgr, val_size, mean=(103.94, 116.78, 123.68), std=(57.38, 57.12, 58.40)):
+    """pad_to_square (:138-165, fill = norm_mean, image at the top-left) -> cv2.resize to val_size (restated as bilinear
+    align_corners=False: cv2 is not importable here — PARITY UNPINNED by cv2) -> (x-mean)/std -> BGR->RGB -> CHW."""
+    img = img_hwc_bgr.float()
+    h, w, _ = img.shape
+    mean_t, std_t = torch.tensor(mean), torch.tensor(std)
+    if h != w:
+        p = max(h, w)
+        pad = mean_t.view(1, 1, 3).expand(p, p, 3).clone()
+        pad[:h, :w] = img
+        img = pad
+    x = img.permute(2, 0, 1).unsqueeze(0)
+    x = F.interpolate(x, (val_size, val_size), mode='bilinear', align_corners=False).squeeze(0)
+    x = (x - mean_t.view(3, 1, 1)) / std_t.view(3, 1, 1)
+    return x[[2, 1, 0]].contiguous()

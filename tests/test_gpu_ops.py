@@ -254,3 +254,15 @@ def test_fold_bn_and_pack():
     want = torch.zeros(5, 7, 7, 4)
     want[..., :3] = w.permute(0, 2, 3, 1)
     assert torch.equal(p[:, :196], want.reshape(5, 196)) and float(p[:, 196:].abs().sum()) == 0
+
+
+@pytest.mark.parametrize('h,w,dtype', [(480, 640, torch.uint8), (640, 427, torch.float32), (544, 544, torch.uint8), (37, 91, torch.float32)])
+def test_val_aug_preprocess(h, w, dtype):
+    from oracle import yolact_ref as R
+    from yolact_minimal_amd.utils.augmentations import val_aug
+    g = torch.Generator().manual_seed(h + w)
+    img = torch.randint(0, 256, (h, w, 3), generator=g).to(dtype)
+    got = val_aug(img.to(_dev()), 544)
+    want = R.val_aug(img, 544)
+    assert got.shape == (3, 544, 544)
+    torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=2e-5)

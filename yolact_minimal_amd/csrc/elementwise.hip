@@ -216,3 +216,51 @@ extern "C" int ym_softmax_rows(const float* in, float* out, int64_t rows, int C,
     hipLaunchKernelGGL(k_softmax_rows, dim3(grid), dim3(256), 0, (hipStream_t)s, in, out, (long long)rows, C);
     return ym_check_launch("softmax_rows");
 }
+
+// ---- val_aug on the GPU (reference utils/augmentations.py:138-165,168-189,212-227) ----------
+// HWC BGR image (uint8 or float32) -> pad to a square with norm_mean (top-left placement) -> bilinear resize to S x S
+// (cv2.resize INTER_LINEAR on float32 == half-pixel centres, source index clamped at 0, i1 = min(i0+1, n-1)) ->
+// (x - mean) / std -> BGR->RGB -> CHW.  The padded square is never materialised: a source pixel outside the image
+// simply evaluates to norm_mean.  One thread per output pixel, 3 channels.
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void k_val_preprocess(const T* __restrict__ img, int H, int W, int S, f32x4 mean, f32x4 stdv,
+                                                         float* __restrict__ out) {
+    const int P = H > W ? H : W;
+    const float scale = (float)P / (float)S;
+    const int total = S * S;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int oy = i / S, ox = i - oy * S;
+        float sy = scale * ((float)oy + 0.5f) - 0.5f, sx = scale * ((float)ox + 0.5f) - 0.5f;
+        if (sy < 0.f) sy = 0.f;
+        if (sx < 0.f) sx = 0.f;
+        int y0 = (int)sy, x0 = (int)sx;
+        if (y0 > P - 1) y0 = P - 1;
+        if (x0 > P - 1) x0 = P - 1;
+        const int y1 = y0 + (y0 < P - 1 ? 1 : 0), x1 = x0 + (x0 < P - 1 ? 1 : 0);
+        const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+        auto px = [&](int y, int x, int c) -> float {
+            return (y < H && x < W) ? (float)img[((size_t)y * W + x) * 3 + c] : mean[c];
+        };
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = hy * (hx * px(y0, x0, c) + lx * px(y0, x1, c)) + ly * (hx * px(y1, x0, c) + lx * px(y1, x1, c));
+            out[(size_t)(2 - c) * total + i] = (v - mean[c]) / stdv[c];          // BGR -> RGB plane order
+        }
+    }
+}
+}  // namespace
+
+extern "C" int ym_val_preprocess(const void* img_hwc_bgr, int is_uint8, int H, int W, int S, const float* mean_bgr,
+                                 const float* std_bgr, float* out_chw_rgb, ym_stream_t s) {
+    YM_REQUIRE(img_hwc_bgr && out_chw_rgb && mean_bgr && std_bgr && H > 0 && W > 0 && S > 0, "val_preprocess: bad args");
+    const f32x4 mean = {mean_bgr[0], mean_bgr[1], mean_bgr[2], 0.f}, stdv = {std_bgr[0], std_bgr[1], std_bgr[2], 1.f};
+    const int grid = (S * S + 255) / 256;
+    if (is_uint8)
+        hipLaunchKernelGGL(k_val_preprocess<unsigned char>, dim3(grid), dim3(256), 0, (hipStream_t)s,
+                           (const unsigned char*)img_hwc_bgr, H, W, S, mean, stdv, out_chw_rgb);
+    else
+        hipLaunchKernelGGL(k_val_preprocess<float>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const float*)img_hwc_bgr, H, W, S,
+                           mean, stdv, out_chw_rgb);
+    return ym_check_launch("val_preprocess");
+}

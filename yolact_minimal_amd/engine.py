@@ -524,10 +524,18 @@ class InferEngine:
                 self._launch_all(self.static_img)          # warm-up outside capture
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._launch_all(self.static_img)
-            self.graph = g
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._launch_all(self.static_img)
+                self.graph = g
+            except Exception as exc:                       # still the HIP kernels, just launched one by one
+                import warnings
+                warnings.warn(f'hipGraph capture failed ({exc!r}); replaying the plan eagerly')
+                self.use_graph = False
+                torch.cuda.synchronize()
+                self._launch_all(img)
+                return
         self.static_img.copy_(img)
         self.graph.replay()
 

@@ -23,7 +23,7 @@ ABI_SYMBOLS = (
     'ym_greedy_nms_workspace_bytes', 'ym_greedy_nms', 'ym_mask_assemble', 'ym_mask_resize_binarize',
     'ym_boxes_to_pixels',
     'ym_pack_conv_weight_dgrad', 'ym_conv2d_wgrad_workspace_bytes', 'ym_conv2d_wgrad', 'ym_bn_train_fwd',
-    'ym_layernorm', 'ym_patch_merge_layernorm', 'ym_swin_window_attention',
+    'ym_val_preprocess', 'ym_layernorm', 'ym_patch_merge_layernorm', 'ym_swin_window_attention',
     'ym_bn_train_bwd', 'ym_act_bias_bwd', 'ym_conv2d_fuses_bn_stats', 'ym_bn_train_fwd_stats', 'ym_maxpool3x3s2_bwd', 'ym_bilinear2x_bwd', 'ym_sgd_step',
 )
 
@@ -99,6 +99,7 @@ def lib():
         L.ym_conv2d_wgrad_workspace_bytes.restype = sz
         L.ym_conv2d_wgrad.argtypes = [ctypes.POINTER(WgradDesc), vp, sz, vp]
         L.ym_bn_train_fwd.argtypes = [vp, i64, i32, vp, vp, f32, f32, vp, vp, vp, i32, vp, vp, vp, vp, sz, vp]
+        L.ym_val_preprocess.argtypes = [vp, i32, i32, i32, i32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), vp, vp]
         L.ym_layernorm.argtypes = [vp, vp, vp, f32, vp, i64, i32, vp]
         L.ym_patch_merge_layernorm.argtypes = [vp, i32, i32, i32, i32, vp, vp, f32, vp, vp]
         L.ym_swin_window_attention.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
