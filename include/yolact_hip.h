@@ -139,6 +139,18 @@ int ym_bn_train_bwd(const float* dout, const float* out, const float* y, int64_t
 int ym_act_bias_bwd(const float* dy, const float* y, int64_t M, int C, int act, float* dz, float* dbias, void* workspace,
                     size_t workspace_bytes, ym_stream_t s);
 
+/* lincomb_mask_loss (modules/yolact.py:241-291) for ONE image, forward and backward in one pass on the f32 MFMA:
+ *   loss += sum_p (wscale/area_p) * sum_pix BCE(crop_p(sigmoid(proto[pix] . coef_p)), gt_masks_ds[gt_idx[p]][pix])
+ * and, with gscale = d(total)/d(loss_i) (= mask_alpha/Hp/Wp/total_pos), dproto [Hp*Wp][32] (overwritten) and
+ * dcoef_full[anchor_idx[p]][32] (rows of the positives overwritten).  proto [Hp*Wp][32], coef_pos [n][32], box_pos [n][4]
+ * (matched gt boxes: crop window, padding 1, and area), gt_masks_ds [n_gt][Hp*Wp] in {0,1}, n <= 128.
+ * loss_accum is a device fp64 scalar the caller zeroes once per batch. */
+size_t ym_mask_loss_workspace_bytes(void);
+int ym_mask_loss_fwd_bwd(const float* proto, const float* coef_pos, const float* box_pos, const int32_t* gt_idx,
+                         const float* gt_masks_ds, const int64_t* anchor_idx, int n, int Hp, int Wp, float wscale, float gscale,
+                         double* loss_accum, float* dproto, float* dcoef_full, void* workspace, size_t workspace_bytes,
+                         ym_stream_t s);
+
 int ym_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, ym_stream_t s);
 int ym_bilinear2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, int align_corners, ym_stream_t s);
 

@@ -267,3 +267,31 @@ def test_bench_under_torchrun_with_rccl_single_rank(tmp_path):
     d = json.loads(line)
     assert d['n_gpus'] == 1 and d['value'] > 0 and d['extra']['train']['finite'] and d['extra']['train']['img_s'] > 0
     assert 'ddp' in d['extra']['train']['parallelism']
+
+
+def test_mask_loss_kernel_matches_oracle_autograd():
+    """`ym_mask_loss_fwd_bwd` (GEMM + sigmoid + crop + BCE + both gradient GEMMs) vs fp64 autograd of the oracle's mask_loss."""
+    from yolact_minimal_amd.loss import lincomb_mask_loss
+    g = torch.Generator().manual_seed(11)
+    b, hp, n_anchor, size = 2, 34, 300, 136
+    proto = torch.relu(torch.randn(b, hp, hp, 32, generator=g))
+    coef = torch.tanh(torch.randn(b, n_anchor, 32, generator=g))
+    boxes, masks = R.synth_targets(b, size, n_gt=3, seed=4)
+    pos = torch.zeros(b, n_anchor, dtype=torch.bool)
+    anchor_gt = torch.zeros(b, n_anchor, dtype=torch.int64)
+    anchor_box = torch.zeros(b, n_anchor, 4)
+    for i in range(b):
+        sel = torch.randperm(n_anchor, generator=g)[:37 + 20 * i]
+        pos[i, sel] = True
+        anchor_gt[i, sel] = torch.randint(0, 3, (sel.numel(),), generator=g)
+        anchor_box[i] = boxes[i][anchor_gt[i], :4]
+    cfg = build_cfg('res50_coco', 'train', 128)
+    pr, cf = proto.double().requires_grad_(), coef.double().requires_grad_()
+    ref = R.mask_loss(pos, anchor_gt, cf, pr, [m.double() for m in masks], anchor_box.double())
+    ref.backward()
+    pg, cg = proto.to(DEV).requires_grad_(), coef.to(DEV).requires_grad_()
+    got = lincomb_mask_loss(cfg, pos.to(DEV), anchor_gt.to(DEV), cg, pg, [m.to(DEV) for m in masks], anchor_box.to(DEV))
+    (got * 1.7).backward()
+    np.testing.assert_allclose(float(got.detach()), float(ref.detach()), rtol=2e-5)
+    torch.testing.assert_close(pg.grad.cpu().double() / 1.7, pr.grad, rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(cg.grad.cpu().double() / 1.7, cf.grad, rtol=1e-4, atol=1e-7)

@@ -1,0 +1,216 @@
+// lincomb_mask_loss (reference modules/yolact.py:241-291) forward AND backward for one image, on the f32 MFMA pipe.
+//
+//   loss_i = sum_p  w_p * sum_pix BCE( crop_p( sigmoid(proto[pix] . coef[p]) ), gt_p[pix] )      w_p = scale / area_p
+//   dproto[pix][k] = sum_p g[p][pix] * coef[p][k]        dcoef[p][k] = sum_pix g[p][pix] * proto[pix][k]
+//   g = dL/dz = inside * (m - t) / max(m(1-m), 1e-12) * s(1-s) * w_p * gscale        (torch's BCE backward, m = inside*s)
+//
+// One wave per 32-pixel tile (grid-stride).  Z^T = coef x proto^T gives D[i = p][j = pix]: lane = pixel, the 16 registers
+// = 16 positives -> loss terms + G in registers, and (as in the attention kernel) G is already the A operand of
+// dproto = G^T-layout x coef.  For dcoef the reduction runs over pixels, so the same operand registers are multiplied the
+// other way round (Z = proto x coef^T: lane = positive, registers = pixels), G' feeds dcoef[i = p][j = k] += G' x proto,
+// accumulated in registers over all of the wave's pixel tiles; per-wave partials go to a workspace and are summed in
+// fixed order (deterministic, no float atomics).  K = 32 lives in registers: no LDS except 3 KB of per-positive
+// metadata.  Algorithmic bytes: P*32*4 (proto) + P*32*4 (dproto) + n_gt*P*4 (gt masks): HBM/L2-bound, ~5 MB per image.
+#include "ym_common.h"
+
+namespace {
+
+constexpr int MAXP = 128;
+
+struct MLP {
+    const float* proto;     // [P][32]
+    const float* coef;      // [n][32]
+    const float* boxes;     // [n][4]  gt boxes of the positives (crop window + area)
+    const int* gt_idx;      // [n]     which downsampled gt mask each positive is trained against
+    const float* dsmask;    // [n_gt][P]  {0,1}
+    float* dproto;          // [P][32]
+    float* part;            // [nwaves][MAXP][32] per-wave dcoef partials
+    double* loss;           // accumulated (atomicAdd)
+    int n, Hp, Wp, P, ntiles;
+    float wscale;           // old_num_pos / num_pos (sub-sampling correction) — multiplies 1/area
+    float gscale;           // d(total loss)/d(loss_i) = mask_alpha / Hp / Wp / total_pos
+};
+
+__device__ __forceinline__ void crop_span(float a, float b, float size, float& lo, float& hi) {
+    a = a * size; b = b * size;
+    lo = fminf(a, b); hi = fmaxf(a, b);
+    lo = lo - 1.f; lo = lo < 0.f ? 0.f : lo;
+    hi = hi + 1.f; hi = hi > size ? size : hi;
+}
+
+__global__ __launch_bounds__(256) void k_mask_loss(const MLP p) {
+    __shared__ float s_win[MAXP][4];     // x1, x2, y1, y2
+    __shared__ float s_w[MAXP];          // wscale / area
+    __shared__ int s_gt[MAXP];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < MAXP; i += 256) {
+        if (i < p.n) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p.boxes + (size_t)i * 4);
+            float x1, x2, y1, y2;
+            crop_span(b[0], b[2], (float)p.Wp, x1, x2);
+            crop_span(b[1], b[3], (float)p.Hp, y1, y2);
+            s_win[i][0] = x1; s_win[i][1] = x2; s_win[i][2] = y1; s_win[i][3] = y2;
+            s_w[i] = p.wscale / ((b[2] - b[0]) * (b[3] - b[1]));
+            s_gt[i] = p.gt_idx[i];
+        } else {
+            s_win[i][0] = 1.f; s_win[i][1] = 0.f; s_win[i][2] = 1.f; s_win[i][3] = 0.f;   // empty window
+            s_w[i] = 0.f; s_gt[i] = 0;
+        }
+    }
+    __syncthreads();
+    const int row = lane & 31, h = lane >> 5;
+    const int nptile = (p.n + 31) / 32;
+    const int wave_id = blockIdx.x * 4 + wv, nwaves = gridDim.x * 4;
+
+    f32x16 dc[4];                       // dcoef partial [p tile][D layout: i = p, j = k]
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dc[t][r] = 0.f;
+    double loss_acc = 0.0;
+
+    for (int tile = wave_id; tile < p.ntiles; tile += nwaves) {
+        const int pix = tile * 32 + row;
+        const bool pix_ok = pix < p.P;
+        f32x4 pf[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            pf[g] = pix_ok ? *reinterpret_cast<const f32x4*>(p.proto + (size_t)pix * 32 + g * 8 + h * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const int py = pix / p.Wp, px = pix - py * p.Wp;
+        const float fx = (float)px, fy = (float)py;
+        f32x16 dp;                       // dproto tile: D[i = pix][j = k]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            if (pt >= nptile) break;                                  // wave-uniform
+            const int pp = pt * 32 + row;                              // this lane's positive (operand row / orientation-2 column)
+            f32x4 cf[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                cf[g] = pp < p.n ? *reinterpret_cast<const f32x4*>(p.coef + (size_t)pp * 32 + g * 8 + h * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+
+            // ---- orientation 1: Z^T[i = positive][j = pixel]: loss + G (lane = pixel) -> dproto ------------------------
+            f32x16 zt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zt[r] = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) zt = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[g][s], pf[g][s], zt, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = pt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;   // positive index of this register
+                float gval = 0.f;
+                if (q < p.n && pix_ok) {
+                    const float sg = 1.f / (1.f + expf(-zt[r]));
+                    const bool inside = fx >= s_win[q][0] && fx < s_win[q][1] && fy >= s_win[q][2] && fy < s_win[q][3];
+                    const float m = inside ? sg : 0.f;
+                    const float t = p.dsmask[(size_t)s_gt[q] * p.P + pix];
+                    const float lm = fmaxf(logf(m), -100.f), l1m = fmaxf(logf(1.f - m), -100.f);
+                    loss_acc += (double)(-(t * lm + (1.f - t) * l1m) * s_w[q]);
+                    if (inside) gval = (m - t) / fmaxf(m * (1.f - m), 1e-12f) * (sg * (1.f - sg)) * s_w[q] * p.gscale;
+                }
+                zt[r] = gval;
+            }
+            // dproto[pix][k] += sum_q G[q][pix] * coef[q][k]: register r of zt is A[i = pix][k-pair member = positive (r, h)]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = pt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float cq = q < p.n ? p.coef[(size_t)q * 32 + row] : 0.f;
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(zt[r], cq, dp, 0, 0, 0);
+            }
+
+            // ---- orientation 2: Z[i = pixel][j = positive]: G' (lane = positive) -> dcoef --------------------------------
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) z = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[g][s], cf[g][s], z, 0, 0, 0);
+            const float w_q = pp < p.n ? s_w[pp] : 0.f;
+            const float wx1 = s_win[pp & (MAXP - 1)][0], wx2 = s_win[pp & (MAXP - 1)][1];
+            const float wy1 = s_win[pp & (MAXP - 1)][2], wy2 = s_win[pp & (MAXP - 1)][3];
+            const size_t gt_base = (size_t)s_gt[pp & (MAXP - 1)] * p.P;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pix2 = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float gval = 0.f;
+                if (pp < p.n && pix2 < p.P) {
+                    const int y2 = pix2 / p.Wp, x2 = pix2 - y2 * p.Wp;
+                    const bool inside = (float)x2 >= wx1 && (float)x2 < wx2 && (float)y2 >= wy1 && (float)y2 < wy2;
+                    if (inside) {
+                        const float sg = 1.f / (1.f + expf(-z[r]));
+                        const float t = p.dsmask[gt_base + pix2];
+                        gval = (sg - t) / fmaxf(sg * (1.f - sg), 1e-12f) * (sg * (1.f - sg)) * w_q * p.gscale;
+                    }
+                }
+                z[r] = gval;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pix2 = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float pv = pix2 < p.P ? p.proto[(size_t)pix2 * 32 + row] : 0.f;
+                dc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(z[r], pv, dc[pt], 0, 0, 0);
+            }
+        }
+        // dproto tile: D[i = pix][j = k]: col = lane & 31 = k, rows = pixels
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pix2 = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (pix2 < p.P) p.dproto[(size_t)pix2 * 32 + row] = dp[r];
+        }
+    }
+    // per-wave dcoef partial: D[i = positive][j = k]
+    float* part = p.part + (size_t)wave_id * MAXP * 32;
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = pt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            part[(size_t)q * 32 + row] = dc[pt][r];
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) loss_acc += __shfl_xor(loss_acc, o);
+    if (lane == 0 && loss_acc != 0.0) atomicAdd(p.loss, loss_acc);
+}
+
+// dcoef_full[anchor_idx[q]][k] = sum over waves (fixed order) of the partials
+__global__ __launch_bounds__(256) void k_mask_loss_reduce(const float* __restrict__ part, int nwaves, int n,
+                                                           const int64_t* __restrict__ anchor_idx, float* __restrict__ dcoef_full) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * 32) return;
+    const int q = e >> 5, k = e & 31;
+    float v = 0.f;
+    for (int w = 0; w < nwaves; ++w) v += part[((size_t)w * MAXP + q) * 32 + k];
+    dcoef_full[(size_t)anchor_idx[q] * 32 + k] = v;
+}
+
+constexpr int ML_BLOCKS = 64;    // 256 waves, each walking ~P/32/256 pixel tiles
+
+}  // namespace
+
+extern "C" size_t ym_mask_loss_workspace_bytes(void) { return (size_t)ML_BLOCKS * 4 * MAXP * 32 * sizeof(float) + 256; }
+
+extern "C" int ym_mask_loss_fwd_bwd(const float* proto, const float* coef_pos, const float* box_pos, const int32_t* gt_idx,
+                                    const float* gt_masks_ds, const int64_t* anchor_idx, int n, int Hp, int Wp, float wscale,
+                                    float gscale, double* loss_accum, float* dproto, float* dcoef_full, void* workspace,
+                                    size_t workspace_bytes, ym_stream_t s) {
+    YM_REQUIRE(n >= 0 && n <= MAXP, "mask_loss: at most %d positives per image (cfg.masks_to_train), got %d", MAXP, n);
+    if (n == 0) return YM_OK;
+    YM_REQUIRE(proto && coef_pos && box_pos && gt_idx && gt_masks_ds && anchor_idx && loss_accum && dproto && dcoef_full && workspace,
+               "mask_loss: null pointer");
+    if (workspace_bytes < ym_mask_loss_workspace_bytes()) { ym_set_error("mask_loss: workspace too small"); return YM_ENOSPC; }
+    MLP p;
+    p.proto = proto; p.coef = coef_pos; p.boxes = box_pos; p.gt_idx = gt_idx; p.dsmask = gt_masks_ds; p.dproto = dproto;
+    p.part = (float*)workspace; p.loss = loss_accum;
+    p.n = n; p.Hp = Hp; p.Wp = Wp; p.P = Hp * Wp; p.ntiles = (p.P + 31) / 32;
+    p.wscale = wscale; p.gscale = gscale;
+    hipStream_t st = (hipStream_t)s;
+    hipLaunchKernelGGL(k_mask_loss, dim3(ML_BLOCKS), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(k_mask_loss_reduce, dim3((n * 32 + 255) / 256), dim3(256), 0, st, (const float*)workspace, ML_BLOCKS * 4, n,
+                       anchor_idx, dcoef_full);
+    return ym_check_launch("mask_loss_fwd_bwd");
+}

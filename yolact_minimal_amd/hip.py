@@ -24,6 +24,7 @@ ABI_SYMBOLS = (
     'ym_boxes_to_pixels',
     'ym_pack_conv_weight_dgrad', 'ym_conv2d_wgrad_workspace_bytes', 'ym_conv2d_wgrad', 'ym_bn_train_fwd',
     'ym_val_preprocess', 'ym_layernorm', 'ym_patch_merge_layernorm', 'ym_swin_window_attention',
+    'ym_mask_loss_workspace_bytes', 'ym_mask_loss_fwd_bwd',
     'ym_bn_train_bwd', 'ym_act_bias_bwd', 'ym_conv2d_fuses_bn_stats', 'ym_bn_train_fwd_stats', 'ym_maxpool3x3s2_bwd', 'ym_bilinear2x_bwd', 'ym_sgd_step',
 )
 
@@ -103,6 +104,9 @@ def lib():
         L.ym_layernorm.argtypes = [vp, vp, vp, f32, vp, i64, i32, vp]
         L.ym_patch_merge_layernorm.argtypes = [vp, i32, i32, i32, i32, vp, vp, f32, vp, vp]
         L.ym_swin_window_attention.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
+        L.ym_mask_loss_workspace_bytes.argtypes = []
+        L.ym_mask_loss_workspace_bytes.restype = sz
+        L.ym_mask_loss_fwd_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp, vp, vp, sz, vp]
         L.ym_conv2d_fuses_bn_stats.argtypes = [ctypes.POINTER(ConvDesc)]
         L.ym_bn_train_fwd_stats.argtypes = [vp, i64, i32, vp, vp, f32, f32, vp, vp, vp, i32, vp, vp, vp, vp, vp]
         L.ym_bn_train_bwd.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, sz, vp]
@@ -113,7 +117,8 @@ def lib():
         for name in ABI_SYMBOLS:
             fn = getattr(L, name)
             if name not in ('ym_last_error', 'ym_conv2d_workspace_bytes', 'ym_nms_workspace_bytes',
-                            'ym_greedy_nms_workspace_bytes', 'ym_conv2d_wgrad_workspace_bytes'):
+                            'ym_greedy_nms_workspace_bytes', 'ym_conv2d_wgrad_workspace_bytes',
+                            'ym_mask_loss_workspace_bytes'):
                 fn.restype = ctypes.c_int
         _lib = L
     return _lib

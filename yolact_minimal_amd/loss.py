@@ -8,8 +8,12 @@ expressed with torch tensor ops on the GPU so that autograd can carry the gradie
 kernels.  Same arithmetic and normalisations as the reference (loss per rank normalised by its LOCAL positive count);
 the python loop over ground-truth boxes in `match` and the CPU `randperm` are kept on purpose for parity.
 """
+import ctypes
+
 import torch
 import torch.nn.functional as F
+
+from . import hip
 
 
 def box_iou(box_a, box_b):
@@ -82,29 +86,60 @@ def box_loss(cfg, box_p, offsets, pos):
     return cfg.bbox_alpha * F.smooth_l1_loss(box_p[pos, :], offsets[pos, :], reduction='sum') / pos.sum()
 
 
+class _MaskLossFn(torch.autograd.Function):
+    """Forward + backward of the mask term in one HIP pass per image (`ym_mask_loss_fwd_bwd`): the coefficient x prototype
+    GEMM, sigmoid, crop, BCE and both gradient GEMMs run on the f32 MFMA; autograd only scales the stored gradients."""
+
+    @staticmethod
+    def forward(ctx, proto_p, coef_p, per_image, coeff):
+        b, hp, wp, _ = proto_p.shape
+        dev = proto_p.device
+        proto_c, coef_c = proto_p.detach().contiguous(), coef_p.detach().contiguous()
+        dproto = torch.zeros_like(proto_c)
+        dcoef = torch.zeros_like(coef_c)
+        acc = torch.zeros(1, dtype=torch.float64, device=dev)
+        ws_bytes = hip.lib().ym_mask_loss_workspace_bytes()
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        for i, item in enumerate(per_image):
+            if item is None:
+                continue
+            idx, gt_idx, boxes, dsmask, wscale = item
+            cpos = coef_c[i][idx].contiguous()
+            hip.check(hip.lib().ym_mask_loss_fwd_bwd(
+                hip.ptr(proto_c[i]), hip.ptr(cpos), hip.ptr(boxes), hip.ptr(gt_idx, torch.int32), hip.ptr(dsmask),
+                hip.ptr(idx, torch.int64), idx.shape[0], hp, wp, float(wscale), float(coeff), ctypes.c_void_p(acc.data_ptr()),
+                hip.ptr(dproto[i]), hip.ptr(dcoef[i]), ctypes.c_void_p(ws.data_ptr()), ws.numel(), hip.stream_ptr()),
+                'ym_mask_loss_fwd_bwd')
+        ctx.save_for_backward(dproto, dcoef)
+        return (acc * coeff).float().reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        dproto, dcoef = ctx.saved_tensors
+        return dproto * grad_out, dcoef * grad_out, None, None
+
+
 def lincomb_mask_loss(cfg, pos, anchor_gt, coef_p, proto_p, mask_gt, anchor_box):
     ph, pw = proto_p.shape[1:3]
-    total = 0
+    total_pos = int(pos.sum())
+    per_image = []
     for i in range(coef_p.shape[0]):
-        ds = F.interpolate(mask_gt[i].unsqueeze(0), (ph, pw), mode='bilinear', align_corners=False).squeeze(0)
-        ds = ds.permute(1, 2, 0).contiguous().gt(0.5).float()
-        idx, bx, cf = anchor_gt[i][pos[i]], anchor_box[i][pos[i]], coef_p[i][pos[i]]
+        idx = torch.nonzero(pos[i]).flatten()
         if idx.shape[0] == 0:
+            per_image.append(None)
             continue
-        old = cf.shape[0]
+        g = mask_gt[i].shape[0]
+        ds = torch.empty(g, ph, pw, device=proto_p.device, dtype=torch.float32)     # bilinear(align_corners=False) then > 0.5
+        hip.mask_resize_binarize(mask_gt[i].contiguous().float(), ph, pw, ds)
+        gt_i, bx = anchor_gt[i][idx], anchor_box[i][idx]
+        old = idx.shape[0]
         if old > cfg.masks_to_train:
-            sel = torch.randperm(old)[:cfg.masks_to_train].to(cf.device)     # CPU generator, like the reference (:263)
-            cf, idx, bx = cf[sel], idx[sel], bx[sel]
-        n = cf.shape[0]
-        gt = ds[:, :, idx]
-        mp = crop(torch.sigmoid(proto_p[i] @ cf.t()), bx)
-        l = F.binary_cross_entropy(torch.clamp(mp, 0, 1), gt, reduction='none')
-        area = (bx[:, 2] - bx[:, 0]) * (bx[:, 3] - bx[:, 1])
-        l = l.sum(dim=(0, 1)) / area
-        if old > n:
-            l = l * (old / n)
-        total = total + torch.sum(l)
-    return cfg.mask_alpha * total / ph / pw / pos.sum()
+            sel = torch.randperm(old)[:cfg.masks_to_train].to(idx.device)            # CPU generator, like the reference (:263)
+            idx, gt_i, bx = idx[sel], gt_i[sel], bx[sel]
+        per_image.append((idx.contiguous(), gt_i.to(torch.int32).contiguous(), bx.contiguous(), ds.reshape(g, ph * pw),
+                          old / idx.shape[0]))
+    coeff = cfg.mask_alpha / ph / pw / total_pos
+    return _MaskLossFn.apply(proto_p, coef_p, per_image, coeff)
 
 
 def semantic_seg_loss(cfg, seg_p, mask_gt, class_gt):
