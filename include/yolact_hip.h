@@ -151,6 +151,31 @@ int ym_mask_loss_fwd_bwd(const float* proto, const float* coef_pos, const float*
                          double* loss_accum, float* dproto, float* dcoef_full, void* workspace, size_t workspace_bytes,
                          ym_stream_t s);
 
+/* match() for ONE image (utils/box_utils.py:57-83, encode :104-114): gt_boxes_cls [g][5] = (x1,y1,x2,y2,class) in [0,1]
+ * coordinates, anchors [N][4] (cx,cy,w,h).  Writes offsets [N][4], conf [N] int64 (class+1 / 0 background / -1 neutral),
+ * anchor_box [N][4] (matched gt corners), anchor_gt [N] int64 (matched gt index).  First maximum wins a tie (torch.max), the
+ * last gt wins a shared best anchor (the sequential loop :72-73).  1 <= g <= 256; workspace >= 4*N bytes. */
+int ym_match_anchors(const float* gt_boxes_cls, int g, const float* anchors, int N, float pos_thre, float neg_thre,
+                     float* offsets, int64_t* conf, float* anchor_box, int64_t* anchor_gt, void* workspace,
+                     size_t workspace_bytes, ym_stream_t s);
+
+/* category_loss (modules/yolact.py:205-232: OHEM hard negatives at neg_pos_ratio, softmax CE summed / total positives) and
+ * box_loss (:234-239: smooth-L1 over positives / total positives) for a batch, with their gradients (d total / d input):
+ * class_p [B][N][C], box_p/offsets [B][N][4], conf [B][N] -> dclass, dbox (fully overwritten), num_pos int32 [B+1]
+ * (per image, then the total) and the two device fp64 scalars loss_c, loss_b (already scaled by conf_alpha / bbox_alpha).
+ * Equal OHEM marks are ranked by anchor index (torch.sort leaves their order unspecified).  No host synchronisation. */
+size_t ym_loss_workspace_bytes(int B, int N);
+int ym_class_box_loss(const float* class_p, const float* box_p, const float* offsets, const int64_t* conf, int B, int N, int C,
+                      float conf_alpha, float bbox_alpha, int neg_pos_ratio, float* dclass, float* dbox, int32_t* num_pos,
+                      double* loss_c, double* loss_b, void* workspace, size_t workspace_bytes, ym_stream_t s);
+
+/* semantic_seg_loss (modules/yolact.py:293-313) for ONE image: seg_nhwc [P][pitch] logits (channels >= num_classes are
+ * padding), gt_masks_ds [g][P] in {0,1} (down-sampled + binarised gt masks), gt_cls[j*gt_cls_stride] the class of gt j.
+ * loss_accum += coeff * sum BCE-with-logits(seg, target) with target[c][pix] = max over gts of class c; dseg [P][pitch] =
+ * coeff * (sigmoid - target), zero in the padding channels.  coeff = semantic_alpha / H / W / B. */
+int ym_semantic_loss(const float* seg_nhwc, int P, int pitch, int num_classes, const float* gt_masks_ds, const int64_t* gt_cls,
+                     int gt_cls_stride, int g, float coeff, float* dseg, double* loss_accum, ym_stream_t s);
+
 int ym_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, ym_stream_t s);
 int ym_bilinear2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, int align_corners, ym_stream_t s);
 

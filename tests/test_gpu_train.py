@@ -295,3 +295,90 @@ def test_mask_loss_kernel_matches_oracle_autograd():
     np.testing.assert_allclose(float(got.detach()), float(ref.detach()), rtol=2e-5)
     torch.testing.assert_close(pg.grad.cpu().double() / 1.7, pr.grad, rtol=1e-4, atol=1e-7)
     torch.testing.assert_close(cg.grad.cpu().double() / 1.7, cf.grad, rtol=1e-4, atol=1e-7)
+
+
+def _loss_inputs(b, size, n_gt, seed):
+    cfg = build_cfg('res50_coco', 'train', size)
+    anchors = R.anchors_for(size, cfg.scales).float()
+    boxes, masks = R.synth_targets(b, size, n_gt=n_gt, seed=seed)
+    return cfg, anchors, boxes, masks
+
+
+@pytest.mark.parametrize('size,n_gt,seed', [(128, 3, 0), (256, 9, 5), (544, 24, 9)])
+def test_match_anchors_kernel_bit_exact(size, n_gt, seed):
+    """`ym_match_anchors` vs the oracle's match(): labels, matched gt index and matched boxes identical; encoded offsets to
+    log() rounding (1e-6)."""
+    from yolact_minimal_amd import loss as L
+    cfg, anchors, boxes, _ = _loss_inputs(2, size, n_gt, seed)
+    boxes[1][1, :4] = boxes[1][0, :4]                        # duplicated gt box: both claim the same best anchor, the later wins
+    n = anchors.shape[0]
+    a_d = anchors.to(DEV)
+    ws = torch.empty(4 * n, dtype=torch.uint8, device=DEV)
+    for bc in boxes:
+        off = torch.empty(n, 4, device=DEV)
+        conf = torch.empty(n, dtype=torch.int64, device=DEV)
+        abox = torch.empty(n, 4, device=DEV)
+        agt = torch.empty(n, dtype=torch.int64, device=DEV)
+        L.match(cfg, bc.to(DEV), a_d, off, conf, abox, agt, ws)
+        r_off, r_conf, r_box, r_gt = R.match_anchors(bc[:, :4], anchors, bc[:, 4].long())
+        assert torch.equal(conf.cpu(), r_conf)
+        assert torch.equal(agt.cpu(), r_gt)
+        assert torch.equal(abox.cpu(), r_box)
+        assert int((r_conf > 0).sum()) >= n_gt - 1
+        torch.testing.assert_close(off.cpu(), r_off, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('b,n,seed', [(2, 3000, 1), (3, 18525, 2)])
+def test_class_box_loss_kernel_matches_oracle_autograd(b, n, seed):
+    """`ym_class_box_loss` (OHEM selection + CE + smooth-L1, gradients in the same pass) vs fp64 autograd of the oracle;
+    includes an image with no positives, neutral anchors and more requested negatives than background anchors."""
+    from yolact_minimal_amd.loss import _ClassBoxLossFn
+    g = torch.Generator().manual_seed(seed)
+    nc = 81
+    class_p = torch.randn(b, n, nc, generator=g) * 2
+    box_p = torch.randn(b, n, 4, generator=g) * 1.5
+    offsets = torch.randn(b, n, 4, generator=g)
+    conf = torch.zeros(b, n, dtype=torch.int64)
+    for i in range(b):
+        npos = [40, 0, n // 3][i % 3]
+        sel = torch.randperm(n, generator=g)
+        conf[i, sel[:npos]] = torch.randint(1, nc, (npos,), generator=g)
+        conf[i, sel[npos:npos + 50]] = -1
+    pos = conf > 0
+    cp, bp = class_p.double().requires_grad_(), box_p.double().requires_grad_()
+    ref_c = R.ohem_class_loss(cp, conf, pos, stable=True)
+    ref_b = R.box_reg_loss(bp, offsets.double(), pos)
+    (ref_c * 1.3 + ref_b * 0.7).backward()
+    cg, bg = class_p.to(DEV).requires_grad_(), box_p.to(DEV).requires_grad_()
+    num_pos = torch.empty(b + 1, dtype=torch.int32, device=DEV)
+    got_c, got_b = _ClassBoxLossFn.apply(cg, bg, offsets.to(DEV), conf.to(DEV), num_pos, 1.0, 1.5, 3)
+    (got_c * 1.3 + got_b * 0.7).backward()
+    assert num_pos.tolist() == pos.sum(1).tolist() + [int(pos.sum())]
+    np.testing.assert_allclose(float(got_c.detach()), float(ref_c.detach()), rtol=2e-5)
+    np.testing.assert_allclose(float(got_b.detach()), float(ref_b.detach()), rtol=2e-5)
+    torch.testing.assert_close(cg.grad.cpu().double(), cp.grad, rtol=1e-4, atol=1e-8)
+    torch.testing.assert_close(bg.grad.cpu().double(), bp.grad, rtol=1e-4, atol=1e-8)
+
+
+def test_semantic_loss_kernel_matches_oracle_autograd():
+    """`ym_semantic_loss` on the padded NHWC conv output vs fp64 autograd of the oracle's semantic_loss."""
+    from yolact_minimal_amd.loss import semantic_seg_loss
+    cfg, _, boxes, masks = _loss_inputs(2, 128, 5, 3)
+    boxes[0][2, 4] = boxes[0][0, 4]                          # two gts of one class: their masks are OR-ed
+    g = torch.Generator().manual_seed(2)
+    nhwc = torch.randn(2, 16, 16, 96, generator=g) * 3
+    seg = nhwc[..., :80].permute(0, 3, 1, 2)
+    sp = seg.double().contiguous().requires_grad_()
+    ref = R.semantic_loss(sp, [m.double() for m in masks], [bc[:, 4].long() for bc in boxes])
+    ref.backward()
+    for padded in (True, False):
+        base = nhwc.to(DEV).requires_grad_()
+        sg = base[..., :80].permute(0, 3, 1, 2)
+        if not padded:
+            sg = sg.contiguous()
+        got = semantic_seg_loss(cfg, sg, [m.to(DEV) for m in masks], [bc.to(DEV) for bc in boxes])
+        (got * 2.0).backward()
+        np.testing.assert_allclose(float(got.detach()), float(ref.detach()), rtol=2e-5)
+        gr = base.grad.cpu()
+        torch.testing.assert_close(gr[..., :80].permute(0, 3, 1, 2).double() / 2.0, sp.grad, rtol=1e-4, atol=1e-9)
+        assert float(gr[..., 80:].abs().max()) == 0.0

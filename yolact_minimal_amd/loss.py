@@ -1,89 +1,59 @@
-"""YOLACT training loss on device tensors.
+"""YOLACT training loss on the device, every term a HIP kernel behind the C-ABI.
 
 Reference: `compute_loss` `/root/reference/modules/yolact.py:166-203`, `category_loss :205-232`, `box_loss :234-239`,
 `lincomb_mask_loss :241-291`, `semantic_seg_loss :293-313`, `match`/`encode` `utils/box_utils.py:57-114`.
 
-These are the small, data-dependent bookkeeping steps on the `[B, 18525, *]` head outputs (a few MFLOP); they are
-expressed with torch tensor ops on the GPU so that autograd can carry the gradient into the HIP backward
-kernels.  Same arithmetic and normalisations as the reference (loss per rank normalised by its LOCAL positive count);
-the python loop over ground-truth boxes in `match` and the CPU `randperm` are kept on purpose for parity.
+  match            -> `ym_match_anchors` (one launch per image, labels + encoded offsets + matched boxes)
+  category + box   -> `ym_class_box_loss` (OHEM ranking by radix select, softmax CE, smooth-L1; gradients in the same pass)
+  mask             -> `ym_mask_loss_fwd_bwd` (f32 MFMA: coefficient x prototype GEMM, sigmoid, crop, BCE, both gradient GEMMs)
+  semantic seg     -> `ym_semantic_loss` (target built on the fly from the down-sampled gt masks)
+
+The losses are terminal nodes of the graph, so each kernel also writes d(loss)/d(input); the autograd Functions below only
+scale those by the incoming gradient.  Same arithmetic and normalisations as the reference (each rank normalises by its LOCAL
+positive count); the CPU `randperm` that subsamples > masks_to_train positives is kept on purpose (:263).  One host read per
+step (the per-image positive counts, needed to size the mask-loss launches).
 """
 import ctypes
 
 import torch
-import torch.nn.functional as F
 
 from . import hip
 
 
-def box_iou(box_a, box_b):
-    """[A,4] x [B,4] corner boxes -> [A,B]; inter / (area_a + area_b - inter) (utils/box_utils.py:8-37)."""
-    lo = torch.max(box_a[:, None, :2], box_b[None, :, :2])
-    hi = torch.min(box_a[:, None, 2:], box_b[None, :, 2:])
-    wh = torch.clamp(hi - lo, min=0)
-    inter = wh[..., 0] * wh[..., 1]
-    area_a = ((box_a[:, 2] - box_a[:, 0]) * (box_a[:, 3] - box_a[:, 1]))[:, None]
-    area_b = ((box_b[:, 2] - box_b[:, 0]) * (box_b[:, 3] - box_b[:, 1]))[None, :]
-    return inter / (area_a + area_b - inter)
+def _vp(t):
+    return ctypes.c_void_p(t.data_ptr())
 
 
-def encode(matched, priors):
-    cxcy = ((matched[:, :2] + matched[:, 2:]) / 2 - priors[:, :2]) / (0.1 * priors[:, 2:])
-    wh = torch.log((matched[:, 2:] - matched[:, :2]) / priors[:, 2:]) / 0.2
-    return torch.cat([cxcy, wh], 1)
+def match(cfg, box_class_i, anchors, out_offsets, out_conf, out_anchor_box, out_anchor_gt, ws):
+    """`match()` for one image straight into row i of the batch buffers."""
+    g = box_class_i.shape[0]
+    hip.check(hip.lib().ym_match_anchors(
+        hip.ptr(box_class_i), g, hip.ptr(anchors), anchors.shape[0], float(cfg.pos_iou_thre), float(cfg.neg_iou_thre),
+        hip.ptr(out_offsets), hip.ptr(out_conf, torch.int64), hip.ptr(out_anchor_box), hip.ptr(out_anchor_gt, torch.int64),
+        _vp(ws), ws.numel(), hip.stream_ptr()), 'ym_match_anchors')
 
 
-def match(cfg, box_gt, anchors, class_gt):
-    corners = torch.cat((anchors[:, :2] - anchors[:, 2:] / 2, anchors[:, :2] + anchors[:, 2:] / 2), 1)
-    overlaps = box_iou(box_gt, corners)                       # [g, N]
-    gt_best_anchor = overlaps.max(1)[1]
-    anchor_best, anchor_gt = overlaps.max(0)
-    anchor_best.index_fill_(0, gt_best_anchor, 2)
-    for j in range(gt_best_anchor.shape[0]):                  # sequential on purpose: the LAST gt wins a shared anchor
-        anchor_gt[gt_best_anchor[j]] = j
-    matched = box_gt[anchor_gt]
-    conf = class_gt[anchor_gt] + 1
-    conf[anchor_best < cfg.pos_iou_thre] = -1
-    conf[anchor_best < cfg.neg_iou_thre] = 0
-    return encode(matched, anchors), conf, matched, anchor_gt
+class _ClassBoxLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, class_p, box_p, offsets, conf, num_pos, conf_alpha, bbox_alpha, ratio):
+        b, n, c = class_p.shape
+        dev = class_p.device
+        cp, bp = class_p.detach().contiguous(), box_p.detach().contiguous()
+        dclass, dbox = torch.empty_like(cp), torch.empty_like(bp)
+        acc = torch.empty(2, dtype=torch.float64, device=dev)
+        ws = torch.empty(hip.lib().ym_loss_workspace_bytes(b, n), dtype=torch.uint8, device=dev)
+        hip.check(hip.lib().ym_class_box_loss(
+            hip.ptr(cp), hip.ptr(bp), hip.ptr(offsets), hip.ptr(conf, torch.int64), b, n, c, float(conf_alpha),
+            float(bbox_alpha), int(ratio), hip.ptr(dclass), hip.ptr(dbox), hip.ptr(num_pos, torch.int32), _vp(acc[0:]),
+            _vp(acc[1:]), _vp(ws), ws.numel(), hip.stream_ptr()), 'ym_class_box_loss')
+        ctx.save_for_backward(dclass, dbox)
+        out = acc.float()
+        return out[0], out[1]
 
-
-def crop(masks, boxes, padding=1):
-    """masks [h,w,n] zeroed outside each (padded) box window — utils/box_utils.py:117-168."""
-    h, w, n = masks.shape
-
-    def span(a, b, size):
-        a, b = a * size, b * size
-        return torch.clamp(torch.min(a, b) - padding, min=0), torch.clamp(torch.max(a, b) + padding, max=size)
-    x1, x2 = span(boxes[:, 0], boxes[:, 2], w)
-    y1, y2 = span(boxes[:, 1], boxes[:, 3], h)
-    xs = torch.arange(w, device=masks.device, dtype=x1.dtype).view(1, -1, 1)
-    ys = torch.arange(h, device=masks.device, dtype=x1.dtype).view(-1, 1, 1)
-    inside = (xs >= x1.view(1, 1, -1)) & (xs < x2.view(1, 1, -1)) & (ys >= y1.view(1, 1, -1)) & (ys < y2.view(1, 1, -1))
-    return masks * inside.float()
-
-
-def category_loss(cfg, class_p, conf_gt, pos, ratio=3):
-    nc = cfg.num_classes
-    flat = class_p.reshape(-1, nc)
-    mx = flat.max()
-    mark = torch.log(torch.sum(torch.exp(flat - mx), 1)) + mx - flat[:, 0]
-    mark = mark.reshape(class_p.shape[0], -1)
-    mark[pos] = 0
-    mark[conf_gt < 0] = 0
-    _, idx = mark.sort(1, descending=True)
-    _, rank = idx.sort(1)
-    num_pos = pos.long().sum(1, keepdim=True)
-    num_neg = torch.clamp(ratio * num_pos, max=pos.shape[1] - 1)
-    neg = rank < num_neg.expand_as(rank)
-    neg[pos] = 0
-    neg[conf_gt < 0] = 0
-    sel = pos | neg
-    return cfg.conf_alpha * F.cross_entropy(class_p[sel].reshape(-1, nc), conf_gt[sel], reduction='sum') / num_pos.sum()
-
-
-def box_loss(cfg, box_p, offsets, pos):
-    return cfg.bbox_alpha * F.smooth_l1_loss(box_p[pos, :], offsets[pos, :], reduction='sum') / pos.sum()
+    @staticmethod
+    def backward(ctx, g_c, g_b):
+        dclass, dbox = ctx.saved_tensors
+        return dclass * g_c, dbox * g_b, None, None, None, None, None, None
 
 
 class _MaskLossFn(torch.autograd.Function):
@@ -119,20 +89,25 @@ class _MaskLossFn(torch.autograd.Function):
         return dproto * grad_out, dcoef * grad_out, None, None
 
 
-def lincomb_mask_loss(cfg, pos, anchor_gt, coef_p, proto_p, mask_gt, anchor_box):
+def lincomb_mask_loss(cfg, pos, anchor_gt, coef_p, proto_p, mask_gt, anchor_box, num_pos=None):
+    """`num_pos`: host list [n_0..n_{B-1}, total] of positive counts (read back once per step); computed here when absent."""
     ph, pw = proto_p.shape[1:3]
-    total_pos = int(pos.sum())
+    if num_pos is None:
+        per = pos.sum(1)
+        num_pos = torch.cat([per, per.sum(0, keepdim=True)]).tolist()
+    total_pos = int(num_pos[-1])
     per_image = []
     for i in range(coef_p.shape[0]):
-        idx = torch.nonzero(pos[i]).flatten()
-        if idx.shape[0] == 0:
+        n_i = int(num_pos[i])
+        if n_i == 0:
             per_image.append(None)
             continue
+        idx = torch.nonzero_static(pos[i], size=n_i).flatten()                        # size known: no host sync
         g = mask_gt[i].shape[0]
         ds = torch.empty(g, ph, pw, device=proto_p.device, dtype=torch.float32)     # bilinear(align_corners=False) then > 0.5
         hip.mask_resize_binarize(mask_gt[i].contiguous().float(), ph, pw, ds)
         gt_i, bx = anchor_gt[i][idx], anchor_box[i][idx]
-        old = idx.shape[0]
+        old = n_i
         if old > cfg.masks_to_train:
             sel = torch.randperm(old)[:cfg.masks_to_train].to(idx.device)            # CPU generator, like the reference (:263)
             idx, gt_i, bx = idx[sel], gt_i[sel], bx[sel]
@@ -142,31 +117,55 @@ def lincomb_mask_loss(cfg, pos, anchor_gt, coef_p, proto_p, mask_gt, anchor_box)
     return _MaskLossFn.apply(proto_p, coef_p, per_image, coeff)
 
 
-def semantic_seg_loss(cfg, seg_p, mask_gt, class_gt):
-    b, nc, mh, mw = seg_p.shape
-    total = 0
-    for i in range(b):
-        ds = F.interpolate(mask_gt[i].unsqueeze(0), (mh, mw), mode='bilinear', align_corners=False).squeeze(0).gt(0.5).float()
-        tgt = torch.zeros_like(seg_p[i])
-        for j in range(ds.shape[0]):
-            tgt[class_gt[i][j]] = torch.max(tgt[class_gt[i][j]], ds[j])
-        total = total + F.binary_cross_entropy_with_logits(seg_p[i], tgt, reduction='sum')
-    return cfg.semantic_alpha * total / mh / mw / b
+class _SemanticLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, seg_p, mask_gt, box_class, coeff):
+        b, nc, mh, mw = seg_p.shape
+        dev = seg_p.device
+        x = seg_p.detach().permute(0, 2, 3, 1)                                        # NHWC view; the conv output is NHWC
+        pitch = x.stride(2)
+        if not (x.stride(3) == 1 and pitch >= nc and x.stride(1) == mw * pitch and x.stride(0) == mh * mw * pitch):
+            x, pitch = x.contiguous(), nc
+        dseg = torch.empty(b, mh, mw, pitch, device=dev, dtype=torch.float32)
+        acc = torch.zeros(1, dtype=torch.float64, device=dev)
+        for i in range(b):
+            g = mask_gt[i].shape[0]
+            ds = torch.empty(g, mh, mw, device=dev, dtype=torch.float32)
+            if g:
+                hip.mask_resize_binarize(mask_gt[i].contiguous().float(), mh, mw, ds)
+            cls = box_class[i][:, -1].long()                                          # [g] int64 class ids
+            hip.check(hip.lib().ym_semantic_loss(
+                _vp(x[i]), mh * mw, pitch, nc, _vp(ds), _vp(cls), 1, g, float(coeff), _vp(dseg[i]), _vp(acc),
+                hip.stream_ptr()), 'ym_semantic_loss')
+        ctx.save_for_backward(dseg)
+        ctx.nc = nc
+        return acc.float().reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (dseg,) = ctx.saved_tensors
+        return (dseg[..., :ctx.nc] * grad_out).permute(0, 3, 1, 2), None, None, None
+
+
+def semantic_seg_loss(cfg, seg_p, mask_gt, box_class):
+    b, _, mh, mw = seg_p.shape
+    return _SemanticLossFn.apply(seg_p, mask_gt, box_class, cfg.semantic_alpha / mh / mw / b)
 
 
 def compute_loss(cfg, anchors, class_p, box_p, coef_p, proto_p, seg_p, box_class, mask_gt):
     device = class_p.device
     b, n = box_p.shape[:2]
-    offsets = torch.zeros(b, n, 4, device=device)
-    conf_gt = torch.zeros(b, n, dtype=torch.int64, device=device)
-    anchor_box = torch.zeros(b, n, 4, device=device)
-    anchor_gt = torch.zeros(b, n, dtype=torch.int64, device=device)
-    class_gt = []
-    with torch.no_grad():
-        for i in range(b):
-            class_gt.append(box_class[i][:, -1].long())
-            offsets[i], conf_gt[i], anchor_box[i], anchor_gt[i] = match(cfg, box_class[i][:, :-1], anchors, class_gt[i])
-    pos = conf_gt > 0
-    return (category_loss(cfg, class_p, conf_gt, pos), box_loss(cfg, box_p, offsets, pos),
-            lincomb_mask_loss(cfg, pos, anchor_gt, coef_p, proto_p, mask_gt, anchor_box),
-            semantic_seg_loss(cfg, seg_p, mask_gt, class_gt))
+    offsets = torch.empty(b, n, 4, device=device)
+    conf_gt = torch.empty(b, n, dtype=torch.int64, device=device)
+    anchor_box = torch.empty(b, n, 4, device=device)
+    anchor_gt = torch.empty(b, n, dtype=torch.int64, device=device)
+    num_pos = torch.empty(b + 1, dtype=torch.int32, device=device)
+    ws = torch.empty(n * 4, dtype=torch.uint8, device=device)
+    anchors = anchors.contiguous().float()
+    for i in range(b):
+        match(cfg, box_class[i].contiguous().float(), anchors, offsets[i], conf_gt[i], anchor_box[i], anchor_gt[i], ws)
+    loss_c, loss_b = _ClassBoxLossFn.apply(class_p, box_p, offsets, conf_gt, num_pos, cfg.conf_alpha, cfg.bbox_alpha, 3)
+    counts = num_pos.tolist()                                                         # the one host read of the step
+    loss_m = lincomb_mask_loss(cfg, conf_gt > 0, anchor_gt, coef_p, proto_p, mask_gt, anchor_box, counts)
+    loss_s = semantic_seg_loss(cfg, seg_p, mask_gt, box_class)
+    return loss_c, loss_b, loss_m, loss_s

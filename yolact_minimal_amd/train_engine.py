@@ -224,6 +224,7 @@ class ConvBias(torch.autograd.Function):
                           residual.contiguous() if residual is not None else None)
         ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
         ctx.meta = (stride, pad, act, cout_pad, bias is not None, residual is not None)
+        ctx.bias_param = bias if isinstance(bias, torch.nn.Parameter) else None
         return y
 
     @staticmethod
@@ -233,7 +234,11 @@ class ConvBias(torch.autograd.Function):
         dy = dy.contiguous()
         m, c = dy.numel() // cout_pad, cout_pad
         dz = torch.empty_like(dy) if act != ACT_NONE else dy
-        dbias = torch.empty(c, device=dy.device, dtype=torch.float32) if has_bias else None
+        bias_param = ctx.bias_param
+        dbias = None
+        if has_bias:
+            dbias = _grad_slot(bias_param, (c,)) if (bias_param is not None and cout_pad == weight.shape[0]) else \
+                torch.empty(c, device=dy.device, dtype=torch.float32)
         ws = scratch(dy.device, c * 16)
         hip.check(hip.lib().ym_act_bias_bwd(hip.ptr(dy), hip.ptr(y) if y is not None else None, m, c, act,
                                             hip.ptr(dz) if act != ACT_NONE else None, hip.ptr(dbias), ctypes.c_void_p(ws.data_ptr()),
@@ -271,6 +276,7 @@ class ConvBn(torch.autograd.Function):
                                                 stats.numel() * 8, hip.stream_ptr()), 'ym_bn_train_fwd')
         ctx.save_for_backward(x, weight, gamma, y, out if relu else None, mean, invstd)
         ctx.meta = (stride, pad, relu, residual is not None)
+        ctx.beta_param = beta
         return out
 
     @staticmethod
@@ -282,8 +288,8 @@ class ConvBn(torch.autograd.Function):
         m = y.numel() // cout
         dy = torch.empty_like(y)
         dres = torch.empty_like(y) if has_res else None
-        dgamma = torch.empty(cout, device=y.device, dtype=torch.float32)
-        dbeta = torch.empty_like(dgamma)
+        dgamma = _grad_slot(gamma, (cout,))
+        dbeta = _grad_slot(ctx.beta_param, (cout,)) if ctx.beta_param is not None else torch.empty(cout, device=y.device)
         ws = scratch(y.device, cout * 16)
         hip.check(hip.lib().ym_bn_train_bwd(hip.ptr(dout), hip.ptr(out) if relu else None, hip.ptr(y), m, cout,
                                             hip.ptr(gamma.detach()), hip.ptr(mean), hip.ptr(invstd), int(relu), hip.ptr(dy),
