@@ -85,7 +85,12 @@ typedef struct {
     int32_t stages;          /* workgroup kernel LDS ring depth: 0/2 = double buffer, 3 = loads two K tiles ahead (64-wide tiles) */
     double* bn_sum;          /* optional [Cout] fp64 accumulators (zeroed by the caller): the epilogue adds the */
     double* bn_sumsq;        /* per-channel sum / sum of squares of the conv OUTPUT (train-mode BN statistics).  */
-                             /* Only when ym_conv2d_fuses_bn_stats(desc) == 1 (plain NHWC output, no K split).   */
+                             /* Only when ym_conv2d_fuses_bn_stats(desc) == 1 (plain NHWC output).               */
+    int32_t* tile_counters;  /* optional, >= ym_conv2d_tile_counters(desc) int32, ZERO before the first launch (the  */
+                             /* kernel leaves them zero): with a K split and a plain NHWC output, the LAST workgroup  */
+                             /* to finish an output tile sums the slices (in slice order: deterministic) and runs the  */
+                             /* epilogue in the same launch; NULL = separate reduce launch.  One buffer may be shared  */
+                             /* by launches that are ordered on one stream, never by concurrent ones.                  */
 } ym_conv_desc;
 
 /* y = act(conv(x, w) * scale + shift + residual), one launch (plus a reduce launch if K is split).
@@ -94,6 +99,7 @@ typedef struct {
  * with three segments, the bbox/conf/coef convs + tanh + permute/reshape/cat of
  * PredictionModule.forward + Yolact.forward (modules/yolact.py:27-30,155-157). */
 size_t ym_conv2d_workspace_bytes(const ym_conv_desc* d);
+int ym_conv2d_tile_counters(const ym_conv_desc* d);   /* output tiles of the chosen plan (0 if K is not split) */
 int ym_conv2d_fuses_bn_stats(const ym_conv_desc* d);
 int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t workspace_bytes, ym_stream_t s);
 

@@ -49,9 +49,46 @@ def _worker(rank, world, port, q):
                for k in range(world)) / world
     full.backward()
     torch.testing.assert_close(g, w2.grad, rtol=1e-5, atol=1e-6)
+    _check_flat_reducer(rank, world)
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, 'ok'))
+
+
+def _check_flat_reducer(rank, world):
+    """FlatGradReducer (the trainer's zero-copy bucketed all-reduce) on a toy net: averaged gradients in the flat buffer equal
+    the mean of the per-rank gradients, with a parameter used twice, one never used, several buckets, two steps."""
+    from yolact_minimal_amd.trainer import FlatSGD, FlatGradReducer, flatten_buffers
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.ReLU(),
+                              torch.nn.Conv2d(8, 8, 3, padding=1), torch.nn.Conv2d(8, 4, 1))
+    unused = torch.nn.Parameter(torch.randn(5))
+    params = list(net.parameters()) + [unused]
+    opt = FlatSGD(params, lr=0.1)
+    red = FlatGradReducer(opt, world, bucket_bytes=150)
+    assert len(red.buckets) >= 3 and sum(len(b[2]) for b in red.buckets) == len(opt.params)
+    assert red.buckets[0][1] == opt.flat.numel() and red.buckets[-1][0] == 0          # reverse order, complete cover
+    for step in range(2):
+        g = torch.Generator().manual_seed(10 * step + rank)
+        x = torch.randn(2, 3, 6, 6, generator=g)
+        h = net[2](net[1](net[0](x)))
+        y = net[4](net[3](net[3](h)))                                                  # net[3] is used twice
+        opt.zero_grad()
+        y.pow(2).mean().backward()
+        local = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).clone() for p in opt.params])
+        assert all(p.grad is None or p.grad.data_ptr() == p._ym_grad_slot.data_ptr() for p in opt.params)
+        red.finish()
+        want = local.clone()
+        dist.all_reduce(want)
+        want /= world
+        torch.testing.assert_close(opt.grad, want, rtol=1e-6, atol=1e-7)
+        assert float(opt.grad[opt.offsets[-1][0]:].abs().sum()) == 0.0                 # the unused parameter reduces zeros
+    assert red.launches == 2 * len(red.buckets)
+    # BN running statistics: one flat broadcast from rank 0
+    flat = flatten_buffers(net)
+    net[1].running_mean.fill_(float(rank + 1))
+    dist.broadcast(flat, 0)
+    assert float(net[1].running_mean[0]) == 1.0 and flat.numel() == 16
 
 
 def test_two_rank_gloo():

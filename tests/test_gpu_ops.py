@@ -12,7 +12,8 @@ def _dev():
     return torch.device('cuda:0')
 
 
-def run_conv(x_nchw, w, scale=None, shift=None, residual=None, stride=1, pad=0, act=0, tile=(0, 0), ksplit=0, kwaves=0, stages=0):
+def run_conv(x_nchw, w, scale=None, shift=None, residual=None, stride=1, pad=0, act=0, tile=(0, 0), ksplit=0, kwaves=0, stages=0,
+             counters=None, repeat=1):
     """Runs ym_conv2d_fwd on NHWC data; returns NCHW cpu tensor."""
     from yolact_minimal_amd import hip
     dev = _dev()
@@ -46,9 +47,12 @@ def run_conv(x_nchw, w, scale=None, shift=None, residual=None, stride=1, pad=0, 
     d.ksplit = ksplit
     d.kwaves = kwaves
     d.stages = stages
+    if counters is not None:
+        d.tile_counters = counters.data_ptr()
     nbytes = hip.conv_workspace_bytes(d)
     ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
-    hip.conv2d_fwd(d, ws)
+    for _ in range(repeat):
+        hip.conv2d_fwd(d, ws)
     torch.cuda.synchronize()
     return out.cpu().permute(0, 3, 1, 2)
 
@@ -122,6 +126,35 @@ def test_conv_three_stage_ring_parity(case):
     got = run_conv(x, wt, scale, shift, res, stride, pad, act, tile, ksplit, 0, 3)
     base = run_conv(x, wt, scale, shift, res, stride, pad, act, tile, ksplit, 0, 2)
     assert torch.equal(got, base)          # same summation order as the 2-stage kernel -> bit-identical
+    torch.testing.assert_close(got, ref_conv(x, wt, scale, shift, res, stride, pad, act), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('case', [
+    # b, cin, h, w, cout, k, stride, pad, act, residual, tile, ksplit, stages
+    (1, 256, 34, 34, 256, 3, 1, 1, 1, False, (64, 64), 6, 3),
+    (1, 1024, 34, 34, 256, 1, 1, 0, 1, False, (64, 64), 4, 2),
+    (1, 256, 34, 34, 1024, 1, 1, 0, 1, True, (64, 64), 2, 2),
+    (1, 1024, 13, 13, 256, 1, 1, 0, 1, True, (64, 64), 5, 2),       # uneven slices
+    (2, 256, 12, 10, 252, 3, 1, 1, 0, False, (64, 128), 3, 2),      # Cout not a multiple of the tile
+    (1, 512, 17, 17, 512, 3, 1, 1, 2, False, (128, 128), 8, 2),
+    (1, 256, 5, 5, 256, 3, 2, 1, 1, False, (0, 0), 0, 0),           # heuristic split
+])
+def test_conv_splitk_fused_finish(case):
+    """K split with `tile_counters`: the last-arriving workgroup reduces the slices in slice order and runs the epilogue in
+    the same launch -> bit-identical to the separate reduce launch, counters back at zero (re-launchable)."""
+    b, cin, h, w, cout, k, stride, pad, act, use_res, tile, ksplit, stages = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    res = torch.randn(b, cout, ho, wo, generator=g) if use_res else None
+    counters = torch.zeros(4096, dtype=torch.int32, device=_dev())
+    got = run_conv(x, wt, scale, shift, res, stride, pad, act, tile, ksplit, 0, stages, counters=counters, repeat=3)
+    base = run_conv(x, wt, scale, shift, res, stride, pad, act, tile, ksplit, 0, stages)
+    assert int(counters.abs().sum()) == 0
+    assert torch.equal(got, base)
     torch.testing.assert_close(got, ref_conv(x, wt, scale, shift, res, stride, pad, act), rtol=1e-4, atol=1e-5)
 
 

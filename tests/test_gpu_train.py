@@ -243,6 +243,10 @@ def test_trainer_steps_reduce_loss_and_refresh_eval_engine():
         losses = tr.step(img, boxes, masks)
         hist.append(sum(float(l.detach()) for l in losses))
     assert all(np.isfinite(hist)) and hist[-1] < hist[0], hist
+    # zero-copy gradients: autograd adopted the optimizer's flat-buffer slots for (nearly) every parameter
+    params = tr.opt.params
+    adopted = sum(1 for p in params if p.grad is not None and p.grad.data_ptr() == p._ym_grad_slot.data_ptr())
+    assert adopted >= 0.9 * len(params), (adopted, len(params))
     net.eval()
     with torch.no_grad():
         a = net(img)

@@ -21,9 +21,10 @@ struct ConvP {
     float* ws;  // split-K partials [ksplit][M][Cout] (only when ksplit > 1)
     double* bn_sum;    // optional fused per-channel sum / sum of squares of the OUTPUT (train-mode BatchNorm)
     double* bn_sumsq;
+    int* counters;     // optional per-output-tile arrival counters: fused split-K finish (see ym_conv_desc.tile_counters)
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, Kpad;
     int M, HoWo, nkt, ksplit, kt_per_split, tiles_m, tiles_n;
-    unsigned in_bytes, w_bytes;   // sizes of `in` / `w` for the raw-buffer descriptors (out-of-range reads return 0)
+    unsigned in_bytes, w_bytes, ws_bytes;   // sizes of `in` / `w` for the raw-buffer descriptors (out-of-range reads return 0)
     int nseg;
     int vec;   // 1: single segment, plain NHWC [M][Cout], Cout % 4 == 0, 16-byte aligned -> vectorised epilogue
     SegDev seg[3];
@@ -31,8 +32,7 @@ struct ConvP {
 
 __device__ __forceinline__ void epilogue_store(const ConvP& p, int m, int n, float acc) {
     float v = acc;
-    if (p.scale) v *= p.scale[n];
-    if (p.shift) v += p.shift[n];
+    v = __builtin_fmaf(v, p.scale ? p.scale[n] : 1.f, p.shift ? p.shift[n] : 0.f);
     if (p.residual) v += p.residual[(size_t)m * p.Cout + n];
     const int b = m / p.HoWo, pix = m - b * p.HoWo;
 #pragma unroll

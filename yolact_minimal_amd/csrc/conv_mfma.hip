@@ -36,6 +36,14 @@ constexpr unsigned OOB = 0xFFFFFFF0u;
 __device__ __forceinline__ f32x4 buf_ld16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
 }
+// agent-scope (sc1) accesses: coherent across the 8 XCD L2s without cache maintenance (aux bit 4 = sc1 on gfx94x/gfx950)
+constexpr int AUX_SC1 = 16;
+__device__ __forceinline__ f32x4 buf_ld16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, AUX_SC1));
+}
+__device__ __forceinline__ void buf_st16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), r, (int)byte_off, 0, AUX_SC1);
+}
 
 // MODE 0: Cin % 32 == 0 (every K tile lies inside one filter tap).  MODE 1: Cin == 4 (stem; one tap per float4).
 // MODE 2: data gradient (transposed conv): output pixel (ih,iw) gathers dY[(ih+pad-kh)/s][(iw+pad-kw)/s] where divisible.
@@ -54,6 +62,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
     const int wm = wave >> 1, wn = wave & 1;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_ws = __builtin_amdgcn_make_buffer_rsrc((void*)p.ws, 0, p.ws_bytes, 0x00020000);
 
     int id = ym_xcd_remap(blockIdx.x, gridDim.x);
     const int ks = id % p.ksplit;
@@ -264,41 +273,76 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
         const int col4 = tid % C4, row0 = tid / C4;
         const int n = n0 + col4 * 4;
         double bsum[4] = {0.0, 0.0, 0.0, 0.0}, bsq[4] = {0.0, 0.0, 0.0, 0.0};   // fp64: var = E[x^2]-E[x]^2 must not cancel in fp32
-        if (n < p.Cout) {
-            if (p.ksplit > 1) {
-                float* wsb = p.ws + (size_t)ks * p.M * p.Cout + n;
-#pragma unroll 4
-                for (int row = row0; row < BM; row += RPP) {
-                    const int m = m0 + row;
-                    if (m < p.M)
-                        *reinterpret_cast<f32x4*>(wsb + (size_t)m * p.Cout) = *reinterpret_cast<const f32x4*>(C + row * CP + col4 * 4);
-                }
-            } else {
-                f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-                if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-                if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
-                const int act = p.seg[0].act;
-                float* outb = p.seg[0].out + n;
-                const float* resb = p.residual ? p.residual + n : nullptr;
+        const size_t slice = (size_t)p.M * p.Cout;
+        if (p.ksplit > 1) {
+            // With arrival counters the slices are exchanged between workgroups of ONE launch (on different XCDs, each with
+            // its own L2): they are written / read with agent-scope (sc1) accesses, which is all the coherence needed — no
+            // L2 write-back / invalidate fences (measured: `__threadfence()` per workgroup doubled the forward time).
+            const bool fused = p.counters != nullptr;
+            if (n < p.Cout) {
+                const unsigned base = (unsigned)(((size_t)ks * slice + n) * 4);      // workspace < 4 GiB (checked on the host)
 #pragma unroll 4
                 for (int row = row0; row < BM; row += RPP) {
                     const int m = m0 + row;
                     if (m < p.M) {
-                        f32x4 v = *reinterpret_cast<const f32x4*>(C + row * CP + col4 * 4);
-                        v = v * sc + sh;
-                        if (resb) v += *reinterpret_cast<const f32x4*>(resb + (size_t)m * p.Cout);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = ym_apply_act(v[e], act);
-                        *reinterpret_cast<f32x4*>(outb + (size_t)m * p.Cout) = v;
-                        if (p.bn_sum) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { const double dv = v[e]; bsum[e] += dv; bsq[e] += dv * dv; }
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(C + row * CP + col4 * 4);
+                        if (fused) buf_st16_sc1(rs_ws, base + (unsigned)m * (unsigned)(p.Cout * 4), v);
+                        else *reinterpret_cast<f32x4*>(p.ws + (size_t)ks * slice + n + (size_t)m * p.Cout) = v;
+                    }
+                }
+            }
+            if (!fused) return;                    // the host launches conv_splitk_reduce
+            // the last workgroup to arrive at this output tile owns the reduction + epilogue
+            __shared__ int s_last;
+            __syncthreads();                       // s_waitcnt vmcnt(0): every lane's slice stores are acknowledged
+            if (tid == 0) {
+                int* cnt = p.counters + tile_m * p.tiles_n + tile_n;
+                const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_last = old == p.ksplit - 1;
+                if (s_last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            }
+            __syncthreads();
+            if (!s_last) return;
+        }
+        if (n < p.Cout) {
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+            if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+            const int act = p.seg[0].act;
+            float* outb = p.seg[0].out + n;
+            const float* resb = p.residual ? p.residual + n : nullptr;
+#pragma unroll 4
+            for (int row = row0; row < BM; row += RPP) {
+                const int m = m0 + row;
+                if (m < p.M) {
+                    f32x4 v;
+                    if (p.ksplit > 1) {
+                        const unsigned off = (unsigned)(((size_t)m * p.Cout + n) * 4);
+                        const unsigned sb = (unsigned)(slice * 4);
+                        v = buf_ld16_sc1(rs_ws, off);
+                        int s2 = 1;
+                        for (; s2 + 3 < p.ksplit; s2 += 4) {           // four slices in flight, summed in slice order
+                            const f32x4 a = buf_ld16_sc1(rs_ws, off + (unsigned)s2 * sb), b = buf_ld16_sc1(rs_ws, off + (unsigned)(s2 + 1) * sb);
+                            const f32x4 c = buf_ld16_sc1(rs_ws, off + (unsigned)(s2 + 2) * sb), d = buf_ld16_sc1(rs_ws, off + (unsigned)(s2 + 3) * sb);
+                            v += a; v += b; v += c; v += d;
                         }
+                        for (; s2 < p.ksplit; ++s2) v += buf_ld16_sc1(rs_ws, off + (unsigned)s2 * sb);
+                    } else {
+                        v = *reinterpret_cast<const f32x4*>(C + row * CP + col4 * 4);
+                    }
+                    v = __builtin_elementwise_fma(v, sc, sh);
+                    if (resb) v += *reinterpret_cast<const f32x4*>(resb + (size_t)m * p.Cout);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ym_apply_act(v[e], act);
+                    *reinterpret_cast<f32x4*>(outb + (size_t)m * p.Cout) = v;
+                    if (p.bn_sum) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const double dv = v[e]; bsum[e] += dv; bsq[e] += dv * dv; }
                     }
                 }
             }
         }
-        if (p.bn_sum && p.ksplit == 1) {
+        if (p.bn_sum) {
             // train-mode BatchNorm statistics of THIS conv output, fused: per-workgroup column sums of the tile
             // (fp64), then one fp64 atomic per channel per workgroup.
             __syncthreads();                       // every lane is done reading the staged tile
@@ -353,7 +397,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
                 for (int r = 0; r < 16; ++r) {
                     const int m = mb + (r & 3) + 8 * (r >> 2);
                     if (m < p.M) {
-                        float v = acc[i][j][r] * sc + sh;
+                        float v = __builtin_fmaf(acc[i][j][r], sc, sh);
                         if (p.residual) v += p.residual[(size_t)m * p.Cout + n];
                         const int b = m / p.HoWo, pix = m - b * p.HoWo;
                         optr[(size_t)b * obs + (size_t)pix * opitch] = ym_apply_act(v, oact);
@@ -375,8 +419,10 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce(const ConvP p) {
             f32x4 v = *reinterpret_cast<const f32x4*>(p.ws + e);
             for (int s = 1; s < p.ksplit; ++s) v += *reinterpret_cast<const f32x4*>(p.ws + (size_t)s * total + e);
             const int n = (int)(e % p.Cout);
-            if (p.scale) v *= *reinterpret_cast<const f32x4*>(p.scale + n);
-            if (p.shift) v += *reinterpret_cast<const f32x4*>(p.shift + n);
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+            if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+            v = __builtin_elementwise_fma(v, sc, sh);
             if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + e);
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = ym_apply_act(v[k], act);
@@ -480,13 +526,19 @@ extern "C" size_t ym_conv2d_workspace_bytes(const ym_conv_desc* d) {
     return pl.ksplit > 1 ? (size_t)pl.ksplit * pl.M * d->Cout * sizeof(float) : 0;
 }
 
+extern "C" int ym_conv2d_tile_counters(const ym_conv_desc* d) {
+    Plan pl;
+    if (make_plan(d, &pl) != YM_OK || d->kwaves > 0) return 0;
+    return pl.ksplit > 1 ? pl.tiles_m * pl.tiles_n : 0;
+}
+
 extern "C" int ym_conv2d_fuses_bn_stats(const ym_conv_desc* d) {
     Plan pl;
     if (make_plan(d, &pl) != YM_OK) return 0;
     const ym_conv_seg& g = d->seg[0];
     const bool plain = d->nseg == 1 && g.n_begin == 0 && g.n_end == d->Cout && g.pitch == d->Cout &&
                        g.batch_stride == (int64_t)d->Ho * d->Wo * d->Cout && d->Cout % 4 == 0;
-    return (plain && pl.ksplit == 1 && d->kwaves == 0) ? 1 : 0;
+    return (plain && (pl.ksplit == 1 || d->tile_counters) && d->kwaves == 0) ? 1 : 0;
 }
 
 extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t workspace_bytes, ym_stream_t s) {
@@ -526,8 +578,10 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
                  g.batch_stride == (int64_t)d->Ho * d->Wo * d->Cout && d->Cout % 4 == 0 && aligned) ? 1 : 0;
     }
     p.bn_sum = d->bn_sum; p.bn_sumsq = d->bn_sumsq;
+    p.counters = (p.vec && pl.ksplit > 1 && d->kwaves == 0 && need < 0xFFFFFFF0ull) ? d->tile_counters : nullptr;
+    p.ws_bytes = (unsigned)(need < 0xFFFFFFF0ull ? need : 0);
     if (d->bn_sum) {
-        YM_REQUIRE(d->bn_sumsq && p.vec && pl.ksplit == 1 && d->kwaves == 0,
+        YM_REQUIRE(d->bn_sumsq && p.vec && (pl.ksplit == 1 || p.counters) && d->kwaves == 0,
                    "conv: bn_sum given but this configuration cannot fuse the statistics (ask ym_conv2d_fuses_bn_stats)");
     }
     hipStream_t st = (hipStream_t)s;
@@ -545,7 +599,7 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
     else { if (d->stages == 3) launch<64, 64, 0, 3>(p, grid, st); else launch<64, 64, 0>(p, grid, st); }
     rc = ym_check_launch("conv_igemm_f32");
     if (rc != YM_OK) return rc;
-    if (pl.ksplit > 1) {
+    if (pl.ksplit > 1 && !p.counters) {
         const size_t total = (size_t)pl.M * d->Cout;
         int rgrid = (int)((total / (p.vec ? 4 : 1) + 255) / 256);
         if (rgrid > 2048) rgrid = 2048;

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_wave_f32(const ConvP p) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(slab0 + row * CP + col4 * 4);
 #pragma unroll
                 for (int s = 1; s < KW; ++s) v += *reinterpret_cast<const f32x4*>(slab0 + (size_t)s * WM * CP + row * CP + col4 * 4);
-                v = v * sc + sh;
+                v = __builtin_elementwise_fma(v, sc, sh);
                 if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.Cout + n);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = ym_apply_act(v[e], act);

@@ -30,7 +30,7 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
-TUNED_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuned_gfx950.json')
+TUNED_PATH = os.environ.get('YM_TUNED_PATH', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuned_gfx950.json'))
 _tuned = None
 
 
@@ -365,6 +365,14 @@ class InferEngine:
         self.workspaces = {sid: (old[sid] if sid in old and old[sid].numel() >= nb else
                                  torch.empty(nb, device=self.device, dtype=torch.uint8)) for sid, nb in need.items()}
         self.workspace = self.workspaces[0]
+        # split-K arrival counters (fused finish, ym_conv_desc.tile_counters): zeroed once, the kernels leave them zero
+        fused = os.environ.get('YM_FUSED_SPLITK', '1') != '0'
+        oldc = getattr(self, 'counters', {})
+        self.counters = {sid: oldc.get(sid, None) if oldc.get(sid, None) is not None else
+                         torch.zeros(hip.TILE_COUNTERS, device=self.device, dtype=torch.int32) for sid in need}
+        for i, (kind, arg) in enumerate(self.ops):
+            if kind == 'conv':
+                arg.desc.tile_counters = self.counters[self.op_stream.get(i, 0)].data_ptr() if fused else None
 
     # ---- execution ---------------------------------------------------------------------------
     def refresh_weights(self):

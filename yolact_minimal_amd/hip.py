@@ -18,7 +18,7 @@ ACT_NONE, ACT_RELU, ACT_TANH, ACT_GELU = 0, 1, 2, 3
 # every symbol include/yolact_hip.h declares (checked by tests/test_abi.py without a GPU)
 ABI_SYMBOLS = (
     'ym_abi_version', 'ym_last_error', 'ym_nchw_to_nhwc4', 'ym_pack_conv_weight', 'ym_fold_bn',
-    'ym_conv2d_workspace_bytes', 'ym_conv2d_fwd', 'ym_maxpool3x3s2_fwd', 'ym_bilinear2x_fwd',
+    'ym_conv2d_workspace_bytes', 'ym_conv2d_tile_counters', 'ym_conv2d_fwd', 'ym_maxpool3x3s2_fwd', 'ym_bilinear2x_fwd',
     'ym_softmax_rows', 'ym_nms_workspace_bytes', 'ym_detect_fast_nms', 'ym_detect_greedy_nms',
     'ym_greedy_nms_workspace_bytes', 'ym_greedy_nms', 'ym_mask_assemble', 'ym_mask_resize_binarize',
     'ym_boxes_to_pixels',
@@ -44,7 +44,8 @@ class ConvDesc(ctypes.Structure):
                 ('Wo', ctypes.c_int32), ('k_pad', ctypes.c_int32), ('nseg', ctypes.c_int32),
                 ('seg', ConvSeg * 3), ('tile_m', ctypes.c_int32), ('tile_n', ctypes.c_int32),
                 ('ksplit', ctypes.c_int32), ('kwaves', ctypes.c_int32), ('transposed', ctypes.c_int32),
-                ('stages', ctypes.c_int32), ('bn_sum', ctypes.c_void_p), ('bn_sumsq', ctypes.c_void_p)]
+                ('stages', ctypes.c_int32), ('bn_sum', ctypes.c_void_p), ('bn_sumsq', ctypes.c_void_p),
+                ('tile_counters', ctypes.c_void_p)]
 
 
 class WgradDesc(ctypes.Structure):
@@ -82,6 +83,7 @@ def lib():
         L.ym_conv2d_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
         L.ym_conv2d_workspace_bytes.restype = sz
         L.ym_conv2d_fwd.argtypes = [ctypes.POINTER(ConvDesc), vp, sz, vp]
+        L.ym_conv2d_tile_counters.argtypes = [ctypes.POINTER(ConvDesc)]
         L.ym_maxpool3x3s2_fwd.argtypes = [vp, vp, i32, i32, i32, i32, vp]
         L.ym_bilinear2x_fwd.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
         L.ym_softmax_rows.argtypes = [vp, vp, i64, i32, vp]
@@ -175,7 +177,12 @@ def conv_workspace_bytes(desc):
     return lib().ym_conv2d_workspace_bytes(ctypes.byref(desc))
 
 
+TILE_COUNTERS = 16384     # int32 entries the engines allocate for ym_conv_desc.tile_counters
+
+
 def conv2d_fwd(desc, workspace=None):
+    if desc.tile_counters and lib().ym_conv2d_tile_counters(ctypes.byref(desc)) > TILE_COUNTERS:
+        desc.tile_counters = None              # more output tiles than counters: separate reduce launch
     ws_ptr = ctypes.c_void_p(workspace.data_ptr()) if workspace is not None else None
     ws_bytes = workspace.numel() * workspace.element_size() if workspace is not None else 0
     check(lib().ym_conv2d_fwd(ctypes.byref(desc), ws_ptr, ws_bytes, stream_ptr()), 'ym_conv2d_fwd')

@@ -120,6 +120,18 @@ def _ru(x, m):
     return (x + m - 1) // m * m
 
 
+_counters = {}
+
+
+def _tile_counters(device):
+    """Arrival counters of the fused split-K finish (ym_conv_desc.tile_counters): zeroed once, kernels leave them zero; the
+    training step is one stream, so every conv shares them."""
+    t = _counters.get(device)
+    if t is None:
+        t = _counters[device] = torch.zeros(hip.TILE_COUNTERS, device=device, dtype=torch.int32)
+    return t.data_ptr()
+
+
 def _pack_fwd(weight, cin_pad, cout_pad):
     cout, cin, kh, kw = weight.shape
     k_pad = _ru(kh * kw * cin_pad, 32)
@@ -145,6 +157,7 @@ def _conv_forward(x, wp, k_pad, cout_pad, kh, kw, stride, pad, shift, act, resid
     d.seg[0].batch_stride, d.seg[0].pitch, d.seg[0].act = ho * wo * cout_pad, cout_pad, act
     if cin != 4:
         _configure_conv(d, f'M{b * ho * wo}_N{cout_pad}_C{cin}_k{kh}_s{stride}_seg1_r{int(residual is not None)}')
+    d.tile_counters = _tile_counters(x.device)
     fused = False
     if bn_stats is not None and hip.lib().ym_conv2d_fuses_bn_stats(ctypes.byref(d)) == 1:
         bn_stats.zero_()
@@ -174,6 +187,7 @@ def _conv_dgrad(dz, weight, cout_pad, x_shape, stride, pad):
     d.seg[0].batch_stride, d.seg[0].pitch, d.seg[0].act = h * w * cin, cin, ACT_NONE
     d.transposed = 1
     _configure_conv(d, f'T_M{b * h * w}_N{cin}_C{cout_pad}_k{kh}_s{stride}')
+    d.tile_counters = _tile_counters(dz.device)
     ws = scratch(dz.device, hip.conv_workspace_bytes(d))
     hip.conv2d_fwd(d, ws)
     return dx
@@ -185,7 +199,7 @@ def _grad_slot(param, shape):
     slot = getattr(param, '_ym_grad_slot', None) if param is not None else None
     if slot is not None and getattr(param, '_ym_slot_free', False):
         param._ym_slot_free = False           # a second use in the same step must accumulate into a fresh tensor
-        return slot
+        return slot.view_as(slot)             # a FRESH view: AccumulateGrad only adopts (instead of cloning) an unshared tensor
     return torch.empty(shape, device=param.device if param is not None else None, dtype=torch.float32)
 
 

@@ -5,10 +5,11 @@ targets, masks); 4-float loss all-reduce (logging); zero_grad; backward with buc
 SGD(momentum 0.9, weight_decay 5e-4) step; LR warm-up / step decay (`train.py:103-109`).
 
 Here: one process per GPU; `torch.distributed` with backend 'nccl' (= RCCL over xGMI on ROCm) carries the
-gradient all-reduce, overlapped with the HIP backward kernels by DDP's bucket hooks (25 MB buckets: ~8 buckets for
-res101's 200 MB of fp32 gradients, ring all-reduce is per-link bound on xGMI so few large messages are preferred
-over many small ones); BN buffers are broadcast from rank 0 every step like the reference; the optimizer is ONE
-launch of `ym_sgd_step` over a flat parameter buffer (parameters are re-pointed at views of it).
+gradient all-reduce.  Parameters, gradients and momentum live in three flat fp32 buffers: the HIP wgrad kernels write
+each gradient into its slice, `FlatGradReducer` all-reduces contiguous >=25 MB ranges of that buffer as backward fills
+them (asynchronously on the RCCL stream, zero copies; ~8 messages for res101's 200 MB — ring all-reduce is per-link
+bound on xGMI so few large messages are preferred), BN running statistics are broadcast from rank 0 every step as ONE
+flat message like `DDP(broadcast_buffers=True)`, and the optimizer is ONE launch of `ym_sgd_step` over the flat buffers.
 """
 import os
 
@@ -68,38 +69,136 @@ class FlatSGD:
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.empty(n, device=dev, dtype=torch.float32)
+        self.offsets = []
         off = 0
         for p in self.params:                       # parameters become views of the flat buffer
             k = p.numel()
             self.flat[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + k].view_as(p.data)
+            self.offsets.append((off, off + k))
             off += k
         self.buf = torch.zeros_like(self.flat)
         self.grad = torch.empty_like(self.flat)
-        off = 0
-        for p in self.params:                       # the HIP wgrad kernels write straight into these views
-            k = p.numel()
-            p._ym_grad_slot = self.grad[off:off + k].view_as(p.data)
+        for p, (a, b) in zip(self.params, self.offsets):   # the HIP wgrad kernels write straight into these views
+            p._ym_grad_slot = self.grad[a:b].view_as(p.data)
             p._ym_slot_free = True
-            off += k
+            p._ym_in_slot = False
         self.steps = 0
 
     def zero_grad(self):
         for p in self.params:
             p.grad = None
             p._ym_slot_free = True
+            p._ym_in_slot = False
+
+    @staticmethod
+    def gather(p):
+        """Make sure this parameter's gradient sits in its slot of the flat buffer (no-op when autograd adopted the slot)."""
+        if p._ym_in_slot:
+            return
+        g = p.grad
+        if g is None:
+            p._ym_grad_slot.zero_()
+        elif g.data_ptr() != p._ym_grad_slot.data_ptr():
+            p._ym_grad_slot.copy_(g)
+        p._ym_in_slot = True
 
     def step(self):
-        for p in self.params:                       # gather only gradients that did not land in their slot
-            g = p.grad
-            if g is None:
-                p._ym_grad_slot.zero_()
-            elif g.data_ptr() != p._ym_grad_slot.data_ptr():
-                p._ym_grad_slot.copy_(g)
+        for p in self.params:
+            self.gather(p)
         hip.check(hip.lib().ym_sgd_step(hip.ptr(self.flat), hip.ptr(self.grad), hip.ptr(self.buf), self.flat.numel(),
                                         float(self.lr), float(self.momentum), float(self.weight_decay),
                                         int(self.steps == 0), hip.stream_ptr()), 'ym_sgd_step')
         self.steps += 1
+        for p in self.params:
+            p._ym_in_slot = False                   # the next step() gathers again unless a hook already did
+
+
+class FlatGradReducer:
+    """Bucketed gradient all-reduce overlapped with backward, zero-copy on the optimizer's flat gradient buffer.
+
+    Takes the place of DDP's reducer (reference `train.py:76`): the HIP wgrad kernels already write every gradient into its
+    slice of one flat buffer, so a bucket is just a contiguous range of it — no per-parameter copies into and out of bucket
+    storage (632 copy launches per res101 step with torch DDP).  Buckets are cut in REVERSE parameter order (the order
+    backward produces gradients), >= `bucket_bytes` each (25 MB: ~8 messages for res101's 200 MB; ring all-reduce over xGMI
+    is per-link bound, so few large messages beat many small ones), and are launched in bucket order on every rank as soon as
+    their last gradient has landed (`register_post_accumulate_grad_hook`), asynchronously on the RCCL stream.
+    """
+
+    def __init__(self, opt, world, bucket_bytes=25 << 20, group=None):
+        self.opt, self.world, self.group = opt, world, group
+        self.buckets = []                            # [start, end, param indices]
+        cur, size, end = [], 0, opt.flat.numel()
+        for i in reversed(range(len(opt.params))):
+            cur.append(i)
+            size += opt.params[i].numel() * 4
+            if size >= bucket_bytes or i == 0:
+                self.buckets.append((opt.offsets[i][0], end, cur))
+                cur, size, end = [], 0, opt.offsets[i][0]
+        self.bucket_of = {}
+        for b, (_, _, idx) in enumerate(self.buckets):
+            for i in idx:
+                self.bucket_of[i] = b
+        backend = dist.get_backend(group) if dist.is_initialized() else 'none'
+        self.avg_op = backend == 'nccl'                # RCCL averages in the collective; gloo has no AVG -> SUM then scale
+        self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(opt.params)]
+        self.launches = 0
+        self.reset()
+
+    def reset(self):
+        self.pending = [len(idx) for _, _, idx in self.buckets]
+        self.next_bucket = 0
+        self.works = []
+
+    def _make_hook(self, i):
+        def hook(p):
+            FlatSGD.gather(p)
+            if p.grad is not None and p.grad.data_ptr() != p._ym_grad_slot.data_ptr():
+                p.grad = p._ym_grad_slot.view_as(p._ym_grad_slot)     # the reduced value is what the caller must see
+            b = self.bucket_of[i]
+            self.pending[b] -= 1
+            self._launch_ready()
+        return hook
+
+    def _launch_ready(self):
+        while self.next_bucket < len(self.buckets) and self.pending[self.next_bucket] == 0:
+            a, e, _ = self.buckets[self.next_bucket]
+            op = dist.ReduceOp.AVG if self.avg_op else dist.ReduceOp.SUM
+            self.works.append(dist.all_reduce(self.opt.grad[a:e], op=op, group=self.group, async_op=True))
+            self.launches += 1
+            self.next_bucket += 1
+
+    def finish(self):
+        """After backward: reduce what is left (parameters that received no gradient count as zeros), wait for every
+        bucket, and leave the AVERAGED gradients in the flat buffer."""
+        for b in range(self.next_bucket, len(self.buckets)):
+            for i in self.buckets[b][2]:
+                p = self.opt.params[i]
+                if not p._ym_in_slot:
+                    FlatSGD.gather(p)
+            self.pending[b] = 0
+        self._launch_ready()
+        for w in self.works:
+            w.wait()
+        if not self.avg_op and self.world > 1:
+            self.opt.grad.mul_(1.0 / self.world)
+        self.reset()
+
+
+def flatten_buffers(module):
+    """Re-point every floating-point buffer (BN running statistics) at a view of one flat tensor so that the per-step
+    rank-0 broadcast (`DDP(broadcast_buffers=True)`, reference train.py:76) is ONE message instead of 2 per BN layer."""
+    bufs = [b for b in module.buffers() if b.is_floating_point()]
+    if not bufs:
+        return None
+    flat = torch.empty(sum(b.numel() for b in bufs), device=bufs[0].device, dtype=bufs[0].dtype)
+    off = 0
+    for b in bufs:
+        k = b.numel()
+        flat[off:off + k].copy_(b.reshape(-1))
+        b.data = flat[off:off + k].view_as(b)
+        off += k
+    return flat
 
 
 class Trainer:
@@ -108,14 +207,26 @@ class Trainer:
         self.opt = FlatSGD(self.net.parameters(), cfg.lr)
         self.model = self.net
         self.ddp = world > 1 or (dist.is_initialized() and os.environ.get('YM_FORCE_DIST', '0') == '1')
-        if self.ddp:
+        self.reducer, self.buffers_flat = None, None
+        self.torch_ddp = self.ddp and os.environ.get('YM_TORCH_DDP', '0') == '1'
+        if self.torch_ddp:                           # the reference's wrapper, kept as an option (per-parameter bucket copies)
             from torch.nn.parallel import DistributedDataParallel as DDP
             self.model = DDP(self.net, device_ids=[local_rank], output_device=local_rank, broadcast_buffers=True,
                              bucket_cap_mb=25, gradient_as_bucket_view=False)
+        elif self.ddp:
+            dist.broadcast(self.opt.flat, 0)         # every replica starts from rank 0's weights
+            self.buffers_flat = flatten_buffers(self.net)
+            self.reducer = FlatGradReducer(self.opt, world)
         self.step_idx = 0
+
+    @property
+    def module(self):
+        return self.net
 
     def step(self, images, targets, masks):
         self.opt.lr = lr_at(self.cfg, self.step_idx)
+        if self.buffers_flat is not None and self.world > 1:
+            dist.broadcast(self.buffers_flat, 0)      # BN running stats follow rank 0, one 0.4 MB message
         losses = self.model(images, targets, masks)
         if self.ddp:
             all_loss = torch.stack([l.detach() for l in losses])
@@ -123,6 +234,8 @@ class Trainer:
         total = losses[0] + losses[1] + losses[2] + losses[3]
         self.opt.zero_grad()
         total.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
         self.opt.step()
         self.net.mark_weights_changed()
         self.step_idx += 1
