@@ -91,6 +91,9 @@ typedef struct {
                              /* to finish an output tile sums the slices (in slice order: deterministic) and runs the  */
                              /* epilogue in the same launch; NULL = separate reduce launch.  One buffer may be shared  */
                              /* by launches that are ordered on one stream, never by concurrent ones.                  */
+    int32_t tail_tiles;      /* workgroup-quantisation fix (needs tile_counters, ksplit <= 1, plain NHWC output): the   */
+    int32_t tail_ksplit;     /* LAST tail_tiles output tiles are each split into tail_ksplit K slices, so that e.g. 580  */
+                             /* tiles on 256 CUs become 512 whole tiles + 68x4 quarter tiles instead of 2-or-3 per CU.   */
 } ym_conv_desc;
 
 /* y = act(conv(x, w) * scale + shift + residual), one launch (plus a reduce launch if K is split).

@@ -13,7 +13,7 @@ def _dev():
 
 
 def run_conv(x_nchw, w, scale=None, shift=None, residual=None, stride=1, pad=0, act=0, tile=(0, 0), ksplit=0, kwaves=0, stages=0,
-             counters=None, repeat=1):
+             counters=None, repeat=1, tail=(0, 0)):
     """Runs ym_conv2d_fwd on NHWC data; returns NCHW cpu tensor."""
     from yolact_minimal_amd import hip
     dev = _dev()
@@ -49,6 +49,7 @@ def run_conv(x_nchw, w, scale=None, shift=None, residual=None, stride=1, pad=0, 
     d.stages = stages
     if counters is not None:
         d.tile_counters = counters.data_ptr()
+    d.tail_tiles, d.tail_ksplit = tail
     nbytes = hip.conv_workspace_bytes(d)
     ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
     for _ in range(repeat):
@@ -156,6 +157,39 @@ def test_conv_splitk_fused_finish(case):
     assert int(counters.abs().sum()) == 0
     assert torch.equal(got, base)
     torch.testing.assert_close(got, ref_conv(x, wt, scale, shift, res, stride, pad, act), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('case', [
+    # b, cin, h, w, cout, k, stride, pad, act, residual, tile, tail (tiles, slices), stages
+    (2, 256, 34, 34, 256, 3, 1, 1, 1, False, (64, 64), (20, 4), 2),      # 37x4 = 148 tiles, the last 20 in quarters
+    (2, 256, 34, 34, 256, 3, 1, 1, 1, True, (64, 64), (148, 3), 3),      # every tile in the tail
+    (1, 1024, 34, 34, 256, 1, 1, 0, 1, False, (128, 64), (7, 8), 2),
+    (2, 128, 40, 40, 252, 3, 2, 1, 2, False, (64, 128), (5, 6), 2),      # ragged M and N edges live in the tail tiles
+    (1, 64, 30, 30, 64, 1, 1, 0, 0, False, (64, 64), (3, 8), 2),         # 2 K tiles: slices clamp to 2
+])
+def test_conv_tail_split(case):
+    """`tail_tiles`/`tail_ksplit`: the last output tiles are computed as K slices by several workgroups and finished by the last
+    arriver; the other tiles are untouched by the split (bit-identical to the plain launch)."""
+    b, cin, h, w, cout, k, stride, pad, act, use_res, tile, tail, stages = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    res = torch.randn(b, cout, ho, wo, generator=g) if use_res else None
+    counters = torch.zeros(4096, dtype=torch.int32, device=_dev())
+    got = run_conv(x, wt, scale, shift, res, stride, pad, act, tile, 1, 0, stages, counters=counters, repeat=2, tail=tail)
+    base = run_conv(x, wt, scale, shift, res, stride, pad, act, tile, 1, 0, stages)
+    assert int(counters.abs().sum()) == 0
+    torch.testing.assert_close(got, ref_conv(x, wt, scale, shift, res, stride, pad, act), rtol=1e-4, atol=1e-5)
+    tiles_n = -(-cout // tile[1])
+    tiles = -(-(b * ho * wo) // tile[0]) * tiles_n
+    main_rows = (tiles - tail[0]) // tiles_n * tile[0]        # rows whose every tile is outside the tail
+    gm = got.permute(0, 2, 3, 1).reshape(-1, cout)[:main_rows]
+    bm = base.permute(0, 2, 3, 1).reshape(-1, cout)[:main_rows]
+    assert torch.equal(gm, bm)
+    assert not torch.equal(got, base) or tail[1] == 1
 
 
 WAVE_CASES = [

@@ -30,15 +30,15 @@ def main():
             res = eng.autotune(args.iters, verbose=True)
             for k, v in res.items():
                 if k not in table:
-                    table[k] = v[:5]
+                    table[k] = v[:7]
                     detail[k] = v
             net._engines.clear()
             torch.cuda.empty_cache()
     os.makedirs(os.path.dirname(args.out) or '.', exist_ok=True)
     json.dump(table, open(args.out, 'w'), indent=0, sort_keys=True)
     json.dump(detail, open(args.out.replace('.json', '_detail.json'), 'w'), indent=0, sort_keys=True)
-    tot_b = sum(v[6] for v in detail.values())
-    tot_a = sum(v[5] for v in detail.values())
+    tot_b = sum(v[8] for v in detail.values())
+    tot_a = sum(v[7] for v in detail.values())
     print(f'{len(table)} shapes; sum of per-shape best {tot_a:.0f} us vs default {tot_b:.0f} us')
 
 

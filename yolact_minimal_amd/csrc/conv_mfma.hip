@@ -64,14 +64,23 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_ws = __builtin_amdgcn_make_buffer_rsrc((void*)p.ws, 0, p.ws_bytes, 0x00020000);
 
-    int id = ym_xcd_remap(blockIdx.x, gridDim.x);
-    const int ks = id % p.ksplit;
-    id /= p.ksplit;
+    int id, ks, nks, ktps;                    // output tile, K slice, slices of THIS tile, K tiles per slice (block-uniform)
+    if ((int)blockIdx.x < p.main_blocks) {
+        id = ym_xcd_remap(blockIdx.x, p.main_blocks);
+        ks = id % p.ksplit;
+        id /= p.ksplit;
+        nks = p.ksplit; ktps = p.kt_per_split;
+    } else {                                  // tail tiles, split finer so that the last partial round of workgroups fills the chip
+        const int t = (int)blockIdx.x - p.main_blocks;
+        ks = t % p.tail_split;
+        id = p.main_tiles + t / p.tail_split;
+        nks = p.tail_split; ktps = p.tail_ktps;
+    }
     const int tile_m = id / p.tiles_n, tile_n = id - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    const int kt_beg = ks * p.kt_per_split;
-    const int kt_end = min(p.nkt, kt_beg + p.kt_per_split);
+    const int kt_beg = ks * ktps;
+    const int kt_end = min(p.nkt, kt_beg + ktps);
 
     // ---- per-thread staging coordinates -------------------------------------------------------
     const int c4 = tid & 7;      // which float4 of the 32-float K row
@@ -273,20 +282,27 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
         const int col4 = tid % C4, row0 = tid / C4;
         const int n = n0 + col4 * 4;
         double bsum[4] = {0.0, 0.0, 0.0, 0.0}, bsq[4] = {0.0, 0.0, 0.0, 0.0};   // fp64: var = E[x^2]-E[x]^2 must not cancel in fp32
+        // K-slice exchange area.  Uniform split: [slice][M][Cout] (what conv_splitk_reduce reads).  Tail tiles: compact
+        // [tail tile][slice][BM][BN], so the workspace does not grow with M.
         const size_t slice = (size_t)p.M * p.Cout;
-        if (p.ksplit > 1) {
+        const bool in_tail = (int)blockIdx.x >= p.main_blocks;
+        const unsigned sb = in_tail ? (unsigned)(BM * BN * 4) : (unsigned)(slice * 4);            // bytes between slices
+        const unsigned rs = in_tail ? (unsigned)(BN * 4) : (unsigned)(p.Cout * 4);                 // bytes between rows
+        const unsigned ws0 = in_tail ? (unsigned)(id - p.main_tiles) * (unsigned)nks * sb + (unsigned)(col4 * 16)
+                                     : (unsigned)m0 * rs + (unsigned)(n * 4);                      // (row 0, this lane's float4), slice 0
+        if (nks > 1) {
             // With arrival counters the slices are exchanged between workgroups of ONE launch (on different XCDs, each with
             // its own L2): they are written / read with agent-scope (sc1) accesses, which is all the coherence needed — no
             // L2 write-back / invalidate fences (measured: `__threadfence()` per workgroup doubled the forward time).
             const bool fused = p.counters != nullptr;
             if (n < p.Cout) {
-                const unsigned base = (unsigned)(((size_t)ks * slice + n) * 4);      // workspace < 4 GiB (checked on the host)
+                const unsigned base = ws0 + (unsigned)ks * sb;                        // workspace < 4 GiB (checked on the host)
 #pragma unroll 4
                 for (int row = row0; row < BM; row += RPP) {
                     const int m = m0 + row;
                     if (m < p.M) {
                         const f32x4 v = *reinterpret_cast<const f32x4*>(C + row * CP + col4 * 4);
-                        if (fused) buf_st16_sc1(rs_ws, base + (unsigned)m * (unsigned)(p.Cout * 4), v);
+                        if (fused) buf_st16_sc1(rs_ws, base + (unsigned)row * rs, v);
                         else *reinterpret_cast<f32x4*>(p.ws + (size_t)ks * slice + n + (size_t)m * p.Cout) = v;
                     }
                 }
@@ -298,7 +314,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
             if (tid == 0) {
                 int* cnt = p.counters + tile_m * p.tiles_n + tile_n;
                 const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_last = old == p.ksplit - 1;
+                s_last = old == nks - 1;
                 if (s_last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
             }
             __syncthreads();
@@ -316,17 +332,16 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
                 const int m = m0 + row;
                 if (m < p.M) {
                     f32x4 v;
-                    if (p.ksplit > 1) {
-                        const unsigned off = (unsigned)(((size_t)m * p.Cout + n) * 4);
-                        const unsigned sb = (unsigned)(slice * 4);
+                    if (nks > 1) {
+                        const unsigned off = ws0 + (unsigned)row * rs;
                         v = buf_ld16_sc1(rs_ws, off);
                         int s2 = 1;
-                        for (; s2 + 3 < p.ksplit; s2 += 4) {           // four slices in flight, summed in slice order
+                        for (; s2 + 3 < nks; s2 += 4) {           // four slices in flight, summed in slice order
                             const f32x4 a = buf_ld16_sc1(rs_ws, off + (unsigned)s2 * sb), b = buf_ld16_sc1(rs_ws, off + (unsigned)(s2 + 1) * sb);
                             const f32x4 c = buf_ld16_sc1(rs_ws, off + (unsigned)(s2 + 2) * sb), d = buf_ld16_sc1(rs_ws, off + (unsigned)(s2 + 3) * sb);
                             v += a; v += b; v += c; v += d;
                         }
-                        for (; s2 < p.ksplit; ++s2) v += buf_ld16_sc1(rs_ws, off + (unsigned)s2 * sb);
+                        for (; s2 < nks; ++s2) v += buf_ld16_sc1(rs_ws, off + (unsigned)s2 * sb);
                     } else {
                         v = *reinterpret_cast<const f32x4*>(C + row * CP + col4 * 4);
                     }
@@ -440,6 +455,14 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce(const ConvP p) {
 
 struct Plan {
     int bm, bn, ksplit, kt_per_split, tiles_m, tiles_n, nkt, M;
+    int tail_tiles, tail_split, tail_ktps;     // 0 = no tail
+    int slots() const { return tail_tiles > 0 && tail_split > ksplit ? tail_split : ksplit; }
+    size_t ws_bytes(int cout) const {          // uniform split: [ksplit][M][Cout]; tail: [tail_tiles][tail_split][bm][bn]
+        const size_t u = ksplit > 1 ? (size_t)ksplit * M * cout * sizeof(float) : 0;
+        const size_t t = tail_tiles > 0 ? (size_t)tail_tiles * tail_split * bm * bn * sizeof(float) : 0;
+        return u > t ? u : t;
+    }
+    int grid() const { return (tiles_m * tiles_n - tail_tiles) * ksplit + tail_tiles * (tail_tiles > 0 ? tail_split : 0); }
 };
 
 int make_plan(const ym_conv_desc* d, Plan* pl) {
@@ -465,6 +488,7 @@ int make_plan(const ym_conv_desc* d, Plan* pl) {
                "conv: tensor too large for 32-bit indexing");
     pl->M = (int)M;
     pl->nkt = d->k_pad / BK;
+    pl->tail_tiles = 0; pl->tail_split = 0; pl->tail_ktps = 0;
     int bm = d->tile_m, bn = d->tile_n;
     if (bm == 0 || bn == 0) {
         // largest tile that still gives every CU at least ~2 workgroups
@@ -503,6 +527,14 @@ int make_plan(const ym_conv_desc* d, Plan* pl) {
     if (ks < 1) ks = 1;
     pl->kt_per_split = ym_cdiv(pl->nkt, ks);
     pl->ksplit = ym_cdiv(pl->nkt, pl->kt_per_split);
+    if (d->tail_tiles > 0 && d->tail_ksplit > 1) {
+        YM_REQUIRE(d->tile_counters && pl->ksplit == 1 && d->Cin != 4, "conv: tail_tiles needs tile_counters, ksplit <= 1 and Cin %% 32 == 0");
+        YM_REQUIRE(d->tail_tiles <= pl->tiles_m * pl->tiles_n, "conv: tail_tiles %d > %d output tiles", d->tail_tiles, pl->tiles_m * pl->tiles_n);
+        int ts = d->tail_ksplit > pl->nkt ? pl->nkt : d->tail_ksplit;
+        pl->tail_ktps = ym_cdiv(pl->nkt, ts);
+        pl->tail_split = ym_cdiv(pl->nkt, pl->tail_ktps);
+        pl->tail_tiles = pl->tail_split > 1 ? d->tail_tiles : 0;
+    }
     return YM_OK;
 }
 
@@ -523,13 +555,13 @@ void launch(const ConvP& p, int grid, hipStream_t st) {
 extern "C" size_t ym_conv2d_workspace_bytes(const ym_conv_desc* d) {
     Plan pl;
     if (make_plan(d, &pl) != YM_OK) return 0;
-    return pl.ksplit > 1 ? (size_t)pl.ksplit * pl.M * d->Cout * sizeof(float) : 0;
+    return pl.ws_bytes(d->Cout);
 }
 
 extern "C" int ym_conv2d_tile_counters(const ym_conv_desc* d) {
     Plan pl;
     if (make_plan(d, &pl) != YM_OK || d->kwaves > 0) return 0;
-    return pl.ksplit > 1 ? pl.tiles_m * pl.tiles_n : 0;
+    return pl.slots() > 1 ? pl.tiles_m * pl.tiles_n : 0;
 }
 
 extern "C" int ym_conv2d_fuses_bn_stats(const ym_conv_desc* d) {
@@ -538,14 +570,14 @@ extern "C" int ym_conv2d_fuses_bn_stats(const ym_conv_desc* d) {
     const ym_conv_seg& g = d->seg[0];
     const bool plain = d->nseg == 1 && g.n_begin == 0 && g.n_end == d->Cout && g.pitch == d->Cout &&
                        g.batch_stride == (int64_t)d->Ho * d->Wo * d->Cout && d->Cout % 4 == 0;
-    return (plain && (pl.ksplit == 1 || d->tile_counters) && d->kwaves == 0) ? 1 : 0;
+    return (plain && (pl.slots() == 1 || d->tile_counters) && d->kwaves == 0) ? 1 : 0;
 }
 
 extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t workspace_bytes, ym_stream_t s) {
     Plan pl;
     int rc = make_plan(d, &pl);
     if (rc != YM_OK) return rc;
-    const size_t need = pl.ksplit > 1 ? (size_t)pl.ksplit * pl.M * d->Cout * sizeof(float) : 0;
+    const size_t need = pl.ws_bytes(d->Cout);
     if (need > workspace_bytes || (need && !workspace)) {
         ym_set_error("conv: workspace %zu B < %zu B needed (ksplit %d)", workspace_bytes, need, pl.ksplit);
         return YM_ENOSPC;
@@ -578,15 +610,20 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
                  g.batch_stride == (int64_t)d->Ho * d->Wo * d->Cout && d->Cout % 4 == 0 && aligned) ? 1 : 0;
     }
     p.bn_sum = d->bn_sum; p.bn_sumsq = d->bn_sumsq;
-    p.counters = (p.vec && pl.ksplit > 1 && d->kwaves == 0 && need < 0xFFFFFFF0ull) ? d->tile_counters : nullptr;
+    p.counters = (p.vec && pl.slots() > 1 && d->kwaves == 0 && need < 0xFFFFFFF0ull) ? d->tile_counters : nullptr;
+    YM_REQUIRE(pl.tail_tiles == 0 || p.counters, "conv: tail_tiles needs a plain NHWC output (vector epilogue) and a workspace < 4 GiB");
+    p.main_tiles = pl.tiles_m * pl.tiles_n - pl.tail_tiles;
+    p.main_blocks = p.main_tiles * pl.ksplit;
+    p.tail_split = pl.tail_tiles > 0 ? pl.tail_split : 1;
+    p.tail_ktps = pl.tail_tiles > 0 ? pl.tail_ktps : pl.nkt;
     p.ws_bytes = (unsigned)(need < 0xFFFFFFF0ull ? need : 0);
     if (d->bn_sum) {
-        YM_REQUIRE(d->bn_sumsq && p.vec && (pl.ksplit == 1 || p.counters) && d->kwaves == 0,
+        YM_REQUIRE(d->bn_sumsq && p.vec && (pl.slots() == 1 || p.counters) && d->kwaves == 0,
                    "conv: bn_sum given but this configuration cannot fuse the statistics (ask ym_conv2d_fuses_bn_stats)");
     }
     hipStream_t st = (hipStream_t)s;
     if (d->kwaves > 0) return ym_launch_conv_wave(p, pl.bm, pl.bn, d->kwaves, st);
-    const int grid = pl.tiles_m * pl.tiles_n * pl.ksplit;
+    const int grid = pl.grid();
     if (d->transposed) {
         if (pl.bm == 128 && pl.bn == 128) launch<128, 128, 2>(p, grid, st);
         else if (pl.bm == 128 && pl.bn == 64) launch<128, 64, 2>(p, grid, st);

@@ -85,6 +85,7 @@ class _Conv:
         self.ksplit = 0
         self.kwaves = 0
         self.stages = 0
+        self.tail = (0, 0)           # (tail_tiles, tail_ksplit): see ym_conv_desc
 
     def refresh(self):
         """(Re)pack parameters from the nn.Modules into the kernel layout, on device."""
@@ -141,7 +142,9 @@ class _Conv:
         if hit and self.tile == (0, 0) and self.ksplit == 0 and self.kwaves == 0:
             self.tile, self.ksplit, self.kwaves = (hit[0], hit[1]), hit[2], (hit[3] if len(hit) > 3 else 0)
             self.stages = hit[4] if len(hit) > 4 else 0
+            self.tail = (hit[5], hit[6]) if len(hit) > 6 else (0, 0)
             d.tile_m, d.tile_n, d.ksplit, d.kwaves, d.stages = hit[0], hit[1], hit[2], self.kwaves, self.stages
+            d.tail_tiles, d.tail_ksplit = self.tail
         return ho, wo
 
 
@@ -354,25 +357,27 @@ class InferEngine:
         self._weights_epoch = self.net._weights_epoch
 
     def _alloc_workspaces(self):
-        """Split-K scratch: one buffer per branch stream (concurrent branches must not share it)."""
-        need = {}
+        """Split-K scratch + arrival counters: one set per branch stream (concurrent branches must not share them)."""
+        sids = {self.op_stream.get(i, 0) for i, (kind, _) in enumerate(self.ops) if kind == 'conv'} | {0}
+        # split-K arrival counters (fused finish, ym_conv_desc.tile_counters): zeroed once, the kernels leave them zero
+        fused = os.environ.get('YM_FUSED_SPLITK', '1') != '0'
+        oldc = getattr(self, 'counters', {})
+        self.counters = {sid: oldc[sid] if sid in oldc else torch.zeros(hip.TILE_COUNTERS, device=self.device, dtype=torch.int32)
+                         for sid in sids}
+        need = {sid: 256 for sid in sids}
         for i, (kind, arg) in enumerate(self.ops):
             if kind == 'conv':
                 sid = self.op_stream.get(i, 0)
-                need[sid] = max(need.get(sid, 256), hip.conv_workspace_bytes(arg.desc))
+                arg.desc.tile_counters = self.counters[sid].data_ptr() if fused else None
+                if not fused:
+                    arg.desc.tail_tiles, arg.desc.tail_ksplit = 0, 0
+                nb = hip.conv_workspace_bytes(arg.desc)
+                need[sid] = max(need[sid], nb)
         need[0] = max(need.values())          # stream 0's buffer also serves sequential (eager / profiling) replays
         old = getattr(self, 'workspaces', {})
         self.workspaces = {sid: (old[sid] if sid in old and old[sid].numel() >= nb else
                                  torch.empty(nb, device=self.device, dtype=torch.uint8)) for sid, nb in need.items()}
         self.workspace = self.workspaces[0]
-        # split-K arrival counters (fused finish, ym_conv_desc.tile_counters): zeroed once, the kernels leave them zero
-        fused = os.environ.get('YM_FUSED_SPLITK', '1') != '0'
-        oldc = getattr(self, 'counters', {})
-        self.counters = {sid: oldc.get(sid, None) if oldc.get(sid, None) is not None else
-                         torch.zeros(hip.TILE_COUNTERS, device=self.device, dtype=torch.int32) for sid in need}
-        for i, (kind, arg) in enumerate(self.ops):
-            if kind == 'conv':
-                arg.desc.tile_counters = self.counters[self.op_stream.get(i, 0)].data_ptr() if fused else None
 
     # ---- execution ---------------------------------------------------------------------------
     def refresh_weights(self):
@@ -388,6 +393,7 @@ class InferEngine:
             c.desc.ksplit = c.ksplit
             c.desc.kwaves = c.kwaves
             c.desc.stages = c.stages
+            c.desc.tail_tiles, c.desc.tail_ksplit = c.tail
         self._alloc_workspaces()
         self.graph = None
 
@@ -398,9 +404,10 @@ class InferEngine:
         big_ws = torch.empty(1 << 28, device=self.device, dtype=torch.uint8)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-        def time_cfg(c, tile, ks, kwv=0, stg=0):
+        def time_cfg(c, tile, ks, kwv=0, stg=0, tail=(0, 0)):
             d = c.desc
             d.tile_m, d.tile_n, d.ksplit, d.kwaves, d.stages = tile[0], tile[1], ks, kwv, stg
+            d.tail_tiles, d.tail_ksplit = tail
             need = hip.conv_workspace_bytes(d)
             if need > big_ws.numel():
                 return None
@@ -422,7 +429,7 @@ class InferEngine:
         seen = {}
         for c in self.convs:
             if c.sig in seen:
-                c.tile, c.ksplit, c.kwaves, c.stages = seen[c.sig]
+                c.tile, c.ksplit, c.kwaves, c.stages, c.tail = seen[c.sig]
                 continue
             d = c.desc
             M, nkt = d.B * d.Ho * d.Wo, d.k_pad // 32
@@ -434,9 +441,17 @@ class InferEngine:
                 for ks in (1, 2, 3, 4, 6, 8, 12, 16, 24):
                     if ks > 1 and (wgs >= 1024 or ks * 2 > nkt or wgs * ks > 8192):
                         continue
-                    cands.append(((tm, tn), ks, 0, 2))
+                    cands.append(((tm, tn), ks, 0, 2, (0, 0)))
                     if (tm, tn) != (128, 128) and nkt // ks >= 3:
-                        cands.append(((tm, tn), ks, 0, 3))
+                        cands.append(((tm, tn), ks, 0, 3, (0, 0)))
+                # workgroup-quantisation fix: split the tiles of the last partial round (over 256 CUs x 1 or 2 workgroups)
+                if not c.stem and d.nseg == 1 and d.tile_counters and 256 < wgs <= hip.TILE_COUNTERS:
+                    for r in sorted({wgs % 256, wgs % 512} - {0}):
+                        for ts in (2, 3, 4, 6, 8):
+                            if ts * 2 > nkt or r * ts > 2048:
+                                continue
+                            for stg in ((2, 3) if (tm, tn) != (128, 128) and nkt // ts >= 3 else (2,)):
+                                cands.append(((tm, tn), 1, 0, stg, (r, ts)))
             if not c.stem:
                 for tm, tn in ((32, 32), (64, 32), (32, 64), (64, 64)):
                     waves = -(-M // tm) * -(-d.Cout // tn)
@@ -447,17 +462,17 @@ class InferEngine:
                             continue
                         if waves * kwv > 65536:
                             continue
-                        cands.append(((tm, tn), 1, kwv, 0))
-            best = (base, (0, 0), 0, 0, 0)
-            for tile, ks, kwv, stg in cands:
-                t = time_cfg(c, tile, ks, kwv, stg)
+                        cands.append(((tm, tn), 1, kwv, 0, (0, 0)))
+            best = (base, (0, 0), 0, 0, 0, (0, 0))
+            for tile, ks, kwv, stg, tail in cands:
+                t = time_cfg(c, tile, ks, kwv, stg, tail)
                 if t is not None and t < best[0] * 0.98:
-                    best = (t, tile, ks, kwv, stg)
-            c.tile, c.ksplit, c.kwaves, c.stages = best[1], best[2], best[3], best[4]
-            seen[c.sig] = (c.tile, c.ksplit, c.kwaves, c.stages)
-            results[c.sig] = [best[1][0], best[1][1], best[2], best[3], best[4], round(best[0], 2), round(base, 2)]
+                    best = (t, tile, ks, kwv, stg, tail)
+            c.tile, c.ksplit, c.kwaves, c.stages, c.tail = best[1], best[2], best[3], best[4], best[5]
+            seen[c.sig] = (c.tile, c.ksplit, c.kwaves, c.stages, c.tail)
+            results[c.sig] = [best[1][0], best[1][1], best[2], best[3], best[4], best[5][0], best[5][1], round(best[0], 2), round(base, 2)]
             if verbose:
-                print(f'{c.sig:44s} default {base:8.1f} us -> {best[1]} ks={best[2]} kw={best[3]} st={best[4]} {best[0]:8.1f} us', flush=True)
+                print(f'{c.sig:44s} default {base:8.1f} us -> {best[1]} ks={best[2]} kw={best[3]} st={best[4]} tail={best[5]} {best[0]:8.1f} us', flush=True)
         del big_ws
         self.retune()
         return results

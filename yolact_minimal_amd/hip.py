@@ -45,7 +45,7 @@ class ConvDesc(ctypes.Structure):
                 ('seg', ConvSeg * 3), ('tile_m', ctypes.c_int32), ('tile_n', ctypes.c_int32),
                 ('ksplit', ctypes.c_int32), ('kwaves', ctypes.c_int32), ('transposed', ctypes.c_int32),
                 ('stages', ctypes.c_int32), ('bn_sum', ctypes.c_void_p), ('bn_sumsq', ctypes.c_void_p),
-                ('tile_counters', ctypes.c_void_p)]
+                ('tile_counters', ctypes.c_void_p), ('tail_tiles', ctypes.c_int32), ('tail_ksplit', ctypes.c_int32)]
 
 
 class WgradDesc(ctypes.Structure):
@@ -174,7 +174,13 @@ def fold_bn(gamma, beta, mean, var, eps):
 
 
 def conv_workspace_bytes(desc):
-    return lib().ym_conv2d_workspace_bytes(ctypes.byref(desc))
+    """Bytes of scratch ym_conv2d_fwd needs for this descriptor (0 = none); raises if the descriptor is invalid."""
+    n = lib().ym_conv2d_workspace_bytes(ctypes.byref(desc))
+    if n == 0 and (desc.ksplit > 1 or desc.tail_tiles > 0) and desc.kwaves == 0:
+        err = lib().ym_last_error().decode()
+        if err and 'conv' in err and desc.tail_tiles > 0:
+            raise RuntimeError(f'ym_conv2d_workspace_bytes: {err}')
+    return n
 
 
 TILE_COUNTERS = 16384     # int32 entries the engines allocate for ym_conv_desc.tile_counters

@@ -51,18 +51,25 @@ def _configure_conv(d, key):
     if hit is None and _TUNING:
         M, nkt = d.B * d.Ho * d.Wo, d.k_pad // 32
         big = scratch(torch.device('cuda', torch.cuda.current_device()), 1 << 28)
-        cands = [((0, 0), 0, 0, 0)]
+        d.tile_counters = _tile_counters(torch.device('cuda', torch.cuda.current_device()))
+        cands = [((0, 0), 0, 0, 0, (0, 0))]
         for tm, tn in ((128, 128), (128, 64), (64, 128), (64, 64)):
             wgs = -(-M // tm) * -(-d.Cout // tn)
             for ks in (1, 2, 3, 4, 6, 8, 12, 16):
                 if ks > 1 and (wgs >= 1024 or ks * 2 > nkt or wgs * ks > 8192):
                     continue
-                cands.append(((tm, tn), ks, 0, 2))
+                cands.append(((tm, tn), ks, 0, 2, (0, 0)))
                 if (tm, tn) == (64, 64) and nkt // ks >= 3:
-                    cands.append(((tm, tn), ks, 0, 3))
-        best = (1e30, (0, 0), 0, 0, 0)
-        for tile, ks, kwv, stg in cands:
+                    cands.append(((tm, tn), ks, 0, 3, (0, 0)))
+            if 256 < wgs <= hip.TILE_COUNTERS:          # split the last partial round of tiles (ym_conv_desc.tail_tiles)
+                for r in sorted({wgs % 256, wgs % 512} - {0}):
+                    for ts in (2, 3, 4, 6, 8):
+                        if ts * 2 <= nkt and r * ts <= 2048:
+                            cands.append(((tm, tn), 1, 0, 2, (r, ts)))
+        best = (1e30, (0, 0), 0, 0, 0, (0, 0))
+        for tile, ks, kwv, stg, tail in cands:
             d.tile_m, d.tile_n, d.ksplit, d.kwaves, d.stages = tile[0], tile[1], ks, kwv, stg
+            d.tail_tiles, d.tail_ksplit = tail
             if hip.conv_workspace_bytes(d) > big.numel():
                 continue
             try:
@@ -70,14 +77,15 @@ def _configure_conv(d, key):
             except RuntimeError:
                 continue
             if t < best[0] * 0.98:
-                best = (t, tile, ks, kwv, stg)
-        hit = [best[1][0], best[1][1], best[2], best[3], best[4]]
+                best = (t, tile, ks, kwv, stg, tail)
+        hit = [best[1][0], best[1][1], best[2], best[3], best[4], best[5][0], best[5][1]]
         _table()[key] = hit
         _new_entries[key] = hit
     if hit is not None:
         d.tile_m, d.tile_n, d.ksplit = hit[0], hit[1], hit[2]
         d.kwaves = hit[3] if len(hit) > 3 else 0
         d.stages = hit[4] if len(hit) > 4 else 0
+        d.tail_tiles, d.tail_ksplit = (hit[5], hit[6]) if len(hit) > 6 else (0, 0)
 
 
 def _configure_wgrad(d, key):
