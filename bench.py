@@ -137,6 +137,60 @@ def conv_roofline(engine, img, iters=5):
     return flops, secs, len(convs), layers
 
 
+def eval_metrics_bench(device, n=100, g=15, h=480, w=640, iters=20, cpu=True):
+    """Next-row f2: `prep_metrics` (mask IoU 100 x 15 masks at 480x640 + box IoU + matching over 10 thresholds) per image.
+    HBM roofline of the mask-IoU kernel: every mask is read once = (n + g) * h * w * 4 bytes."""
+    from oracle import metrics_ref as M                  # synthetic-input generator + the CPU baseline leg
+    from yolact_minimal_amd.utils import common_utils as C
+    from yolact_minimal_amd.utils.box_utils import mask_iou
+    thres = [x / 100 for x in range(50, 100, 5)]
+    ids, scores, boxes, masks, gt, gt_masks, h, w = M.synth_eval_case(1, n, g, h, w, 10)
+    d = [boxes.to(device), masks.to(device), gt.to(device), gt_masks.to(device)]
+    a, b = d[1].reshape(n, -1), d[3].reshape(g, -1)
+    for _ in range(3):
+        mask_iou(a, b, to_cpu=False)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        mask_iou(a, b, to_cpu=False)
+    e1.record()
+    torch.cuda.synchronize()
+    t_iou = e0.elapsed_time(e1) / iters * 1e-3
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        ap = {k: [[C.APDataObject() for _ in range(10)] for _ in thres] for k in ('box', 'mask')}
+        C.prep_metrics(ap, ids, scores, d[0], d[1], d[2].clone(), d[3], h, w, thres)
+    torch.cuda.synchronize()
+    t_prep = (time.perf_counter() - t0) / iters
+    nbytes = (n + g) * h * w * 4
+    out = dict(workload=f'{n} predicted x {g} gt masks at {h}x{w}, 10 IoU thresholds', mask_iou_us=round(t_iou * 1e6, 1),
+               mask_iou_gbs=round(nbytes / t_iou / 1e9, 1), frac_hbm_peak=round(nbytes / t_iou / 8e12, 4),
+               prep_metrics_ms=round(t_prep * 1e3, 3))
+    # next-row f3: COCO RLE of the same 100 masks (two passes over each mask = 2 * n*h*w*4 bytes; strings cross PCIe)
+    for _ in range(2):
+        rles = C.rle_encode(d[1])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        rles = C.rle_encode(d[1])
+    t_rle = (time.perf_counter() - t0) / iters
+    out.update(rle_encode_ms=round(t_rle * 1e3, 3), rle_gbs=round(2 * n * h * w * 4 / t_rle / 1e9, 1),
+               rle_bytes_per_image=sum(len(r['counts']) for r in rles), dense_mask_bytes_per_image=n * h * w * 4)
+    if cpu:
+        from oracle import rle_ref as R
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ref = M.new_ap_data(10, len(thres))
+            M.prep_metrics(ref, ids, scores, boxes, masks, gt, gt_masks, h, w, thres)
+        out['cpu_oracle_prep_metrics_ms'] = round((time.perf_counter() - t0) / 3 * 1e3, 2)
+        mk = masks.numpy()
+        t0 = time.perf_counter()
+        ref_rle = [R.encode(mk[i]) for i in range(n)]
+        out['cpu_oracle_rle_ms'] = round((time.perf_counter() - t0) * 1e3, 2)
+        out['rle_equal_to_oracle'] = ref_rle == rles
+    return out
+
+
 def train_bench(cfg_name, img_size, batch, steps, warmup, world, local_rank, device, barrier):
     """DDP training: one step = forward + loss + backward (+ RCCL gradient all-reduce overlapped by DDP hooks) +
     SGD step on `batch` synthetic images per GPU (targets: 4 boxes + rectangular masks per image)."""
@@ -274,6 +328,8 @@ def main():
                 extra[f'{name}_bs{b}'] = dict(img_s=round(b * 8 / t2, 1), forward_only_img_s=round(b / tf2, 1),
                                               forward_tflops=round(fl2 / tf2 / 1e12, 2),
                                               frac_f32_mfma_peak=round(fl2 / tf2 / 1e12 / F32_MFMA_PEAK_TFLOPS, 4))
+        if not args.no_extra and world == 1:
+            extra['eval_metrics'] = eval_metrics_bench(device, cpu=not args.no_cpu_baseline)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.cfg, args.img_size)

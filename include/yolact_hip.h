@@ -106,6 +106,29 @@ int ym_conv2d_tile_counters(const ym_conv_desc* d);   /* output tiles of the cho
 int ym_conv2d_fuses_bn_stats(const ym_conv_desc* d);
 int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t workspace_bytes, ym_stream_t s);
 
+/* ---- evaluation inner products right after after_nms (next row f2) -----------------------------------------------
+ * mask_iou (utils/box_utils.py:189-200): masks_a [n][P], masks_b [g][P] fp32 in {0,1} (P = img_h*img_w < 2^24) ->
+ * iou [n][g] = inter / ((area_a + area_b) - inter), the reference's fp32 matmul evaluated as popcounts of bit rows
+ * (exact, so bit-identical; 0/0 -> NaN).  Every mask is read from HBM once. */
+size_t ym_mask_iou_workspace_bytes(int n, int g);
+int ym_mask_iou(const float* masks_a, int n, const float* masks_b, int g, int64_t P, float* iou, void* workspace,
+                size_t workspace_bytes, ym_stream_t s);
+/* box_iou (utils/box_utils.py:8-37) of corner boxes [n][4] x [g][4] -> [n][g]. */
+int ym_box_iou(const float* boxes_a, int n, const float* boxes_b, int g, float* iou, ym_stream_t s);
+/* The matching loop of prep_metrics (utils/common_utils.py:186-216) for both IoU types and every threshold at once:
+ * matched[type][t][i] = 1 iff prediction i (visited in order, class pred_cls[i]) found an unused gt of its class with
+ * IoU > thresholds[t] (largest such IoU; double comparison like the python floats).  g <= 512. */
+int ym_match_detections(const float* iou_box, const float* iou_mask, const int32_t* pred_cls, const int32_t* gt_cls, int n,
+                        int g, const double* thresholds, int T, int num_classes, uint8_t* matched, ym_stream_t s);
+
+/* COCO RLE of n binary masks [n][H][W] (fp32, nonzero = foreground), next row f3: what pycocotools.mask.encode(
+ * np.asfortranarray(mask)) + .decode('ascii') yield in MakeJson.add_mask (utils/common_utils.py:88-96).  Per mask i:
+ * counts[i*cap_runs .. +nruns[i]) = column-major run lengths starting with the zeros run, and the compressed ASCII string
+ * str[i*cap_str .. +str_len[i]).  If a mask needs more than cap_runs runs (or cap_str bytes) nruns[i] still holds the
+ * number of runs and str_len[i] = -1: call again with larger buffers.  W <= 4096; workspace >= n*cap_runs*4 bytes. */
+int ym_rle_encode(const float* masks, int n, int H, int W, uint32_t* counts, int cap_runs, int32_t* nruns, uint8_t* str,
+                  int cap_str, int32_t* str_len, void* workspace, size_t workspace_bytes, ym_stream_t s);
+
 /* ---- training: weight gradient, batch-norm with batch statistics, small backward ops, SGD -------------------
  * These replace what autograd + ATen/cuDNN execute for `loss_total.backward()` / `optimizer.step()`
  * (reference train.py:124-130) and nn.BatchNorm2d in train mode (modules/resnet.py:10-14,46). */

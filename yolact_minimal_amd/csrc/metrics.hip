@@ -1,0 +1,173 @@
+// Evaluation inner products right after after_nms: mask IoU of the predicted binary masks against the
+// ground-truth masks (reference utils/box_utils.py:189-200: a [n,HW]x[HW,g] fp32 matmul on {0,1} masks), pixel-box IoU
+// (utils/box_utils.py:8-37) and the greedy per-class matching of prep_metrics (utils/common_utils.py:174-216).
+// The masks are {0,1}, so the matmul is a popcount of ANDed bit rows: HBM-bound (every mask read exactly once, 123 MB for 100
+// masks at 480x640), exact in integers -> the IoU is bit-identical to the reference's fp32 result (counts < 2^24).
+#pragma clang fp contract(off)
+#include "ym_common.h"
+
+namespace {
+
+constexpr int CHUNK = 1024;            // pixels per workgroup pass = 16 x 64-bit words per mask row (2 x 17 KB of LDS)
+constexpr int WORDS = CHUNK / 64;
+constexpr int MAXR = 128;              // rows of each side held in LDS at once
+
+// bits of 256 consecutive pixels of one mask row (lane l holds pixels 4l..4l+3): four ballots = four 64-bit words.  The bit
+// order inside a chunk is a fixed permutation of the pixel order, the same for both operands, so popcount(a & b) is unchanged.
+__device__ __forceinline__ void pack256(const float* __restrict__ row, long long p0, long long P, int lane, unsigned long long out[4]) {
+    const long long p = p0 + 4 * lane;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (p + 3 < P) {
+        v = *reinterpret_cast<const f32x4*>(row + p);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (p + e < P) v[e] = row[p + e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[e] = __ballot(v[e] != 0.f);
+}
+
+// grid: (pixel chunks, groups of 128 gt rows).  inter [n][g] / area_a [n] / area_b [g] are int32 accumulators (zeroed by the host).
+__global__ __launch_bounds__(512) void k_mask_inter(const float* __restrict__ A, int n, const float* __restrict__ Bm, int g, long long P,
+                                                    int* __restrict__ inter, int* __restrict__ area_a, int* __restrict__ area_b) {
+    __shared__ unsigned long long sa[MAXR][WORDS + 1];
+    __shared__ unsigned long long sb[MAXR][WORDS + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const long long p0 = (long long)blockIdx.x * CHUNK;
+    const int g0 = blockIdx.y * MAXR, gn = min(MAXR, g - g0);
+    const bool aligned = (P & 3) == 0;         // float4 loads need 16-byte aligned rows
+    for (int a0 = 0; a0 < n; a0 += MAXR) {
+        const int an = min(MAXR, n - a0);
+        __syncthreads();
+        // pack rows: task = (row, 256-pixel segment)
+        const int tasks = (an + (a0 == 0 ? gn : 0)) * (CHUNK / 256);
+        for (int t = wave; t < tasks; t += nw) {
+            const int r = t / (CHUNK / 256), seg = t - r * (CHUNK / 256);
+            const bool is_a = r < an;
+            const float* row = is_a ? A + (size_t)(a0 + r) * P : Bm + (size_t)(g0 + r - an) * P;
+            unsigned long long w[4];
+            if (aligned) {
+                pack256(row, p0 + seg * 256, P, lane, w);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const long long p = p0 + seg * 256 + e * 64 + lane;
+                    w[e] = __ballot(p < P && row[p] != 0.f);
+                }
+            }
+            if (lane < 4) {
+                unsigned long long* dst = is_a ? sa[r] : sb[r - an];
+                dst[seg * 4 + lane] = w[lane];
+            }
+            // areas (once per row: a rows only from the first gt group, gt rows only from the first a pass)
+            if (lane == 0) {
+                const int c = __popcll(w[0]) + __popcll(w[1]) + __popcll(w[2]) + __popcll(w[3]);
+                if (c) {
+                    if (is_a) { if (blockIdx.y == 0) atomicAdd(&area_a[a0 + r], c); }
+                    else atomicAdd(&area_b[g0 + r - an], c);
+                }
+            }
+        }
+        __syncthreads();
+        for (int pr = tid; pr < an * gn; pr += blockDim.x) {
+            const int i = pr / gn, j = pr - i * gn;
+            int c = 0;
+#pragma unroll 8
+            for (int w = 0; w < WORDS; ++w) c += __popcll(sa[i][w] & sb[j][w]);
+            if (c) atomicAdd(&inter[(size_t)(a0 + i) * g + g0 + j], c);
+        }
+    }
+}
+
+__global__ void k_mask_iou_finalize(const int* __restrict__ inter, const int* __restrict__ area_a, const int* __restrict__ area_b,
+                                    int n, int g, float* __restrict__ iou) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * g) return;
+    const int i = e / g, j = e - i * g;
+    const float it = (float)inter[e];
+    const float uni = ((float)area_a[i] + (float)area_b[j]) - it;          // (area1.t() + area2) - intersection
+    iou[e] = __fdiv_rn(it, uni);                                            // 0/0 -> NaN like the reference
+}
+
+__global__ void k_box_iou(const float* __restrict__ a, const float* __restrict__ b, int n, int g, float* __restrict__ iou) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * g) return;
+    const int i = e / g, j = e - i * g;
+    const float* p = a + (size_t)i * 4;
+    const float* q = b + (size_t)j * 4;
+    float w = fminf(p[2], q[2]) - fmaxf(p[0], q[0]);
+    float h = fminf(p[3], q[3]) - fmaxf(p[1], q[1]);
+    w = w < 0.f ? 0.f : w;
+    h = h < 0.f ? 0.f : h;
+    const float inter = w * h;
+    const float aa = (p[2] - p[0]) * (p[3] - p[1]), ab = (q[2] - q[0]) * (q[3] - q[1]);
+    iou[e] = __fdiv_rn(inter, (aa + ab) - inter);
+}
+
+// prep_metrics' matching (utils/common_utils.py:186-216): block = (iou type, threshold), thread = class.  Predictions are
+// visited in their given order; each takes the unused same-class gt with the largest IoU strictly above the running maximum
+// (which starts AT the threshold; python compares float32->double IoUs with the double threshold).
+constexpr int MAXG = 512;
+__global__ __launch_bounds__(128) void k_match_detections(const float* __restrict__ iou_box, const float* __restrict__ iou_mask,
+                                                          const int* __restrict__ pred_cls, const int* __restrict__ gt_cls, int n, int g,
+                                                          const double* __restrict__ thr, int T, int num_classes,
+                                                          uint8_t* __restrict__ matched) {
+    const int type = blockIdx.x / T, k = blockIdx.x - type * T;
+    const float* iou = type == 0 ? iou_box : iou_mask;
+    uint8_t* out = matched + ((size_t)type * T + k) * n;
+    const double th = thr[k];
+    for (int c = threadIdx.x; c < num_classes; c += blockDim.x) {
+        unsigned used[MAXG / 32];
+#pragma unroll
+        for (int w = 0; w < MAXG / 32; ++w) used[w] = 0u;
+        for (int i = 0; i < n; ++i) {
+            if (pred_cls[i] != c) continue;
+            double best = th;
+            int bj = -1;
+            for (int j = 0; j < g; ++j) {
+                if (gt_cls[j] != c || ((used[j >> 5] >> (j & 31)) & 1u)) continue;
+                const double v = (double)iou[(size_t)i * g + j];
+                if (v > best) { best = v; bj = j; }
+            }
+            if (bj >= 0) used[bj >> 5] |= 1u << (bj & 31);
+            out[i] = bj >= 0 ? 1 : 0;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t ym_mask_iou_workspace_bytes(int n, int g) { return ((size_t)n * g + n + g) * sizeof(int) + 256; }
+
+extern "C" int ym_mask_iou(const float* masks_a, int n, const float* masks_b, int g, int64_t P, float* iou, void* workspace,
+                           size_t workspace_bytes, ym_stream_t s) {
+    YM_REQUIRE(masks_a && masks_b && iou && workspace, "mask_iou: null pointer");
+    YM_REQUIRE(n > 0 && g > 0 && P > 0 && P < (1ll << 24), "mask_iou: n, g > 0 and 0 < P < 2^24 (exact fp32 counts)");
+    YM_REQUIRE((long long)n * g < (1ll << 24), "mask_iou: n*g too large");
+    if (workspace_bytes < ym_mask_iou_workspace_bytes(n, g)) { ym_set_error("mask_iou: workspace too small"); return YM_ENOSPC; }
+    hipStream_t st = (hipStream_t)s;
+    int* inter = (int*)workspace;
+    int* area_a = inter + (size_t)n * g;
+    int* area_b = area_a + n;
+    (void)hipMemsetAsync(workspace, 0, ((size_t)n * g + n + g) * sizeof(int), st);
+    const dim3 grid((unsigned)((P + CHUNK - 1) / CHUNK), (unsigned)((g + MAXR - 1) / MAXR));
+    hipLaunchKernelGGL(k_mask_inter, grid, dim3(512), 0, st, masks_a, n, masks_b, g, (long long)P, inter, area_a, area_b);
+    hipLaunchKernelGGL(k_mask_iou_finalize, dim3((n * g + 255) / 256), dim3(256), 0, st, inter, area_a, area_b, n, g, iou);
+    return ym_check_launch("mask_iou");
+}
+
+extern "C" int ym_box_iou(const float* boxes_a, int n, const float* boxes_b, int g, float* iou, ym_stream_t s) {
+    YM_REQUIRE(boxes_a && boxes_b && iou && n > 0 && g > 0, "box_iou: bad args");
+    hipLaunchKernelGGL(k_box_iou, dim3((n * g + 255) / 256), dim3(256), 0, (hipStream_t)s, boxes_a, boxes_b, n, g, iou);
+    return ym_check_launch("box_iou");
+}
+
+extern "C" int ym_match_detections(const float* iou_box, const float* iou_mask, const int32_t* pred_cls, const int32_t* gt_cls, int n,
+                                   int g, const double* thresholds, int T, int num_classes, uint8_t* matched, ym_stream_t s) {
+    YM_REQUIRE(iou_box && iou_mask && pred_cls && gt_cls && thresholds && matched, "match_detections: null pointer");
+    YM_REQUIRE(n > 0 && g > 0 && g <= MAXG && T > 0 && num_classes > 0, "match_detections: need 0 < g <= %d", MAXG);
+    hipLaunchKernelGGL(k_match_detections, dim3(2 * T), dim3(128), 0, (hipStream_t)s, iou_box, iou_mask, pred_cls, gt_cls, n, g,
+                       thresholds, T, num_classes, matched);
+    return ym_check_launch("match_detections");
+}

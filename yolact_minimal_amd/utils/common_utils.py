@@ -1,0 +1,190 @@
+"""Evaluation step right after `after_nms`: `prep_metrics` with its IoU caches and greedy matching on
+the device.  Reference: `/root/reference/utils/common_utils.py:107-262` (`APDataObject`, `prep_metrics`, `calc_map`), called
+from `eval.py:69,106`.
+
+The reference computes `mask_iou` / `box_iou` on the device, copies both [n, g] matrices to the host and walks a triple python
+loop (class x threshold x iou type) with a `.item()` per candidate pair.  Here: `ym_mask_iou` (bit-row popcounts, each mask read
+once), `ym_box_iou`, then `ym_match_detections` resolves all 2 x T matchings in one launch; the host reads back ONE uint8
+tensor [2, T, n] and only does the AP bookkeeping (lists of (score, is_true)), which stays Python like the reference.
+"""
+import ctypes
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .. import hip
+from .box_utils import box_iou, mask_iou
+
+
+class APDataObject:
+    """Stores all the information necessary to calculate the AP for one IoU and one class (common_utils.py:107-169)."""
+
+    def __init__(self):
+        self.data_points = []
+        self.num_gt_positives = 0
+
+    def push(self, score, is_true):
+        self.data_points.append((score, is_true))
+
+    def add_gt_positives(self, num_positives):
+        self.num_gt_positives += num_positives
+
+    def is_empty(self):
+        return len(self.data_points) == 0 and self.num_gt_positives == 0
+
+    def get_ap(self):
+        if self.num_gt_positives == 0:
+            return 0
+        self.data_points.sort(key=lambda x: -x[0])
+        precisions, recalls = [], []
+        num_true = num_false = 0
+        for datum in self.data_points:
+            if datum[1]:
+                num_true += 1
+            else:
+                num_false += 1
+            precisions.append(num_true / (num_true + num_false))
+            recalls.append(num_true / self.num_gt_positives)
+        for i in range(len(precisions) - 1, 0, -1):          # monotone envelope, like COCOeval
+            if precisions[i] > precisions[i - 1]:
+                precisions[i - 1] = precisions[i]
+        y_range = [0] * 101                                   # 101-point Riemann sum over recall 0.00 .. 1.00
+        x_range = np.array([x / 100 for x in range(101)])
+        indices = np.searchsorted(np.array(recalls), x_range, side='left')
+        for bar_idx, precision_idx in enumerate(indices):
+            if precision_idx < len(precisions):
+                y_range[bar_idx] = precisions[precision_idx]
+        return sum(y_range) / len(y_range)
+
+
+def match_detections(iou_box, iou_mask, ids_p, gt_classes, iou_thres, num_classes):
+    """[2, T, n] uint8 on the host: does prediction i find an unused same-class gt above threshold t (box / mask IoU)?"""
+    dev = iou_box.device
+    n, g, t = iou_box.shape[0], iou_box.shape[1], len(iou_thres)
+    pred = torch.tensor(ids_p, dtype=torch.int32, device=dev)
+    gtc = torch.tensor(gt_classes, dtype=torch.int32, device=dev)
+    thr = torch.tensor(iou_thres, dtype=torch.float64, device=dev)
+    matched = torch.zeros(2, t, n, dtype=torch.uint8, device=dev)
+    hip.check(hip.lib().ym_match_detections(hip.ptr(iou_box), hip.ptr(iou_mask), hip.ptr(pred, torch.int32),
+                                            hip.ptr(gtc, torch.int32), n, g, hip.ptr(thr, torch.float64), t, num_classes,
+                                            ctypes.c_void_p(matched.data_ptr()), hip.stream_ptr()), 'ym_match_detections')
+    return matched.cpu().numpy()
+
+
+def prep_metrics(ap_data, ids_p, classes_p, boxes_p, masks_p, gt, gt_masks, height, width, iou_thres):
+    """Same arguments, mutations and `ap_data` updates as the reference (common_utils.py:174-216): `gt` boxes are scaled to
+    pixels IN PLACE; classes are visited as `set(ids_p + gt_classes)`; per class / threshold / iou type the gt positives are
+    added and one (score, is_true) is pushed per prediction of that class, in prediction order."""
+    gt_boxes = gt[:, :4]
+    gt_boxes[:, [0, 2]] *= width
+    gt_boxes[:, [1, 3]] *= height
+    gt_classes = gt[:, 4].int().tolist()
+    gt_masks = gt_masks.reshape(-1, height * width)
+    masks_p = masks_p.reshape(-1, height * width)
+    ids_p = [int(i) for i in ids_p]
+
+    iou_mask = mask_iou(masks_p, gt_masks, to_cpu=False)
+    iou_box = box_iou(boxes_p.float(), gt_boxes.float())
+    num_classes = max(ids_p + gt_classes) + 1
+    matched = match_detections(iou_box, iou_mask, ids_p, gt_classes, iou_thres, num_classes)
+
+    for _class in set(ids_p + gt_classes):
+        num_gt_per_class = gt_classes.count(_class)
+        for iou_idx in range(len(iou_thres)):
+            for type_idx, iou_type in enumerate(('box', 'mask')):
+                ap_obj = ap_data[iou_type][iou_idx][_class]
+                ap_obj.add_gt_positives(num_gt_per_class)
+                for i, pred_class in enumerate(ids_p):
+                    if pred_class == _class:
+                        ap_obj.push(classes_p[i], bool(matched[type_idx, iou_idx, i]))
+
+
+def calc_map(ap_data, iou_thres, num_classes, step):
+    """common_utils.py:219-262; the table is returned as plain rows (terminaltables is a formatting dependency)."""
+    aps = [{'box': [], 'mask': []} for _ in iou_thres]
+    for _class in range(num_classes):
+        for iou_idx in range(len(iou_thres)):
+            for iou_type in ('box', 'mask'):
+                ap_obj = ap_data[iou_type][iou_idx][_class]
+                if not ap_obj.is_empty():
+                    aps[iou_idx][iou_type].append(ap_obj.get_ap())
+    all_maps = {'box': OrderedDict(), 'mask': OrderedDict()}
+    for iou_type in ('box', 'mask'):
+        all_maps[iou_type]['all'] = 0
+        for i, threshold in enumerate(iou_thres):
+            vals = aps[i][iou_type]
+            all_maps[iou_type][int(threshold * 100)] = sum(vals) / len(vals) * 100 if len(vals) > 0 else 0
+        all_maps[iou_type]['all'] = sum(all_maps[iou_type].values()) / (len(all_maps[iou_type].values()) - 1)
+    row1 = list(all_maps['box'].keys())
+    row1.insert(0, f'{step // 1000}k' if step else '')
+    row2 = [round(a, 2) for a in all_maps['box'].values()]
+    row2.insert(0, 'box')
+    row3 = [round(a, 2) for a in all_maps['mask'].values()]
+    row3.insert(0, 'mask')
+    table = '\n'.join(' | '.join(str(c) for c in row) for row in (row1, row2, row3))
+    return table, row2, row3
+
+
+def rle_encode(masks, cap_runs=4096):
+    """COCO RLE of binary masks [n, h, w] on the device (`ym_rle_encode`) -> list of {'size': [h, w], 'counts': str}, i.e.
+    `pycocotools.mask.encode(np.asfortranarray(m.astype(np.uint8)))` with `counts` decoded to ascii (common_utils.py:90-91).
+    Only the compressed strings (a few hundred bytes per mask) cross PCIe."""
+    if not masks.is_cuda:
+        raise RuntimeError('yolact_minimal_amd has no CPU path: rle_encode needs CUDA/HIP tensors')
+    m = masks.to(torch.float32).contiguous()
+    n, h, w = m.shape
+    dev = m.device
+    while True:
+        cap_str = cap_runs * 4
+        counts = torch.empty(n, cap_runs, dtype=torch.int32, device=dev)
+        ws = torch.empty(n, cap_runs, dtype=torch.int32, device=dev)
+        meta = torch.empty(2, n, dtype=torch.int32, device=dev)
+        out = torch.empty(n, cap_str, dtype=torch.uint8, device=dev)
+        hip.check(hip.lib().ym_rle_encode(hip.ptr(m), n, h, w, ctypes.c_void_p(counts.data_ptr()), cap_runs,
+                                          ctypes.c_void_p(meta[0].data_ptr()), ctypes.c_void_p(out.data_ptr()), cap_str,
+                                          ctypes.c_void_p(meta[1].data_ptr()), ctypes.c_void_p(ws.data_ptr()), ws.numel() * 4,
+                                          hip.stream_ptr()), 'ym_rle_encode')
+        nruns, slen = meta.cpu().tolist()
+        if min(slen) >= 0:
+            break
+        cap_runs = max(cap_runs * 2, max(nruns) + 1)            # a mask was busier than the buffers: grow and redo
+    longest = max(slen)
+    host = out[:, :max(longest, 1)].cpu().numpy()
+    return [{'size': [h, w], 'counts': host[i, :slen[i]].tobytes().decode('ascii')} for i in range(n)]
+
+
+class MakeJson:
+    """Detection dumps for the COCO API (reference common_utils.py:66-104, eval.py:59-67).  `add_mask` accepts the dense
+    [h, w] mask like the reference (host or device) or an RLE dict from `rle_encode` (batch the image's masks there)."""
+
+    def __init__(self, coco_label_map=None):
+        from ..config import COCO_LABEL_MAP
+        self.bbox_data, self.mask_data = [], []
+        self.coco_cats = {}
+        for coco_id, real_id in (COCO_LABEL_MAP if coco_label_map is None else coco_label_map).items():
+            self.coco_cats[real_id - 1] = coco_id
+
+    def _cat(self, category_id):
+        return self.coco_cats[int(category_id)]
+
+    def add_bbox(self, image_id, category_id, bbox, score):
+        bbox = [bbox[0], bbox[1], bbox[2] - bbox[0], bbox[3] - bbox[1]]
+        bbox = [round(float(x) * 10) / 10 for x in bbox]        # nearest 10th, as COCO suggests
+        self.bbox_data.append({'image_id': int(image_id), 'category_id': self._cat(category_id), 'bbox': bbox,
+                               'score': float(score)})
+
+    def add_mask(self, image_id, category_id, segmentation, score):
+        if not isinstance(segmentation, dict):
+            seg = torch.as_tensor(segmentation)
+            if not seg.is_cuda:
+                seg = seg.cuda()
+            segmentation = rle_encode(seg[None])[0]
+        self.mask_data.append({'image_id': int(image_id), 'category_id': self._cat(category_id),
+                               'segmentation': segmentation, 'score': float(score)})
+
+    def dump(self, bbox_path='results/bbox_detections.json', mask_path='results/mask_detections.json'):
+        import json
+        for data, path in ((self.bbox_data, bbox_path), (self.mask_data, mask_path)):
+            with open(path, 'w') as f:
+                json.dump(data, f)
