@@ -110,7 +110,7 @@ int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t workspace_bytes
  * mask_iou (utils/box_utils.py:189-200): masks_a [n][P], masks_b [g][P] fp32 in {0,1} (P = img_h*img_w < 2^24) ->
  * iou [n][g] = inter / ((area_a + area_b) - inter), the reference's fp32 matmul evaluated as popcounts of bit rows
  * (exact, so bit-identical; 0/0 -> NaN).  Every mask is read from HBM once. */
-size_t ym_mask_iou_workspace_bytes(int n, int g);
+size_t ym_mask_iou_workspace_bytes(int n, int g, int64_t P);
 int ym_mask_iou(const float* masks_a, int n, const float* masks_b, int g, int64_t P, float* iou, void* workspace,
                 size_t workspace_bytes, ym_stream_t s);
 /* box_iou (utils/box_utils.py:8-37) of corner boxes [n][4] x [g][4] -> [n][g]. */

@@ -12,23 +12,11 @@ constexpr int CHUNK = 1024;            // pixels per workgroup pass = 16 x 64-bi
 constexpr int WORDS = CHUNK / 64;
 constexpr int MAXR = 128;              // rows of each side held in LDS at once
 
-// bits of 256 consecutive pixels of one mask row (lane l holds pixels 4l..4l+3): four ballots = four 64-bit words.  The bit
-// order inside a chunk is a fixed permutation of the pixel order, the same for both operands, so popcount(a & b) is unchanged.
-__device__ __forceinline__ void pack256(const float* __restrict__ row, long long p0, long long P, int lane, unsigned long long out[4]) {
-    const long long p = p0 + 4 * lane;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (p + 3 < P) {
-        v = *reinterpret_cast<const f32x4*>(row + p);
-    } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (p + e < P) v[e] = row[p + e];
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) out[e] = __ballot(v[e] != 0.f);
-}
-
-// grid: (pixel chunks, groups of 128 gt rows).  inter [n][g] / area_a [n] / area_b [g] are int32 accumulators (zeroed by the host).
+// Bits of a mask-row chunk: lane l of a 256-pixel segment holds pixels 4l..4l+3, one ballot per component = four 64-bit
+// words.  The bit order inside a chunk is a fixed permutation of the pixel order, the same for both operands, so
+// popcount(a & b) is unchanged.
+// grid: (pixel chunks, groups of 128 gt rows).  Every workgroup writes its own partial counts inter[chunk][n][g], area_a[chunk][n],
+// area_b[chunk][g] with plain stores (global atomics were the bottleneck: 1500 per workgroup); the finalize kernel sums the chunks.
 __global__ __launch_bounds__(512) void k_mask_inter(const float* __restrict__ A, int n, const float* __restrict__ Bm, int g, long long P,
                                                     int* __restrict__ inter, int* __restrict__ area_a, int* __restrict__ area_b) {
     __shared__ unsigned long long sa[MAXR][WORDS + 1];
@@ -37,35 +25,68 @@ __global__ __launch_bounds__(512) void k_mask_inter(const float* __restrict__ A,
     const long long p0 = (long long)blockIdx.x * CHUNK;
     const int g0 = blockIdx.y * MAXR, gn = min(MAXR, g - g0);
     const bool aligned = (P & 3) == 0;         // float4 loads need 16-byte aligned rows
+    inter += (size_t)blockIdx.x * n * g;
+    area_a += (size_t)blockIdx.x * n;
+    area_b += (size_t)blockIdx.x * g;
     for (int a0 = 0; a0 < n; a0 += MAXR) {
         const int an = min(MAXR, n - a0);
         __syncthreads();
-        // pack rows: task = (row, 256-pixel segment)
-        const int tasks = (an + (a0 == 0 ? gn : 0)) * (CHUNK / 256);
-        for (int t = wave; t < tasks; t += nw) {
-            const int r = t / (CHUNK / 256), seg = t - r * (CHUNK / 256);
-            const bool is_a = r < an;
-            const float* row = is_a ? A + (size_t)(a0 + r) * P : Bm + (size_t)(g0 + r - an) * P;
-            unsigned long long w[4];
-            if (aligned) {
-                pack256(row, p0 + seg * 256, P, lane, w);
-            } else {
+        // pack rows: one wave takes a whole row chunk (CHUNK/256 float4 loads per lane issued back to back, two rows per
+        // iteration = 8 independent 1 KB requests in flight per wave: the pass is HBM-latency bound otherwise)
+        constexpr int SEGS = CHUNK / 256;
+        const int rows = an + (a0 == 0 ? gn : 0);
+        for (int r = wave; r < rows; r += 2 * nw) {
+            unsigned long long w[2][SEGS][4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const long long p = p0 + seg * 256 + e * 64 + lane;
-                    w[e] = __ballot(p < P && row[p] != 0.f);
+            for (int u = 0; u < 2; ++u) {
+                const int rr = r + u * nw;
+                if (rr >= rows) continue;
+                const float* row = rr < an ? A + (size_t)(a0 + rr) * P : Bm + (size_t)(g0 + rr - an) * P;
+                if (aligned) {
+                    f32x4 v[SEGS];
+#pragma unroll
+                    for (int sg = 0; sg < SEGS; ++sg) {
+                        const long long p = p0 + sg * 256 + 4 * lane;
+                        v[sg] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (p + 3 < P) v[sg] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + p));
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (p + e < P) v[sg][e] = row[p + e];
+                        }
+                    }
+#pragma unroll
+                    for (int sg = 0; sg < SEGS; ++sg)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w[u][sg][e] = __ballot(v[sg][e] != 0.f);
+                } else {
+#pragma unroll
+                    for (int sg = 0; sg < SEGS; ++sg)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const long long p = p0 + sg * 256 + e * 64 + lane;
+                            w[u][sg][e] = __ballot(p < P && row[p] != 0.f);
+                        }
                 }
             }
-            if (lane < 4) {
-                unsigned long long* dst = is_a ? sa[r] : sb[r - an];
-                dst[seg * 4 + lane] = w[lane];
-            }
-            // areas (once per row: a rows only from the first gt group, gt rows only from the first a pass)
-            if (lane == 0) {
-                const int c = __popcll(w[0]) + __popcll(w[1]) + __popcll(w[2]) + __popcll(w[3]);
-                if (c) {
-                    if (is_a) { if (blockIdx.y == 0) atomicAdd(&area_a[a0 + r], c); }
-                    else atomicAdd(&area_b[g0 + r - an], c);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int rr = r + u * nw;
+                if (rr >= rows) continue;
+                const bool is_a = rr < an;
+                unsigned long long* dst = is_a ? sa[rr] : sb[rr - an];
+                int c = 0;
+#pragma unroll
+                for (int sg = 0; sg < SEGS; ++sg)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (lane == sg * 4 + e) dst[sg * 4 + e] = w[u][sg][e];
+                        c += __popcll(w[u][sg][e]);
+                    }
+                // areas (once per row: a rows only from the first gt group, gt rows only from the first a pass)
+                if (lane == 0) {
+                    if (is_a) { if (blockIdx.y == 0) area_a[a0 + rr] = c; }
+                    else area_b[g0 + rr - an] = c;
                 }
             }
         }
@@ -75,19 +96,34 @@ __global__ __launch_bounds__(512) void k_mask_inter(const float* __restrict__ A,
             int c = 0;
 #pragma unroll 8
             for (int w = 0; w < WORDS; ++w) c += __popcll(sa[i][w] & sb[j][w]);
-            if (c) atomicAdd(&inter[(size_t)(a0 + i) * g + g0 + j], c);
+            inter[(size_t)(a0 + i) * g + g0 + j] = c;
         }
     }
 }
 
-__global__ void k_mask_iou_finalize(const int* __restrict__ inter, const int* __restrict__ area_a, const int* __restrict__ area_b,
-                                    int n, int g, float* __restrict__ iou) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n * g) return;
-    const int i = e / g, j = e - i * g;
-    const float it = (float)inter[e];
-    const float uni = ((float)area_a[i] + (float)area_b[j]) - it;          // (area1.t() + area2) - intersection
-    iou[e] = __fdiv_rn(it, uni);                                            // 0/0 -> NaN like the reference
+// sum the per-chunk partials (exact integers) and apply the reference's formula; 64 pairs x 4 chunk slices per workgroup
+__global__ __launch_bounds__(256) void k_mask_iou_finalize(const int* __restrict__ inter, const int* __restrict__ area_a,
+                                                           const int* __restrict__ area_b, int chunks, int n, int g, float* __restrict__ iou) {
+    __shared__ int s_i[4][64], s_a[4][64], s_b[4][64];
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    int it = 0, aa = 0, ab = 0;
+    if (e < n * g) {
+        const int i = e / g, j = e - i * g;
+        for (int c = sl; c < chunks; c += 4) {
+            it += inter[(size_t)c * n * g + e];
+            aa += area_a[(size_t)c * n + i];
+            ab += area_b[(size_t)c * g + j];
+        }
+    }
+    s_i[sl][lane] = it; s_a[sl][lane] = aa; s_b[sl][lane] = ab;
+    __syncthreads();
+    if (sl == 0 && e < n * g) {
+        const float fi = (float)(s_i[0][lane] + s_i[1][lane] + s_i[2][lane] + s_i[3][lane]);
+        const float fa = (float)(s_a[0][lane] + s_a[1][lane] + s_a[2][lane] + s_a[3][lane]);
+        const float fb = (float)(s_b[0][lane] + s_b[1][lane] + s_b[2][lane] + s_b[3][lane]);
+        iou[e] = __fdiv_rn(fi, (fa + fb) - fi);          // inter / ((area1.t() + area2) - inter); 0/0 -> NaN like the reference
+    }
 }
 
 __global__ void k_box_iou(const float* __restrict__ a, const float* __restrict__ b, int n, int g, float* __restrict__ iou) {
@@ -138,22 +174,25 @@ __global__ __launch_bounds__(128) void k_match_detections(const float* __restric
 
 }  // namespace
 
-extern "C" size_t ym_mask_iou_workspace_bytes(int n, int g) { return ((size_t)n * g + n + g) * sizeof(int) + 256; }
+extern "C" size_t ym_mask_iou_workspace_bytes(int n, int g, int64_t P) {
+    const size_t chunks = (size_t)((P + CHUNK - 1) / CHUNK);
+    return chunks * ((size_t)n * g + n + g) * sizeof(int) + 256;
+}
 
 extern "C" int ym_mask_iou(const float* masks_a, int n, const float* masks_b, int g, int64_t P, float* iou, void* workspace,
                            size_t workspace_bytes, ym_stream_t s) {
     YM_REQUIRE(masks_a && masks_b && iou && workspace, "mask_iou: null pointer");
     YM_REQUIRE(n > 0 && g > 0 && P > 0 && P < (1ll << 24), "mask_iou: n, g > 0 and 0 < P < 2^24 (exact fp32 counts)");
     YM_REQUIRE((long long)n * g < (1ll << 24), "mask_iou: n*g too large");
-    if (workspace_bytes < ym_mask_iou_workspace_bytes(n, g)) { ym_set_error("mask_iou: workspace too small"); return YM_ENOSPC; }
+    if (workspace_bytes < ym_mask_iou_workspace_bytes(n, g, P)) { ym_set_error("mask_iou: workspace too small"); return YM_ENOSPC; }
     hipStream_t st = (hipStream_t)s;
+    const int chunks = (int)((P + CHUNK - 1) / CHUNK);
     int* inter = (int*)workspace;
-    int* area_a = inter + (size_t)n * g;
-    int* area_b = area_a + n;
-    (void)hipMemsetAsync(workspace, 0, ((size_t)n * g + n + g) * sizeof(int), st);
-    const dim3 grid((unsigned)((P + CHUNK - 1) / CHUNK), (unsigned)((g + MAXR - 1) / MAXR));
+    int* area_a = inter + (size_t)chunks * n * g;
+    int* area_b = area_a + (size_t)chunks * n;
+    const dim3 grid((unsigned)chunks, (unsigned)((g + MAXR - 1) / MAXR));
     hipLaunchKernelGGL(k_mask_inter, grid, dim3(512), 0, st, masks_a, n, masks_b, g, (long long)P, inter, area_a, area_b);
-    hipLaunchKernelGGL(k_mask_iou_finalize, dim3((n * g + 255) / 256), dim3(256), 0, st, inter, area_a, area_b, n, g, iou);
+    hipLaunchKernelGGL(k_mask_iou_finalize, dim3((n * g + 63) / 64), dim3(256), 0, st, inter, area_a, area_b, chunks, n, g, iou);
     return ym_check_launch("mask_iou");
 }
 

@@ -12,6 +12,7 @@ namespace {
 
 constexpr int NT = 1024;
 constexpr int MAXW = 4096;
+constexpr int UNR = 16;
 
 // exclusive prefix sum of one value per thread over the workgroup; returns the prefix, *total = sum of all
 __device__ __forceinline__ int block_exscan(int v, int* total, int* s_wave /*[NT/64 + 1]*/) {
@@ -50,8 +51,19 @@ __global__ __launch_bounds__(NT) void k_rle_encode(const float* __restrict__ mas
     // pass 1: transitions per column (the pixel before (0, x) in column-major order is (H-1, x-1); before (0,0): background)
     for (int x = tid; x < W; x += NT) {
         bool prev = x > 0 && m[(size_t)(H - 1) * W + x - 1] != 0.f;
-        int c = 0;
-        for (int y = 0; y < H; ++y) {
+        int c = 0, y = 0;
+        for (; y + UNR <= H; y += UNR) {          // UNR independent row loads in flight per lane (the walk is latency bound)
+            float v[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) v[u] = m[(size_t)(y + u) * W + x];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const bool cur = v[u] != 0.f;
+                c += cur != prev;
+                prev = cur;
+            }
+        }
+        for (; y < H; ++y) {
             const bool cur = m[(size_t)y * W + x] != 0.f;
             c += cur != prev;
             prev = cur;
@@ -80,8 +92,19 @@ __global__ __launch_bounds__(NT) void k_rle_encode(const float* __restrict__ mas
     // pass 2: positions of the transitions, in column-major order
     for (int x = tid; x < W; x += NT) {
         bool prev = x > 0 && m[(size_t)(H - 1) * W + x - 1] != 0.f;
-        int o = s_col[x];
-        for (int y = 0; y < H; ++y) {
+        int o = s_col[x], y = 0;
+        for (; y + UNR <= H; y += UNR) {
+            float v[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) v[u] = m[(size_t)(y + u) * W + x];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const bool cur = v[u] != 0.f;
+                if (cur != prev) pos[o++] = (unsigned)x * (unsigned)H + (unsigned)(y + u);
+                prev = cur;
+            }
+        }
+        for (; y < H; ++y) {
             const bool cur = m[(size_t)y * W + x] != 0.f;
             if (cur != prev) pos[o++] = (unsigned)x * (unsigned)H + (unsigned)y;
             prev = cur;

@@ -111,7 +111,7 @@ def lib():
         L.ym_mask_loss_workspace_bytes.argtypes = []
         L.ym_mask_loss_workspace_bytes.restype = sz
         L.ym_mask_loss_fwd_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp, vp, vp, sz, vp]
-        L.ym_mask_iou_workspace_bytes.argtypes = [i32, i32]
+        L.ym_mask_iou_workspace_bytes.argtypes = [i32, i32, i64]
         L.ym_mask_iou_workspace_bytes.restype = sz
         L.ym_mask_iou.argtypes = [vp, i32, vp, i32, i64, vp, vp, sz, vp]
         L.ym_box_iou.argtypes = [vp, i32, vp, i32, vp, vp]

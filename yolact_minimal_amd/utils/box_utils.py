@@ -50,7 +50,7 @@ def mask_iou(mask1, mask2, to_cpu=True):
     n, g, p = a.shape[0], b.shape[0], a.shape[1]
     out = torch.empty(n, g, device=a.device, dtype=torch.float32)
     if n and g:
-        nb = hip.lib().ym_mask_iou_workspace_bytes(n, g)
+        nb = hip.lib().ym_mask_iou_workspace_bytes(n, g, p)
         ws = torch.empty(nb, device=a.device, dtype=torch.uint8)
         hip.check(hip.lib().ym_mask_iou(hip.ptr(a), n, hip.ptr(b), g, p, hip.ptr(out), ctypes.c_void_p(ws.data_ptr()), nb,
                                         hip.stream_ptr()), 'ym_mask_iou')

@@ -89,15 +89,16 @@ def prep_metrics(ap_data, ids_p, classes_p, boxes_p, masks_p, gt, gt_masks, heig
     num_classes = max(ids_p + gt_classes) + 1
     matched = match_detections(iou_box, iou_mask, ids_p, gt_classes, iou_thres, num_classes)
 
+    flags = matched.astype(bool)
     for _class in set(ids_p + gt_classes):
         num_gt_per_class = gt_classes.count(_class)
+        mine = [i for i, pred_class in enumerate(ids_p) if pred_class == _class]      # prediction order is kept
+        scores = [classes_p[i] for i in mine]
         for iou_idx in range(len(iou_thres)):
             for type_idx, iou_type in enumerate(('box', 'mask')):
                 ap_obj = ap_data[iou_type][iou_idx][_class]
                 ap_obj.add_gt_positives(num_gt_per_class)
-                for i, pred_class in enumerate(ids_p):
-                    if pred_class == _class:
-                        ap_obj.push(classes_p[i], bool(matched[type_idx, iou_idx, i]))
+                ap_obj.data_points.extend(zip(scores, flags[type_idx, iou_idx, mine].tolist()))
 
 
 def calc_map(ap_data, iou_thres, num_classes, step):
