@@ -223,6 +223,35 @@ class Trainer:
     def module(self):
         return self.net
 
+    # ---- full-state checkpoint (the reference's save_latest/save_best keep only net.state_dict(),
+    # utils/common_utils.py:41-63, so a resumed run restarts the momentum buffers and the LR warm-up) -------------------
+    def state_dict(self):
+        """Model weights under the reference's key names (loadable by `Yolact.load_weights` / the reference) plus the
+        optimizer's flat momentum buffer and the step counters."""
+        return {'model': {k: v.detach().clone() for k, v in self.net.state_dict().items()},
+                'momentum': self.opt.buf.detach().clone(), 'opt_steps': self.opt.steps, 'step_idx': self.step_idx,
+                'param_numel': [p.numel() for p in self.opt.params]}
+
+    def load_state_dict(self, state):
+        if state['param_numel'] != [p.numel() for p in self.opt.params]:
+            raise RuntimeError('checkpoint does not match this model (parameter sizes differ)')
+        with torch.no_grad():
+            own = self.net.state_dict()                       # tensors alias the flat buffers: copy in place
+            missing = set(own) ^ set(state['model'])
+            if missing:
+                raise RuntimeError(f'checkpoint keys differ: {sorted(missing)[:5]}')
+            for k, v in state['model'].items():
+                own[k].copy_(v)
+            self.opt.buf.copy_(state['momentum'])
+        self.opt.steps, self.step_idx = int(state['opt_steps']), int(state['step_idx'])
+        self.net.mark_weights_changed()
+
+    def save(self, path):
+        torch.save(self.state_dict(), path)
+
+    def load(self, path):
+        self.load_state_dict(torch.load(path, map_location=self.device))
+
     def step(self, images, targets, masks):
         self.opt.lr = lr_at(self.cfg, self.step_idx)
         if self.buffers_flat is not None and self.world > 1:
