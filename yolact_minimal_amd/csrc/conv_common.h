@@ -6,6 +6,19 @@ namespace ymk {
 
 constexpr int BK = 32;   // K step in floats (one 128-byte row of either operand)
 
+// Division by a launch-invariant positive integer: q = (mulhi(x, mg) + x) >> sh (x < 2^31).  Integer division is ~40 VALU
+// instructions on gfx950; the conv prologue needs ~8 of them before its first load can issue.
+struct FastDiv {
+    unsigned mg, sh, d;
+    __host__ static FastDiv make(unsigned d) {
+        unsigned s = 0;
+        while ((1ull << s) < d) ++s;
+        return FastDiv{(unsigned)(((1ull << 32) * ((1ull << s) - d)) / d + 1), s, d};
+    }
+    __device__ __forceinline__ unsigned div(unsigned x) const { return (__umulhi(x, mg) + x) >> sh; }
+    __device__ __forceinline__ void divmod(unsigned x, unsigned& q, unsigned& r) const { q = div(x); r = x - q * d; }
+};
+
 struct SegDev {
     float* out;
     long long bstride;
@@ -24,7 +37,8 @@ struct ConvP {
     int* counters;     // optional per-output-tile arrival counters: fused split-K finish (see ym_conv_desc.tile_counters)
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, Kpad;
     int M, HoWo, nkt, ksplit, kt_per_split, tiles_m, tiles_n;
-    int main_blocks, main_tiles, tail_split, tail_ktps;   // blocks >= main_blocks: tile main_tiles + t / tail_split, slice t % tail_split
+    int main_blocks, main_tiles, tail_split, tail_ktps;
+    FastDiv fd_ksplit, fd_tail, fd_tiles_n, fd_howo, fd_wo, fd_cin, fd_kw;   // blocks >= main_blocks: tile main_tiles + t / tail_split, slice t % tail_split
     unsigned in_bytes, w_bytes, ws_bytes;   // sizes of `in` / `w` for the raw-buffer descriptors (out-of-range reads return 0)
     int nseg;
     int vec;   // 1: single segment, plain NHWC [M][Cout], Cout % 4 == 0, 16-byte aligned -> vectorised epilogue

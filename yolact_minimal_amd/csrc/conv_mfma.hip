@@ -65,18 +65,19 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
     const __amdgpu_buffer_rsrc_t rs_ws = __builtin_amdgcn_make_buffer_rsrc((void*)p.ws, 0, p.ws_bytes, 0x00020000);
 
     int id, ks, nks, ktps;                    // output tile, K slice, slices of THIS tile, K tiles per slice (block-uniform)
-    if ((int)blockIdx.x < p.main_blocks) {
-        id = ym_xcd_remap(blockIdx.x, p.main_blocks);
-        ks = id % p.ksplit;
-        id /= p.ksplit;
-        nks = p.ksplit; ktps = p.kt_per_split;
-    } else {                                  // tail tiles, split finer so that the last partial round of workgroups fills the chip
-        const int t = (int)blockIdx.x - p.main_blocks;
-        ks = t % p.tail_split;
-        id = p.main_tiles + t / p.tail_split;
-        nks = p.tail_split; ktps = p.tail_ktps;
+    {
+        unsigned q, r;
+        if ((int)blockIdx.x < p.main_blocks) {
+            p.fd_ksplit.divmod((unsigned)ym_xcd_remap(blockIdx.x, p.main_blocks), q, r);
+            id = (int)q; ks = (int)r;
+            nks = p.ksplit; ktps = p.kt_per_split;
+        } else {                              // tail tiles, split finer so that the last partial round of workgroups fills the chip
+            p.fd_tail.divmod(blockIdx.x - (unsigned)p.main_blocks, q, r);
+            id = p.main_tiles + (int)q; ks = (int)r;
+            nks = p.tail_split; ktps = p.tail_ktps;
+        }
     }
-    const int tile_m = id / p.tiles_n, tile_n = id - tile_m * p.tiles_n;
+    const int tile_m = (int)p.fd_tiles_n.div((unsigned)id), tile_n = id - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int kt_beg = ks * ktps;
@@ -91,8 +92,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
     for (int i = 0; i < AR; ++i) {
         const int m = m0 + rbase + 32 * i;
         if (m < p.M) {
-            const int b = m / p.HoWo, rem = m - b * p.HoWo;
-            const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+            unsigned ub, urem, uoh, uow;
+            p.fd_howo.divmod((unsigned)m, ub, urem);
+            p.fd_wo.divmod(urem, uoh, uow);
+            const int b = (int)ub, oh = (int)uoh, ow = (int)uow;
             if (MODE == 2) {
                 a_ih0[i] = oh + p.pad;
                 a_iw0[i] = ow + p.pad;
@@ -118,11 +121,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
     // tap walker for MODE 0 (uniform across the block)
     int kh = 0, kw = 0, c0 = 0;
     if (MODE == 0 || MODE == 2) {
-        const int k0 = kt_beg * BK;
-        const int tap = k0 / p.Cin;
-        c0 = k0 - tap * p.Cin;
-        kh = tap / p.KW;
-        kw = tap - kh * p.KW;
+        unsigned tap, uc0, ukh, ukw;
+        p.fd_cin.divmod((unsigned)(kt_beg * BK), tap, uc0);
+        p.fd_kw.divmod(tap, ukh, ukw);
+        c0 = (int)uc0; kh = (int)ukh; kw = (int)ukw;
     }
 
     constexpr int NSET = NS == 3 ? 2 : 1;
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
             }
         } else {
             const int tap = kt * 8 + c4;  // Cin == 4: one tap per float4
-            const int th = tap / p.KW, tw = tap - th * p.KW;
+            const int th = (int)p.fd_kw.div((unsigned)tap), tw = tap - th * p.KW;
             const bool tap_ok = tap < p.KH * p.KW;
 #pragma unroll
             for (int i = 0; i < AR; ++i) {
@@ -223,6 +225,28 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
         }
     };
+    // Epilogue operands of the plain path (BN scale/shift, residual rows) are requested BEFORE the K loop: at bs=1 a launch
+    // is a ~25 k-cycle latency chain and these loads were a serial ~1.5 k-cycle round trip after the last MFMA.
+    constexpr int EC4 = BN / 4, ERPP = 256 / EC4, ENR = BM / ERPP;
+    constexpr bool PRE_RES = BM * BN <= 64 * 128;               // the 128x128 tile has no registers to spare
+    const bool direct = p.vec && nks == 1;
+    f32x4 pre_sc = {1.f, 1.f, 1.f, 1.f}, pre_sh = {0.f, 0.f, 0.f, 0.f}, pre_res[PRE_RES ? ENR : 1];
+    if (direct) {
+        const int ecol4 = tid % EC4, erow0 = tid / EC4, en = n0 + ecol4 * 4;
+        if (en < p.Cout) {
+            if (p.scale) pre_sc = *reinterpret_cast<const f32x4*>(p.scale + en);
+            if (p.shift) pre_sh = *reinterpret_cast<const f32x4*>(p.shift + en);
+        }
+        if (PRE_RES) {
+            const __amdgpu_buffer_rsrc_t rs_res =
+                __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, p.residual ? (unsigned)((size_t)p.M * p.Cout * 4) : 0u, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < ENR; ++k) {
+                const int m = m0 + erow0 + k * ERPP;
+                pre_res[k] = buf_ld16(rs_res, (m < p.M && en < p.Cout) ? (unsigned)(((size_t)m * p.Cout + en) * 4) : OOB);
+            }
+        }
+    }
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, NS == 3 ? 1 : 0>;
     if constexpr (NS == 3) {
@@ -321,14 +345,17 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
             if (!s_last) return;
         }
         if (n < p.Cout) {
-            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-            if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-            if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+            f32x4 sc = pre_sc, sh = pre_sh;
+            if (!direct) {
+                if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+                if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+            }
             const int act = p.seg[0].act;
             float* outb = p.seg[0].out + n;
-            const float* resb = p.residual ? p.residual + n : nullptr;
-#pragma unroll 4
-            for (int row = row0; row < BM; row += RPP) {
+            const float* resb = (p.residual && !(direct && PRE_RES)) ? p.residual + n : nullptr;
+#pragma unroll
+            for (int rk = 0; rk < BM / RPP; ++rk) {
+                const int row = row0 + rk * RPP;
                 const int m = m0 + row;
                 if (m < p.M) {
                     f32x4 v;
@@ -346,7 +373,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
                         v = *reinterpret_cast<const f32x4*>(C + row * CP + col4 * 4);
                     }
                     v = __builtin_elementwise_fma(v, sc, sh);
-                    if (resb) v += *reinterpret_cast<const f32x4*>(resb + (size_t)m * p.Cout);
+                    if (direct && PRE_RES) v += pre_res[PRE_RES ? rk : 0];      // zeros when there is no residual
+                    else if (resb) v += *reinterpret_cast<const f32x4*>(resb + (size_t)m * p.Cout);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = ym_apply_act(v[e], act);
                     *reinterpret_cast<f32x4*>(outb + (size_t)m * p.Cout) = v;
@@ -414,7 +442,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
                     if (m < p.M) {
                         float v = __builtin_fmaf(acc[i][j][r], sc, sh);
                         if (p.residual) v += p.residual[(size_t)m * p.Cout + n];
-                        const int b = m / p.HoWo, pix = m - b * p.HoWo;
+                        const int b = (int)p.fd_howo.div((unsigned)m), pix = m - b * p.HoWo;
                         optr[(size_t)b * obs + (size_t)pix * opitch] = ym_apply_act(v, oact);
                     }
                 }
@@ -616,6 +644,9 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
     p.main_blocks = p.main_tiles * pl.ksplit;
     p.tail_split = pl.tail_tiles > 0 ? pl.tail_split : 1;
     p.tail_ktps = pl.tail_tiles > 0 ? pl.tail_ktps : pl.nkt;
+    p.fd_ksplit = FastDiv::make((unsigned)pl.ksplit); p.fd_tail = FastDiv::make((unsigned)p.tail_split);
+    p.fd_tiles_n = FastDiv::make((unsigned)pl.tiles_n); p.fd_howo = FastDiv::make((unsigned)(d->Ho * d->Wo));
+    p.fd_wo = FastDiv::make((unsigned)d->Wo); p.fd_cin = FastDiv::make((unsigned)d->Cin); p.fd_kw = FastDiv::make((unsigned)d->KW);
     p.ws_bytes = (unsigned)(need < 0xFFFFFFF0ull ? need : 0);
     if (d->bn_sum) {
         YM_REQUIRE(d->bn_sumsq && p.vec && (pl.slots() == 1 || p.counters) && d->kwaves == 0,
