@@ -38,7 +38,8 @@ struct ConvP {
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, Kpad;
     int M, HoWo, nkt, ksplit, kt_per_split, tiles_m, tiles_n;
     int main_blocks, main_tiles, tail_split, tail_ktps;
-    FastDiv fd_ksplit, fd_tail, fd_tiles_n, fd_howo, fd_wo, fd_cin, fd_kw;   // blocks >= main_blocks: tile main_tiles + t / tail_split, slice t % tail_split
+    FastDiv fd_ksplit, fd_tail, fd_tiles_n, fd_howo, fd_wo, fd_cin, fd_kw;
+    long long* trace;  // debug builds (-DYM_TRACE, tools/conv_trace.py): per-workgroup s_memtime stamps [grid][4]   // blocks >= main_blocks: tile main_tiles + t / tail_split, slice t % tail_split
     unsigned in_bytes, w_bytes, ws_bytes;   // sizes of `in` / `w` for the raw-buffer descriptors (out-of-range reads return 0)
     int nseg;
     int vec;   // 1: single segment, plain NHWC [M][Cout], Cout % 4 == 0, 16-byte aligned -> vectorised epilogue

@@ -19,6 +19,7 @@
 // is MFMA-issue bound, LDS and the global->LDS staging (register prefetch, double-buffered) sit
 // far below their limits.  Grid: one block per (tile, k-slice), XCD-aware remap so the N-tiles
 // sharing an A panel run on the same XCD L2.
+#include <stdlib.h>
 #include <type_traits>
 #include "conv_common.h"
 
@@ -27,6 +28,13 @@ using namespace ymk;
 namespace {
 
 constexpr int PITCH = 36;  // floats
+
+// Phase stamps for tools/conv_trace.py (only in the -DYM_TRACE debug build: `make -C yolact_minimal_amd/csrc trace`).
+#ifdef YM_TRACE
+#define YM_STAMP(i) do { if ((i) == 3) __builtin_amdgcn_s_waitcnt(0); if (p.trace && threadIdx.x == 0) p.trace[(size_t)blockIdx.x * 4 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define YM_STAMP(i) do { } while (0)
+#endif
 
 // Branch-free operand fetch: raw buffer loads return 0 for offsets beyond the descriptor's range, so padding taps,
 // rows past M / Cout and the K tail need no control flow (and hipcc can keep COUNTED vmcnt waits across the K loop —
@@ -60,6 +68,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    YM_STAMP(0);
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_ws = __builtin_amdgcn_make_buffer_rsrc((void*)p.ws, 0, p.ws_bytes, 0x00020000);
@@ -256,6 +265,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
         store_tile(0, I0{});
         load_tile(kt_beg + 1, I1{});
         __syncthreads();
+        YM_STAMP(1);
         int buf = 0;
         for (int t = 0; t < nt; t += 2) {
             load_tile(kt_beg + t + 2, I0{});
@@ -276,6 +286,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
         load_tile(kt_beg, I0{});
         store_tile(0, I0{});
         __syncthreads();
+        YM_STAMP(1);
         for (int kt = kt_beg; kt < kt_end; ++kt) {
             const int cur = (kt - kt_beg) & 1;
             load_tile(kt + 1, I0{});
@@ -285,6 +296,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
         }
     }
 
+    YM_STAMP(2);
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) --
     if (p.vec) {
         // Stage the BM x BN accumulator tile through LDS (the K loop ended on a barrier, so the operand
@@ -404,6 +416,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
                 atomicAdd(p.bn_sumsq + n0 + tid, Q);
             }
         }
+        YM_STAMP(3);
         return;
     }
 #pragma unroll
@@ -638,6 +651,10 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
                  g.batch_stride == (int64_t)d->Ho * d->Wo * d->Cout && d->Cout % 4 == 0 && aligned) ? 1 : 0;
     }
     p.bn_sum = d->bn_sum; p.bn_sumsq = d->bn_sumsq;
+    p.trace = nullptr;
+#ifdef YM_TRACE
+    if (const char* e = getenv("YM_TRACE_PTR")) p.trace = (long long*)strtoull(e, nullptr, 10);
+#endif
     p.counters = (p.vec && pl.slots() > 1 && d->kwaves == 0 && need < 0xFFFFFFF0ull) ? d->tile_counters : nullptr;
     YM_REQUIRE(pl.tail_tiles == 0 || p.counters, "conv: tail_tiles needs a plain NHWC output (vector epilogue) and a workspace < 4 GiB");
     p.main_tiles = pl.tiles_m * pl.tiles_n - pl.tail_tiles;
