@@ -140,9 +140,36 @@ def _tile_counters(device):
     return t.data_ptr()
 
 
+class _StatsPool:
+    """fp64 accumulators for the fused BN statistics of every ConvBn of one forward: ONE buffer, zeroed by ONE fill per step,
+    handed out in slices (instead of an allocation + fill launch per layer)."""
+
+    def __init__(self):
+        self.buf, self.off, self.want = None, 0, 0
+
+    def begin(self, device):
+        if self.buf is None or self.buf.device != device or self.buf.numel() < self.want:
+            self.buf = torch.empty(max(self.want, 1 << 16), device=device, dtype=torch.float64)
+        self.buf.zero_()
+        self.off, self.want = 0, 0
+
+    def take(self, n, device):
+        self.want += n
+        if self.buf is not None and self.buf.device == device and self.off + n <= self.buf.numel():
+            out = self.buf[self.off:self.off + n]
+            self.off += n
+            return out
+        return torch.zeros(n, device=device, dtype=torch.float64)      # pool too small this step: grows at the next begin()
+
+
+_stats_pool = _StatsPool()
+
+
 def _pack_fwd(weight, cin_pad, cout_pad):
     cout, cin, kh, kw = weight.shape
     k_pad = _ru(kh * kw * cin_pad, 32)
+    if kh == 1 and kw == 1 and cin_pad == cin and cout_pad == cout and cin % 32 == 0 and weight.is_contiguous():
+        return weight.detach().view(cout, cin), cin        # OIHW of a 1x1 conv IS the packed [Cout][K] image: no copy
     if cout_pad == cout:
         return hip.pack_conv_weight(weight.detach(), cin_pad, k_pad), k_pad
     wp = torch.zeros(cout_pad, k_pad, device=weight.device, dtype=torch.float32)
@@ -168,7 +195,6 @@ def _conv_forward(x, wp, k_pad, cout_pad, kh, kw, stride, pad, shift, act, resid
     d.tile_counters = _tile_counters(x.device)
     fused = False
     if bn_stats is not None and hip.lib().ym_conv2d_fuses_bn_stats(ctypes.byref(d)) == 1:
-        bn_stats.zero_()
         d.bn_sum, d.bn_sumsq = bn_stats.data_ptr(), bn_stats.data_ptr() + cout_pad * 8
         fused = True
     ws = scratch(x.device, hip.conv_workspace_bytes(d))
@@ -279,7 +305,7 @@ class ConvBn(torch.autograd.Function):
     def forward(ctx, x, weight, gamma, beta, running_mean, running_var, residual, stride, pad, relu, momentum, eps):
         cout, cin, kh, kw = weight.shape
         wp, k_pad = _pack_fwd(weight, x.shape[-1], cout)
-        stats = torch.empty(2 * cout, device=x.device, dtype=torch.float64)
+        stats = _stats_pool.take(2 * cout, x.device)           # zeroed (the fused epilogue accumulates into it)
         y, fused = _conv_forward(x, wp, k_pad, cout, kh, kw, stride, pad, None, ACT_NONE, bn_stats=stats)
         m = y.numel() // cout
         out = torch.empty_like(y)
@@ -365,7 +391,8 @@ class Bilinear2x(torch.autograd.Function):
 def _conv_bn(x, conv, bn, relu=True, residual=None):
     out = ConvBn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, conv.stride[0],
                        conv.padding[0], relu, float(bn.momentum), float(bn.eps))
-    bn.num_batches_tracked += 1
+    if not getattr(bn, '_ym_nbt_flat', False):               # the trainer bumps all counters with one launch
+        bn.num_batches_tracked += 1
     return out
 
 
@@ -380,6 +407,7 @@ def train_features(net, img):
     b, _, h, w = img.shape
     x = torch.empty(b, h, w, 4, device=img.device, dtype=torch.float32)
     hip.nchw_to_nhwc4(img.contiguous().float(), x)
+    _stats_pool.begin(img.device)
     bb = net.backbone
     x = _conv_bn(x, bb.conv1, bb.bn1)
     x = MaxPool.apply(x)

@@ -185,6 +185,19 @@ class FlatGradReducer:
         self.reset()
 
 
+def flatten_batch_counters(module):
+    """All BatchNorm `num_batches_tracked` counters as views of one int64 tensor: one `+= 1` launch per step instead of one
+    per layer (the modules are flagged so the forward skips its own increment)."""
+    bns = [m for m in module.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.num_batches_tracked is not None]
+    if not bns:
+        return None
+    flat = torch.stack([m.num_batches_tracked.reshape(()) for m in bns]).contiguous()
+    for i, m in enumerate(bns):
+        m.num_batches_tracked.data = flat[i]
+        m._ym_nbt_flat = True
+    return flat
+
+
 def flatten_buffers(module):
     """Re-point every floating-point buffer (BN running statistics) at a view of one flat tensor so that the per-step
     rank-0 broadcast (`DDP(broadcast_buffers=True)`, reference train.py:76) is ONE message instead of 2 per BN layer."""
@@ -208,6 +221,7 @@ class Trainer:
         self.model = self.net
         self.ddp = world > 1 or (dist.is_initialized() and os.environ.get('YM_FORCE_DIST', '0') == '1')
         self.reducer, self.buffers_flat = None, None
+        self.nbt_flat = flatten_batch_counters(self.net)
         self.torch_ddp = self.ddp and os.environ.get('YM_TORCH_DDP', '0') == '1'
         if self.torch_ddp:                           # the reference's wrapper, kept as an option (per-parameter bucket copies)
             from torch.nn.parallel import DistributedDataParallel as DDP
@@ -218,6 +232,7 @@ class Trainer:
             self.buffers_flat = flatten_buffers(self.net)
             self.reducer = FlatGradReducer(self.opt, world)
         self.step_idx = 0
+        self.net.mark_weights_changed()              # parameters were re-pointed at the flat buffer
 
     @property
     def module(self):
@@ -257,6 +272,8 @@ class Trainer:
         if self.buffers_flat is not None and self.world > 1:
             dist.broadcast(self.buffers_flat, 0)      # BN running stats follow rank 0, one 0.4 MB message
         losses = self.model(images, targets, masks)
+        if self.nbt_flat is not None:
+            self.nbt_flat += 1                        # every BatchNorm ran once (num_batches_tracked)
         if self.ddp:
             all_loss = torch.stack([l.detach() for l in losses])
             dist.all_reduce(all_loss)                 # 16-byte logging collective, train.py:121-122
