@@ -106,6 +106,28 @@ int ym_conv2d_tile_counters(const ym_conv_desc* d);   /* output tiles of the cho
 int ym_conv2d_fuses_bn_stats(const ym_conv_desc* d);
 int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t workspace_bytes, ym_stream_t s);
 
+/* ---- Swin-T backward + AdamW (row a18 under loss.backward(); reference train.py:62-63,126) ---------------------------
+ * LayerNorm backward over the last dim of x [M][C] (statistics recomputed): dx, dgamma, dbeta (overwritten). */
+size_t ym_layernorm_bwd_workspace_bytes(int C);
+int ym_layernorm_bwd(const float* dy, const float* x, const float* gamma, float eps, int64_t M, int C, float* dx, float* dgamma,
+                     float* dbeta, void* workspace, size_t workspace_bytes, ym_stream_t s);
+/* Backward of ym_patch_merge_layernorm: dy [B*ceil(H/2)*ceil(W/2)][4C], x NHWC [B][H][W][C] -> dx (same shape as x; every
+ * element written), dgamma / dbeta [4C].  workspace >= ym_layernorm_bwd_workspace_bytes(4*C). */
+int ym_patch_merge_layernorm_bwd(const float* dy, const float* x, int B, int H, int W, int C, const float* gamma, float eps,
+                                 float* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, ym_stream_t s);
+/* Exact (erf) GELU of Mlp.forward (modules/swin_transformer.py:92-96) on a saved pre-activation; n % 4 == 0. */
+int ym_gelu_fwd(const float* z, float* out, int64_t n, ym_stream_t s);
+int ym_gelu_bwd(const float* dy, const float* z, float* dz, int64_t n, ym_stream_t s);
+/* Backward of ym_swin_window_attention: dout [B*H*W][C] -> dqkv [B*H*W][3C] (every element written), and ACCUMULATED into
+ * caller-zeroed buffers: dqkv_bias_pad [3C] (gradient reaching the qkv bias through the padded tokens, to be added to the
+ * qkv Linear's bias gradient) and dtable [(2*window-1)^2][heads] (relative-position-bias table). */
+int ym_swin_window_attention_bwd(const float* qkv, const float* qkv_bias, const float* rel_bias_table, const float* dout, int B,
+                                 int H, int W, int C, int heads, int window, int shift, float* dqkv, float* dqkv_bias_pad,
+                                 float* dtable, ym_stream_t s);
+/* torch.optim.AdamW (amsgrad=False) on flat fp32 buffers, step >= 1 (reference train.py:63: lr, weight_decay=0.05). */
+int ym_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, ym_stream_t s);
+
 /* ---- evaluation inner products right after after_nms (next row f2) -----------------------------------------------
  * mask_iou (utils/box_utils.py:189-200): masks_a [n][P], masks_b [g][P] fp32 in {0,1} (P = img_h*img_w < 2^24) ->
  * iou [n][g] = inter / ((area_a + area_b) - inter), the reference's fp32 matmul evaluated as popcounts of bit rows

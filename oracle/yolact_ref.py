@@ -635,6 +635,21 @@ def features_any(img, sd):
     return torch.cat(confs, 1), torch.cat(boxes, 1), torch.cat(coefs, 1), proto
 
 
+def forward_train_any(img, sd):
+    """Train-branch outputs of Yolact.forward (modules/yolact.py:141-161) for a backbone WITHOUT batch-norm state, i.e. Swin-T
+    with DropPath inactive (rate 0): LayerNorm / Linear / attention behave identically in train and eval mode, so the functional
+    eval restatement is also the train-mode one and autograd through it gives the reference gradients.
+    Returns (class logits, box, coef, proto, semantic-seg logits)."""
+    assert 'backbone.patch_embed.proj.weight' in sd, 'ResNet training goes through TrainNet (batch-statistics BatchNorm)'
+    outs = swin_backbone(img, sd)
+    levels = fpn(outs[1], outs[2], outs[3], sd)
+    proto = protonet(levels[0], sd).permute(0, 2, 3, 1).contiguous()
+    num_classes = sd['prediction_layers.conf_layer.weight'].shape[0] // 3
+    confs, boxes, coefs = zip(*(head(lv, sd, num_classes) for lv in levels))
+    seg = F.conv2d(levels[0], sd['semantic_seg_conv.weight'], sd['semantic_seg_conv.bias'])
+    return torch.cat(confs, 1), torch.cat(boxes, 1), torch.cat(coefs, 1), proto, seg
+
+
 def forward_eval_any(img, sd):
     conf, box, coef, proto = features_any(img, sd)
     return F.softmax(conf, -1), box, coef, proto

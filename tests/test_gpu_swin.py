@@ -110,3 +110,159 @@ def test_swin_forward_544_digest(golden_dir):
     _close(box[0, ::37], g['box_sample'], 'box sample')
     _close(coef[0, ::37], g['coef_sample'], 'coef sample')
     _close(proto[0, ::5, ::5], g['proto_sample'], 'proto sample')
+
+
+# ---- training (backward kernels, AdamW) ---------------------------------------------------------------------------------
+def test_layernorm_gelu_merge_backward():
+    from yolact_minimal_amd.swin_train import LayerNormFn, PatchMergeLNFn, GeluFn
+    g = torch.Generator().manual_seed(5)
+    for m, c in ((37, 96), (300, 384), (1200, 768)):
+        x, w, b, dy = (torch.randn(m, c, generator=g) * 2 + 0.5, torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g),
+                       torch.randn(m, c, generator=g))
+        xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+        (F.layer_norm(xr, (c,), wr, br, 1e-5) * dy.double()).sum().backward()
+        xg, wg, bg = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+        (LayerNormFn.apply(xg, wg, bg, 1e-5) * dy.to(DEV)).sum().backward()
+        torch.testing.assert_close(xg.grad.cpu().double(), xr.grad, rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(wg.grad.cpu().double(), wr.grad, rtol=2e-4, atol=2e-4)
+        torch.testing.assert_close(bg.grad.cpu().double(), br.grad, rtol=2e-4, atol=2e-4)
+    z, dy = torch.randn(40, 384, generator=g) * 2, torch.randn(40, 384, generator=g)
+    zr = z.double().requires_grad_()
+    (F.gelu(zr) * dy.double()).sum().backward()
+    zg = z.to(DEV).requires_grad_()
+    out = GeluFn.apply(zg)
+    (out * dy.to(DEV)).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), F.gelu(z), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(zg.grad.cpu().double(), zr.grad, rtol=1e-5, atol=1e-6)
+    for (h, w_, c) in ((8, 8, 96), (7, 9, 192), (17, 17, 384)):
+        x = torch.randn(2, h, w_, c, generator=g)
+        gm, bt = torch.rand(4 * c, generator=g) + 0.5, torch.randn(4 * c, generator=g)
+        dy = torch.randn(2, (h + 1) // 2 * ((w_ + 1) // 2), 4 * c, generator=g)
+        xr, gr, br = x.double().requires_grad_(), gm.double().requires_grad_(), bt.double().requires_grad_()
+        sd = {'m.norm.weight': gr, 'm.norm.bias': br, 'm.reduction.weight': torch.eye(4 * c, dtype=torch.float64)}
+        (R.swin_merge(xr.reshape(2, h * w_, c), h, w_, sd, 'm') * dy.double()).sum().backward()
+        xg, gg, bg = x.to(DEV).requires_grad_(), gm.to(DEV).requires_grad_(), bt.to(DEV).requires_grad_()
+        (PatchMergeLNFn.apply(xg, gg, bg, 1e-5).reshape(2, -1, 4 * c) * dy.to(DEV)).sum().backward()
+        torch.testing.assert_close(xg.grad.cpu().double(), xr.grad, rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(gg.grad.cpu().double(), gr.grad, rtol=2e-4, atol=2e-4)
+        torch.testing.assert_close(bg.grad.cpu().double(), br.grad, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize('h,w,heads,shift', [(14, 14, 3, 0), (10, 12, 3, 3), (17, 17, 6, 3), (5, 6, 12, 0)])
+def test_swin_block_gradients_match_oracle(h, w, heads, shift):
+    """One SwinTransformerBlock (LN -> qkv -> shifted-window attention with padding -> proj + residual -> LN -> MLP + residual):
+    output and the gradient of every parameter (incl. the relative-position table and the qkv bias, which also receives
+    gradient through the padded tokens) and of the input vs fp64 autograd of the oracle."""
+    from yolact_minimal_amd.modules.swin_transformer import SwinTransformerBlock
+    from yolact_minimal_amd.swin_train import swin_block
+    g = torch.Generator().manual_seed(h * 31 + w + heads + shift)
+    c, ws, b = heads * 32, 7, 2
+    torch.manual_seed(h + w)
+    blk = SwinTransformerBlock(c, heads, ws, shift)
+    with torch.no_grad():
+        for n_, p_ in blk.named_parameters():
+            if n_.endswith('bias'):
+                p_.copy_(torch.randn(p_.shape, generator=g) * 0.2)
+            elif 'norm' in n_:
+                p_.copy_(torch.rand(p_.shape, generator=g) * 0.5 + 0.75)
+            elif 'table' in n_:
+                p_.copy_(torch.randn(p_.shape, generator=g) * 0.5)
+    x = torch.randn(b, h, w, c, generator=g)
+    dy = torch.randn(b, h, w, c, generator=g)
+    sd = {('b.' + k): v.detach().double().requires_grad_() for k, v in blk.state_dict().items() if v.is_floating_point()}
+    sd['b.attn.relative_position_index'] = R.swin_rel_index(ws)
+    xr = x.double().requires_grad_()
+    hp, wp = -(-h // ws) * ws, -(-w // ws) * ws
+    mask = R.swin_shift_mask(hp, wp, ws, ws // 2).double()
+    want = R.swin_block(xr.reshape(b, h * w, c), h, w, sd, 'b', heads, ws, shift, mask)
+    (want * dy.double().reshape(b, h * w, c)).sum().backward()
+    blk = blk.to(DEV)
+    xg = x.to(DEV).requires_grad_()
+    got = swin_block(xg, blk, heads, ws, training=True)
+    (got * dy.to(DEV)).sum().backward()
+    torch.testing.assert_close(got.detach().cpu().double().reshape(b, h * w, c), want.detach(), rtol=1e-4, atol=1e-4)
+    scale = float(xr.grad.abs().max())
+    torch.testing.assert_close(xg.grad.cpu().double(), xr.grad, rtol=1e-3, atol=1e-4 * scale)
+    for n_, p_ in blk.named_parameters():
+        ref = sd['b.' + n_].grad
+        tol = 2e-4 * max(1.0, float(ref.abs().max()))
+        torch.testing.assert_close(p_.grad.cpu().double(), ref, rtol=1e-3, atol=tol, msg=lambda m, n_=n_: f'{n_}: {m}')
+
+
+def test_adamw_kernel_matches_torch():
+    from yolact_minimal_amd.trainer import FlatAdamW
+    g = torch.Generator().manual_seed(0)
+    shapes = [(96, 3, 4, 4), (96,), (288, 96), (169, 3)]
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g).to(DEV)) for s in shapes]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    ref = torch.optim.AdamW(qs, lr=5e-3, weight_decay=0.05)
+    opt = FlatAdamW(ps, lr=5e-3, weight_decay=0.05)
+    for step in range(4):
+        for p, q in zip(ps, qs):
+            gr = torch.randn(p.shape, generator=g).to(DEV)
+            p.grad, q.grad = gr.clone(), gr.clone()
+        opt.step()
+        ref.step()
+        for p, q in zip(ps, qs):
+            torch.testing.assert_close(p.data, q.data, rtol=2e-6, atol=2e-7)
+
+
+def test_swin_training_step_matches_oracle_and_reference_losses(golden_dir):
+    """swin_tiny_coco train forward + loss + backward (DropPath off): losses vs the real reference's golden, all gradients vs
+    fp64 autograd of the oracle (same conditioning-aware bound as the ResNet path: fp32 vs fp64 of the oracle itself)."""
+    from oracle.make_golden_swin import randomize_swin_
+    g = np.load(os.path.join(golden_dir, 'train_swin_tiny_coco_128_b2.npz'))
+    seed, size, batch = int(g['seed']), 128, 2
+    cfg = build_cfg('swin_tiny_coco', 'train', size)
+    torch.manual_seed(seed)
+    net = Yolact(cfg).train()
+    for blk in (b for l in net.backbone.layers for b in l.blocks):
+        blk.drop_prob = 0.0
+    with torch.no_grad():
+        randomize_swin_(net.state_dict(), seed + 1)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    img = torch.randn(batch, 3, size, size, generator=torch.Generator().manual_seed(seed + 300))
+    boxes, masks = R.synth_targets(batch, size, seed=seed)
+    net = net.to(DEV)
+    losses = net(img.to(DEV), [b.to(DEV) for b in boxes], [m.to(DEV) for m in masks])
+    np.testing.assert_allclose(np.array([float(l.detach()) for l in losses]), g['losses'], rtol=3e-4)
+    sum(losses).backward()
+    grads = {k: p.grad.detach().cpu() for k, p in net.named_parameters()}
+
+    def oracle(dtype):
+        params = {k: v.clone().to(dtype) if v.is_floating_point() else v.clone() for k, v in sd.items()}
+        for k, _ in net.named_parameters():
+            params[k].requires_grad_(True)
+        out = R.forward_train_any(img.to(dtype), params)
+        anchors = torch.tensor(net.anchors if isinstance(net.anchors, list) else net.anchors.tolist()).reshape(-1, 4).to(dtype)
+        sum(R.compute_loss(*out, [b.to(dtype) for b in boxes], [m.to(dtype) for m in masks], anchors, stable=True)).backward()
+        return {k: params[k].grad for k, _ in net.named_parameters()}
+    g64, g32 = oracle(torch.float64), oracle(torch.float32)
+    worst = 0.0
+    for k in grads:
+        ref = g64[k]
+        scale = float(ref.abs().max()) + 1e-12
+        mine = float((grads[k].double() - ref).abs().max()) / scale
+        cpu32 = float((g32[k].double() - ref).abs().max()) / scale
+        worst = max(worst, mine)
+        assert mine <= max(5e-3, 20 * cpu32), (k, mine, cpu32)
+    keys = list(g['grad_keys'])
+    np.testing.assert_allclose(grads['backbone.layers.0.blocks.1.attn.relative_position_bias_table'].numpy(), g['grad_table'],
+                               rtol=5e-2, atol=5e-3 * float(np.abs(g['grad_table']).max()))
+    assert set(keys) == set(grads)
+
+
+def test_swin_trainer_adamw_reduces_loss():
+    from yolact_minimal_amd.trainer import Trainer, FlatAdamW
+    cfg = build_cfg('swin_tiny_coco', 'train', 128, train_bs=2, bs_per_gpu=2)
+    torch.manual_seed(3)
+    net = Yolact(cfg)
+    tr = Trainer(net, cfg, torch.device(DEV))
+    assert isinstance(tr.opt, FlatAdamW)
+    tr.cfg.warmup_until = 0                                     # use the full lr from the first step
+    img = torch.randn(2, 3, 128, 128, generator=torch.Generator().manual_seed(1)).to(DEV)
+    boxes, masks = R.synth_targets(2, 128, seed=5)
+    boxes, masks = [b.to(DEV) for b in boxes], [m.to(DEV) for m in masks]
+    torch.manual_seed(0)                                        # DropPath masks (torch.rand on the device)
+    hist = [sum(float(l.detach()) for l in tr.step(img, boxes, masks)) for _ in range(10)]
+    assert all(np.isfinite(hist)) and min(hist[-3:]) < hist[0], hist

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Run K training steps only (for `rocprofv3 --kernel-trace --stats -- python tools/train_profile.py`)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle.yolact_ref import synth_targets  # noqa: E402  (input generator)
+from yolact_minimal_amd.config import build_cfg  # noqa: E402
+from yolact_minimal_amd.modules.yolact import Yolact  # noqa: E402
+from yolact_minimal_amd.trainer import Trainer  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--cfg', default='res101_coco')
+ap.add_argument('--batch', type=int, default=8)
+ap.add_argument('--steps', type=int, default=8)
+args = ap.parse_args()
+dev = torch.device('cuda:0')
+cfg = build_cfg(args.cfg, 'train', 544, train_bs=args.batch, bs_per_gpu=args.batch)
+torch.manual_seed(0)
+tr = Trainer(Yolact(cfg), cfg, dev)
+img = torch.randn(args.batch, 3, 544, 544, device=dev)
+boxes, masks = synth_targets(args.batch, 544, seed=0)
+boxes, masks = [b.to(dev) for b in boxes], [m.to(dev) for m in masks]
+for _ in range(2):
+    tr.step(img, boxes, masks)
+torch.cuda.synchronize()
+import time  # noqa: E402
+t0 = time.perf_counter()
+for _ in range(args.steps):
+    tr.step(img, boxes, masks)
+torch.cuda.synchronize()
+print(f'{(time.perf_counter() - t0) / args.steps * 1e3:.2f} ms/step over {args.steps} steps (+2 warm-up)')

@@ -57,9 +57,10 @@ class WindowAttention(nn.Module):
 
 
 class SwinTransformerBlock(nn.Module):
-    def __init__(self, dim, num_heads, window_size=7, shift_size=0, mlp_ratio=4.):
+    def __init__(self, dim, num_heads, window_size=7, shift_size=0, mlp_ratio=4., drop_path=0.):
         super().__init__()
         self.dim, self.num_heads, self.window_size, self.shift_size = dim, num_heads, window_size, shift_size
+        self.drop_prob = float(drop_path)           # DropPath rate of this block (train mode only, reference :226,287-288)
         self.norm1 = nn.LayerNorm(dim)
         self.attn = WindowAttention(dim, window_size, num_heads)
         self.norm2 = nn.LayerNorm(dim)
@@ -75,11 +76,12 @@ class PatchMerging(nn.Module):
 
 
 class BasicLayer(nn.Module):
-    def __init__(self, dim, depth, num_heads, window_size=7, mlp_ratio=4., downsample=False):
+    def __init__(self, dim, depth, num_heads, window_size=7, mlp_ratio=4., downsample=False, drop_path=None):
         super().__init__()
         self.window_size, self.shift_size, self.depth = window_size, window_size // 2, depth
+        drop_path = drop_path or [0.] * depth
         self.blocks = nn.ModuleList(SwinTransformerBlock(dim, num_heads, window_size, 0 if i % 2 == 0 else window_size // 2,
-                                                         mlp_ratio) for i in range(depth))
+                                                         mlp_ratio, drop_path[i]) for i in range(depth))
         self.downsample = PatchMerging(dim) if downsample else None
 
 
@@ -93,16 +95,18 @@ class PatchEmbed(nn.Module):
 
 class SwinTransformer(nn.Module):
     def __init__(self, patch_size=4, in_chans=3, embed_dim=96, depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), window_size=7,
-                 mlp_ratio=4.):
+                 mlp_ratio=4., drop_path_rate=0.2):
         super().__init__()
         self.num_layers, self.embed_dim, self.depths, self.heads = len(depths), embed_dim, depths, num_heads
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]      # stochastic depth decay rule (:464)
         self.window_size = window_size
         self.out_norm_indices = (1, 2, 3)
         self.patch_embed = PatchEmbed(patch_size, in_chans, embed_dim)
         self.layers = nn.ModuleList()
         for i in range(self.num_layers):
             self.layers.append(BasicLayer(int(embed_dim * 2 ** i), depths[i], num_heads[i], window_size, mlp_ratio,
-                                          downsample=i < self.num_layers - 1))
+                                          downsample=i < self.num_layers - 1,
+                                          drop_path=dpr[sum(depths[:i]):sum(depths[:i + 1])]))
         self.num_features = [int(embed_dim * 2 ** i) for i in range(self.num_layers)]
         for i in self.out_norm_indices:
             self.add_module(f'norm{i}', nn.LayerNorm(self.num_features[i]))

@@ -155,9 +155,6 @@ class Yolact(nn.Module):
                                'test infrastructure).')
         if self.training:
             # train branch of the reference forward (:158-161): head logits + semantic-seg conv + compute_loss
-            if not hasattr(self.backbone, 'conv1'):
-                raise NotImplementedError('training is built for the ResNet backbones (res50_* / res101_*); the Swin-T '
-                                          'backward kernels (LayerNorm / window attention / GELU) are not built yet')
             from ..train_engine import train_features
             from ..loss import compute_loss
             if isinstance(self.anchors, list):

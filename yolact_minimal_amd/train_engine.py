@@ -409,17 +409,21 @@ def train_features(net, img):
     hip.nchw_to_nhwc4(img.contiguous().float(), x)
     _stats_pool.begin(img.device)
     bb = net.backbone
-    x = _conv_bn(x, bb.conv1, bb.bn1)
-    x = MaxPool.apply(x)
-    outs = []
-    for stage in bb.layers:
-        for blk in stage:
-            y = _conv_bn(x, blk.conv1, blk.bn1)
-            y = _conv_bn(y, blk.conv2, blk.bn2)
-            skip = _conv_bn(x, blk.downsample[0], blk.downsample[1], relu=False) if blk.downsample is not None else x
-            x = _conv_bn(y, blk.conv3, blk.bn3, relu=True, residual=skip)
-        outs.append(x)
-    c3, c4, c5 = outs[1:4]
+    if hasattr(bb, 'patch_embed'):                                # Swin-T (modules/swin_transformer.py)
+        from .swin_train import swin_backbone_train
+        c3, c4, c5 = swin_backbone_train(bb, x, net.training)
+    else:
+        x = _conv_bn(x, bb.conv1, bb.bn1)
+        x = MaxPool.apply(x)
+        outs = []
+        for stage in bb.layers:
+            for blk in stage:
+                y = _conv_bn(x, blk.conv1, blk.bn1)
+                y = _conv_bn(y, blk.conv2, blk.bn2)
+                skip = _conv_bn(x, blk.downsample[0], blk.downsample[1], relu=False) if blk.downsample is not None else x
+                x = _conv_bn(y, blk.conv3, blk.bn3, relu=True, residual=skip)
+            outs.append(x)
+        c3, c4, c5 = outs[1:4]
     fpn = net.fpn
     p5_1 = _conv_bias(c5, fpn.lat_layers[2])
     p4_1 = _conv_bias(c4, fpn.lat_layers[1], residual=Bilinear2x.apply(p5_1, False))     # top-down add fused

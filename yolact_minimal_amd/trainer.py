@@ -114,6 +114,27 @@ class FlatSGD:
             p._ym_in_slot = False                   # the next step() gathers again unless a hook already did
 
 
+class FlatAdamW(FlatSGD):
+    """torch.optim.AdamW(lr, betas=(0.9, 0.999), eps=1e-8, weight_decay) as one HIP launch over the flat buffers — what the
+    reference picks for swin_tiny_coco (train.py:62-63: weight_decay=0.05).  Shares FlatSGD's flat parameter / gradient layout."""
+
+    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05):
+        super().__init__(params, lr, momentum=0.0, weight_decay=weight_decay)
+        self.betas, self.eps = betas, eps
+        self.exp_avg_sq = torch.zeros_like(self.flat)          # `buf` is exp_avg
+
+    def step(self):
+        for p in self.params:
+            self.gather(p)
+        self.steps += 1
+        hip.check(hip.lib().ym_adamw_step(hip.ptr(self.flat), hip.ptr(self.grad), hip.ptr(self.buf), hip.ptr(self.exp_avg_sq),
+                                          self.flat.numel(), float(self.lr), float(self.betas[0]), float(self.betas[1]),
+                                          float(self.eps), float(self.weight_decay), int(self.steps), hip.stream_ptr()),
+                  'ym_adamw_step')
+        for p in self.params:
+            p._ym_in_slot = False
+
+
 class FlatGradReducer:
     """Bucketed gradient all-reduce overlapped with backward, zero-copy on the optimizer's flat gradient buffer.
 
@@ -217,7 +238,10 @@ def flatten_buffers(module):
 class Trainer:
     def __init__(self, net, cfg, device, world=1, local_rank=0):
         self.net, self.cfg, self.device, self.world = net.train().to(device), cfg, device, world
-        self.opt = FlatSGD(self.net.parameters(), cfg.lr)
+        if cfg.__class__.__name__ == 'swin_tiny_coco':           # optimizer choice of the reference (train.py:60-63)
+            self.opt = FlatAdamW(self.net.parameters(), cfg.lr, weight_decay=0.05)
+        else:
+            self.opt = FlatSGD(self.net.parameters(), cfg.lr)
         self.model = self.net
         self.ddp = world > 1 or (dist.is_initialized() and os.environ.get('YM_FORCE_DIST', '0') == '1')
         self.reducer, self.buffers_flat = None, None
@@ -245,6 +269,7 @@ class Trainer:
         optimizer's flat momentum buffer and the step counters."""
         return {'model': {k: v.detach().clone() for k, v in self.net.state_dict().items()},
                 'momentum': self.opt.buf.detach().clone(), 'opt_steps': self.opt.steps, 'step_idx': self.step_idx,
+                'exp_avg_sq': self.opt.exp_avg_sq.detach().clone() if hasattr(self.opt, 'exp_avg_sq') else None,
                 'param_numel': [p.numel() for p in self.opt.params]}
 
     def load_state_dict(self, state):
@@ -258,6 +283,8 @@ class Trainer:
             for k, v in state['model'].items():
                 own[k].copy_(v)
             self.opt.buf.copy_(state['momentum'])
+            if state.get('exp_avg_sq') is not None and hasattr(self.opt, 'exp_avg_sq'):
+                self.opt.exp_avg_sq.copy_(state['exp_avg_sq'])
         self.opt.steps, self.step_idx = int(state['opt_steps']), int(state['step_idx'])
         self.net.mark_weights_changed()
 
