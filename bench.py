@@ -218,10 +218,11 @@ def train_bench(cfg_name, img_size, batch, steps, warmup, world, local_rank, dev
     torch.cuda.synchronize()
     barrier()
     elapsed = reduce_max(time.perf_counter() - t0, device)
-    flops_img = 3.0 * (157.2e9 if cfg_name.startswith('res101') else 113.4e9)
+    flops_img = 3.0 * {'res101': 157.2e9, 'res50_': 113.4e9, 'swin_t': 119.2e9}.get(cfg_name[:6], 157.2e9)   # step ~ 3x forward
+    opt = 'AdamW' if cfg_name.startswith('swin') else 'SGD'
     img_s = batch * world * steps / elapsed
     return dict(img_s=round(img_s, 2), ms_per_step=round(elapsed / steps * 1e3, 2), steps=steps, warmup=warmup,
-                batch_per_gpu=batch, global_batch=batch * world, parallelism=f'ddp{world} (RCCL all-reduce, 25 MB buckets)',
+                batch_per_gpu=batch, global_batch=batch * world, parallelism=f'ddp{world} (RCCL all-reduce, 25 MB buckets)', optimizer=opt,
                 tflops_per_gpu=round(img_s / world * flops_img / 1e12, 2),
                 frac_f32_mfma_peak=round(img_s / world * flops_img / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
                 last_losses=[round(float(l.detach()), 4) for l in losses], finite=all(bool(torch.isfinite(l)) for l in losses))
@@ -330,6 +331,11 @@ def main():
                                               frac_f32_mfma_peak=round(fl2 / tf2 / 1e12 / F32_MFMA_PEAK_TFLOPS, 4))
         if not args.no_extra and world == 1:
             extra['eval_metrics'] = eval_metrics_bench(device, cpu=not args.no_cpu_baseline)
+            if not args.no_train and args.cfg != 'swin_tiny_coco':
+                net._engines.clear()
+                torch.cuda.empty_cache()
+                extra['train_swin_tiny_coco'] = train_bench('swin_tiny_coco', args.img_size, args.train_batch, args.train_steps, 2, 1,
+                                                            local_rank, device, lambda: None)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.cfg, args.img_size)

@@ -75,7 +75,10 @@ def _check_flat_reducer(rank, world):
         y = net[4](net[3](net[3](h)))                                                  # net[3] is used twice
         opt.zero_grad()
         y.pow(2).mean().backward()
-        local = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).clone() for p in opt.params])
+        local = torch.zeros_like(opt.grad)                     # same (64-byte aligned, zero padded) layout as the flat buffer
+        for p, (a_, b_) in zip(opt.params, opt.offsets):
+            if p.grad is not None:
+                local[a_:b_] = p.grad.reshape(-1)
         assert all(p.grad is None or p.grad.data_ptr() == p._ym_grad_slot.data_ptr() for p in opt.params)
         red.finish()
         want = local.clone()

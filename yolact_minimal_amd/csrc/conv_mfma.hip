@@ -494,6 +494,15 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce(const ConvP p) {
     }
 }
 
+// Can the output be written by the vectorised row-major epilogue (one plain NHWC tensor, 16-byte aligned operands)?  The K-slice
+// exchange of the fused split-K finish / tail split lives in that epilogue.
+bool vec_epilogue(const ym_conv_desc* d) {
+    const ym_conv_seg& g = d->seg[0];
+    const bool aligned = (((uintptr_t)g.out | (uintptr_t)d->residual | (uintptr_t)d->scale | (uintptr_t)d->shift) & 15) == 0;
+    return d->nseg == 1 && g.n_begin == 0 && g.n_end == d->Cout && g.pitch == d->Cout &&
+           g.batch_stride == (int64_t)d->Ho * d->Wo * d->Cout && d->Cout % 4 == 0 && aligned;
+}
+
 struct Plan {
     int bm, bn, ksplit, kt_per_split, tiles_m, tiles_n, nkt, M;
     int tail_tiles, tail_split, tail_ktps;     // 0 = no tail
@@ -568,7 +577,7 @@ int make_plan(const ym_conv_desc* d, Plan* pl) {
     if (ks < 1) ks = 1;
     pl->kt_per_split = ym_cdiv(pl->nkt, ks);
     pl->ksplit = ym_cdiv(pl->nkt, pl->kt_per_split);
-    if (d->tail_tiles > 0 && d->tail_ksplit > 1) {
+    if (d->tail_tiles > 0 && d->tail_ksplit > 1 && vec_epilogue(d)) {   // (a segmented / unaligned output ignores the tail knobs)
         YM_REQUIRE(d->tile_counters && pl->ksplit == 1 && d->Cin != 4, "conv: tail_tiles needs tile_counters, ksplit <= 1 and Cin %% 32 == 0");
         YM_REQUIRE(d->tail_tiles <= pl->tiles_m * pl->tiles_n, "conv: tail_tiles %d > %d output tiles", d->tail_tiles, pl->tiles_m * pl->tiles_n);
         int ts = d->tail_ksplit > pl->nkt ? pl->nkt : d->tail_ksplit;
@@ -608,10 +617,7 @@ extern "C" int ym_conv2d_tile_counters(const ym_conv_desc* d) {
 extern "C" int ym_conv2d_fuses_bn_stats(const ym_conv_desc* d) {
     Plan pl;
     if (make_plan(d, &pl) != YM_OK) return 0;
-    const ym_conv_seg& g = d->seg[0];
-    const bool plain = d->nseg == 1 && g.n_begin == 0 && g.n_end == d->Cout && g.pitch == d->Cout &&
-                       g.batch_stride == (int64_t)d->Ho * d->Wo * d->Cout && d->Cout % 4 == 0;
-    return (plain && (pl.slots() == 1 || d->tile_counters) && d->kwaves == 0) ? 1 : 0;
+    return (vec_epilogue(d) && (pl.slots() == 1 || d->tile_counters) && d->kwaves == 0) ? 1 : 0;
 }
 
 extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t workspace_bytes, ym_stream_t s) {
@@ -644,11 +650,8 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
         }
     }
     {
-        const ym_conv_seg& g = d->seg[0];
-        const bool aligned = (((uintptr_t)g.out | (uintptr_t)d->residual | (uintptr_t)d->scale | (uintptr_t)d->shift |
-                               (uintptr_t)workspace) & 15) == 0;
-        p.vec = (d->nseg == 1 && g.n_begin == 0 && g.n_end == d->Cout && g.pitch == d->Cout &&
-                 g.batch_stride == (int64_t)d->Ho * d->Wo * d->Cout && d->Cout % 4 == 0 && aligned) ? 1 : 0;
+        YM_REQUIRE(pl.tail_tiles == 0 || ((uintptr_t)workspace & 15) == 0, "conv: tail split needs a 16-byte aligned workspace");
+        p.vec = (vec_epilogue(d) && ((uintptr_t)workspace & 15) == 0) ? 1 : 0;
     }
     p.bn_sum = d->bn_sum; p.bn_sumsq = d->bn_sumsq;
     p.trace = nullptr;

@@ -66,19 +66,22 @@ class FlatSGD:
     def __init__(self, params, lr, momentum=0.9, weight_decay=5e-4):
         self.params = [p for p in params if p.requires_grad]
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
-        n = sum(p.numel() for p in self.params)
+        # every parameter starts on a 64-byte boundary of the flat buffer (the conv epilogue wants 16-byte aligned bias /
+        # scale vectors, and a misaligned one silently costs the vectorised epilogue); the gaps stay zero for ever
+        starts, n = [], 0
+        for p in self.params:
+            starts.append(n)
+            n += (p.numel() + 15) // 16 * 16
         dev = self.params[0].device
-        self.flat = torch.empty(n, device=dev, dtype=torch.float32)
+        self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
         self.offsets = []
-        off = 0
-        for p in self.params:                       # parameters become views of the flat buffer
+        for p, off in zip(self.params, starts):     # parameters become views of the flat buffer
             k = p.numel()
             self.flat[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + k].view_as(p.data)
             self.offsets.append((off, off + k))
-            off += k
         self.buf = torch.zeros_like(self.flat)
-        self.grad = torch.empty_like(self.flat)
+        self.grad = torch.zeros_like(self.flat)
         for p, (a, b) in zip(self.params, self.offsets):   # the HIP wgrad kernels write straight into these views
             p._ym_grad_slot = self.grad[a:b].view_as(p.data)
             p._ym_slot_free = True
