@@ -1,0 +1,88 @@
+"""GPU: the whole evaluation chain of the reference's eval.py loop (`val_aug` -> `Yolact.forward` -> `nms` -> `after_nms` ->
+`prep_metrics` / `calc_map` and the COCO-json branch with `rle_encode`) through the drop-in surface, every stage checked
+against the CPU oracle on the same data (eval.py:36-69)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import metrics_ref as M
+from oracle import rle_ref as RL
+from oracle import yolact_ref as R
+from yolact_minimal_amd.config import build_cfg
+from yolact_minimal_amd.modules.yolact import Yolact
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def test_eval_loop_end_to_end():
+    from yolact_minimal_amd.utils.augmentations import val_aug
+    from yolact_minimal_amd.utils.common_utils import APDataObject, prep_metrics, calc_map, rle_encode, MakeJson
+    from yolact_minimal_amd.utils.output_utils import nms, after_nms
+    size, img_h, img_w = 128, 96, 120
+    cfg = build_cfg('res50_coco', 'val', size)
+    torch.manual_seed(0)
+    net = Yolact(cfg).eval()
+    sd = net.state_dict()
+    R.randomize_bn_(sd, 1)
+    R.randomize_bias_(sd, 2)
+    net.load_state_dict(sd)
+    g = torch.Generator().manual_seed(4)
+    raw = torch.randint(0, 256, (img_h, img_w, 3), generator=g, dtype=torch.uint8)          # HWC BGR, like cv2.imread
+
+    # 1. pre-processing + forward (the prediction tensors of a random-init net are checked, not used for detections)
+    x = val_aug(raw.to(DEV), size)
+    x_ref = R.val_aug(raw, size)
+    torch.testing.assert_close(x.cpu(), x_ref, rtol=1e-5, atol=1e-5)
+    net = net.to(DEV)
+    with torch.no_grad():
+        out = net(x[None])
+        ref = R.forward_eval(x_ref[None], sd)
+    for a, b in zip(out, ref):
+        torch.testing.assert_close(a.cpu(), b, rtol=1e-4, atol=1e-4 * max(1.0, float(b.abs().max())))
+
+    # 2. post-processing on synthetic head outputs of the same shapes (random-init nets give degenerate detections)
+    cls, box, coef, proto = R.synth_head_outputs(len(net.anchors) // 4, proto_hw=size // 4, seed=3, bg_bias=5.0)
+    anchors = torch.tensor(net.anchors).reshape(-1, 4)
+    r_ids, r_sc, r_box, r_coef, r_proto = R.nms(cls, box, coef, proto, anchors, stable=True)
+    ids, sc, bx, cf, pr = nms(cls.to(DEV), box.to(DEV), coef.to(DEV), proto.to(DEV), net.anchors, cfg)
+    assert torch.equal(ids.cpu(), r_ids) and torch.equal(sc.cpu(), r_sc)
+    r_ids2, r_sc2, r_boxes, r_masks = R.after_nms(r_ids, r_sc, r_box, r_coef, r_proto, img_h, img_w)
+    ids2, sc2, boxes_p, masks_p = after_nms(ids, sc, bx, cf, pr, img_h, img_w, cfg)
+    assert torch.equal(boxes_p.cpu(), r_boxes)
+    assert float((masks_p.cpu() != r_masks).float().mean()) < 1e-4
+    n = ids2.shape[0]
+    assert n > 10
+
+    # 3. metrics against synthetic ground truth made from some of the detections (so that there are true positives)
+    pick = list(range(0, n, 3))[:8]
+    gt = torch.cat([r_boxes[pick].float() / torch.tensor([img_w, img_h, img_w, img_h]), r_ids2[pick].float()[:, None]], 1)
+    gt_masks = r_masks[pick].clone()
+    thres = [x_ / 100 for x_ in range(50, 100, 5)]
+    nc = len(cfg.class_names)
+    ap = {k: [[APDataObject() for _ in range(nc)] for _ in thres] for k in ('box', 'mask')}
+    ids_list = list(ids2.cpu().numpy().astype(int))
+    sc_list = list(sc2.cpu().numpy().astype(float))
+    prep_metrics(ap, ids_list, sc_list, boxes_p, masks_p, gt.clone().to(DEV), gt_masks.to(DEV), img_h, img_w, thres)
+    ref_ap = M.new_ap_data(nc, len(thres))
+    M.prep_metrics(ref_ap, [int(i) for i in r_ids2], [float(s) for s in r_sc2], boxes_p.cpu(), masks_p.cpu(), gt, gt_masks, img_h, img_w,
+                   thres)
+    for kind in ('box', 'mask'):
+        for k in range(len(thres)):
+            for c in range(nc):
+                a, b = ap[kind][k][c], ref_ap[kind][k][c]
+                assert a.num_gt_positives == b.num_gt_positives and [p[1] for p in a.data_points] == [p[1] for p in b.data_points]
+    _, row_box, row_mask = calc_map(ap, thres, nc, step=0)
+    want = M.calc_map(ref_ap, thres, nc)
+    assert row_box[1:] == [round(v, 2) for v in want['box']] and row_mask[1:] == [round(v, 2) for v in want['mask']]
+    assert row_mask[1] > 0                                                                      # some detections matched
+
+    # 4. COCO-json branch: RLE of the detection masks without a dense D2H copy
+    rles = rle_encode(masks_p)
+    mk = masks_p.cpu().numpy()
+    assert rles == [RL.encode(mk[i]) for i in range(n)]
+    mj = MakeJson()
+    for j in range(n):
+        mj.add_bbox(1, ids_list[j], boxes_p[j].cpu().numpy(), sc_list[j])
+        mj.add_mask(1, ids_list[j], rles[j], sc_list[j])
+    assert len(mj.mask_data) == n and mj.mask_data[0]['segmentation']['size'] == [img_h, img_w]
