@@ -82,7 +82,8 @@ typedef struct {
                                 INPUT size, Cout = forward Cin), stride/pad/KH/KW are the forward conv's, and
                                 `weight` comes from ym_pack_conv_weight_dgrad.  Autograd counterpart of every
                                 nn.Conv2d on the path (loss_total.backward(), reference train.py:126). */
-    int32_t stages;          /* workgroup kernel LDS ring depth: 0/2 = double buffer, 3 = loads two K tiles ahead (64-wide tiles) */
+    int32_t stages;          /* workgroup kernel operand staging: 0/2 = registers, double buffer; 3 = registers, loads two K tiles
+                                ahead (64-wide tiles); 22/23/24 = direct global->LDS DMA, ring of 2/3/4 (24: 64x64 tile only) */
     double* bn_sum;          /* optional [Cout] fp64 accumulators (zeroed by the caller): the epilogue adds the */
     double* bn_sumsq;        /* per-channel sum / sum of squares of the conv OUTPUT (train-mode BN statistics).  */
                              /* Only when ym_conv2d_fuses_bn_stats(desc) == 1 (plain NHWC output).               */

@@ -192,6 +192,35 @@ def test_conv_tail_split(case):
     assert not torch.equal(got, base) or tail[1] == 1
 
 
+@pytest.mark.parametrize('case', [
+    # b, cin, h, w, cout, k, stride, pad, act, residual, tile, ksplit
+    (1, 64, 17, 17, 64, 1, 1, 0, 1, False, (64, 64), 1),        # 2 K tiles
+    (1, 32, 9, 9, 64, 1, 1, 0, 0, False, (64, 64), 1),          # 1 K tile: every prefetch is past the end
+    (2, 96, 12, 10, 128, 1, 1, 0, 1, True, (64, 128), 1),       # 3 K tiles
+    (1, 256, 34, 34, 256, 3, 1, 1, 1, False, (64, 64), 6),      # split-K, 12 tiles per slice, padding taps
+    (1, 128, 19, 19, 128, 3, 2, 1, 1, False, (128, 64), 1),     # stride 2
+    (1, 256, 9, 9, 96, 3, 1, 1, 2, False, (64, 128), 2),        # ragged N
+    (2, 256, 20, 20, 256, 3, 1, 1, 1, True, (128, 128), 1),
+    (1, 1024, 13, 13, 256, 1, 1, 0, 1, True, (64, 64), 5),      # uneven slices
+])
+def test_conv_direct_to_lds_parity(case):
+    """stages 22 / 23 / 24: operand tiles DMA'd global -> LDS (`buffer_load ... lds`, XOR-swizzled chunks, ring of 2 / 3 / 4).
+    Same MFMA order as the register-staged kernel -> bit-identical output."""
+    b, cin, h, w, cout, k, stride, pad, act, use_res, tile, ksplit = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    res = torch.randn(b, cout, ho, wo, generator=g) if use_res else None
+    base = run_conv(x, wt, scale, shift, res, stride, pad, act, tile, ksplit, 0, 2)
+    for stages in (22, 23) + ((24,) if tile == (64, 64) else ()):
+        got = run_conv(x, wt, scale, shift, res, stride, pad, act, tile, ksplit, 0, stages)
+        assert torch.equal(got, base), stages
+    torch.testing.assert_close(base, ref_conv(x, wt, scale, shift, res, stride, pad, act), rtol=1e-4, atol=1e-5)
+
+
 WAVE_CASES = [
     # b, cin, h, w, cout, k, stride, pad, act, residual, wave tile, kwaves
     (1, 64, 17, 17, 64, 1, 1, 0, 1, False, (32, 32), 1),

@@ -18,7 +18,7 @@ from yolact_minimal_amd.modules.yolact import Yolact  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default='gpurun_out/tuned_train.json')
-    ap.add_argument('--cfgs', default='res101_coco,res50_coco')
+    ap.add_argument('--cfgs', default='res101_coco,res50_coco,swin_tiny_coco')
     ap.add_argument('--batch', type=int, default=8)
     args = ap.parse_args()
     dev = torch.device('cuda:0')

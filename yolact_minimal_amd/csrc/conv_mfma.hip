@@ -57,13 +57,19 @@ __device__ __forceinline__ void buf_st16_sc1(__amdgpu_buffer_rsrc_t r, unsigned 
 // MODE 2: data gradient (transposed conv): output pixel (ih,iw) gathers dY[(ih+pad-kh)/s][(iw+pad-kw)/s] where divisible.
 // NS: LDS ring depth.  2 = load(t+1) overlaps compute(t).  3 = loads run TWO tiles ahead (small tiles with one workgroup per
 // CU measured 2250 cycles per K tile against 1024 cycles of MFMA with NS=2: one L2 round trip was exposed per tile).
-template <int BM, int BN, int MODE, int NS>
+// DL ("direct to LDS"): operand tiles go global -> LDS with `buffer_load_dwordx4 ... lds` (no staging registers, no ds_write);
+// the LDS image is then [rows][32] floats UNPADDED (the DMA places lane l's 16 bytes at base + 16*l) and bank conflicts are
+// avoided by an XOR swizzle of the 16-byte chunks instead: chunk c of row r lives in slot c ^ ((r >> 1) & 7), so the 16 rows a
+// ds_read_b128 phase touches cover all 16 distinct (row parity, slot) bank groups.  The ring is NS deep with loads NS-1 tiles
+// ahead; the waits are explicit `s_waitcnt vmcnt(n)` + `s_barrier` (a __syncthreads() would drain every outstanding DMA).
+template <int BM, int BN, int MODE, int NS, bool DL = false>
 __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
     constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave (wave tile = BM/2 x BN/2)
     constexpr int AR = BM / 32, BR = BN / 32;   // staging rows per thread
+    constexpr int RP = DL ? 32 : PITCH;         // LDS row pitch in floats
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                         // [NS][BM][PITCH]
-    float* Bs = smem + NS * BM * PITCH;       // [NS][BN][PITCH]
+    float* As = smem;                         // [NS][BM][RP]
+    float* Bs = smem + NS * BM * RP;          // [NS][BN][RP]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
     const int kt_end = min(p.nkt, kt_beg + ktps);
 
     // ---- per-thread staging coordinates -------------------------------------------------------
-    const int c4 = tid & 7;      // which float4 of the 32-float K row
+    const int c4 = DL ? ((tid & 7) ^ ((tid >> 4) & 7)) : (tid & 7);   // which float4 of the 32-float K row (DL: swizzled)
     const int rbase = tid >> 3;  // 0..31
     int a_pix[AR];               // (b*H + ih0)*W + iw0   (may be negative; only used when in range); MODE 2: b*H
     int a_ih0[AR], a_iw0[AR];
@@ -136,14 +142,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
         c0 = (int)uc0; kh = (int)ukh; kw = (int)ukw;
     }
 
-    constexpr int NSET = NS == 3 ? 2 : 1;
-    f32x4 rA[NSET][AR], rB[NSET][BR];
-    auto load_tile = [&](int kt, auto set_c) {
-        constexpr int SET = decltype(set_c)::value;
-        f32x4 (&ra)[AR] = rA[SET];
-        f32x4 (&rb)[BR] = rB[SET];
-        const bool live = kt < kt_end;      // prefetches past the end are issued anyway (OOB -> zeros, never stored):
-                                            // an UNCONDITIONAL load count is what lets hipcc emit counted vmcnt waits
+    // One K tile of both operands: `sink_a(i, byte_offset)` / `sink_b(i, byte_offset)` receive the source offset of this lane's
+    // 16 bytes of staging row i (OOB -> zeros).  Prefetches past the end are issued anyway (never consumed): an UNCONDITIONAL
+    // load count is what keeps the vmcnt waits counted.
+    auto gather_tile = [&](int kt, auto&& sink_a, auto&& sink_b) {
+        const bool live = kt < kt_end;
         if (MODE == 0) {
             const int tap_off = (kh * p.W + kw);
 #pragma unroll
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
                 const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
                 const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
                 const unsigned off = (unsigned)(((a_pix[i] + tap_off) * p.Cin + c0 + c4 * 4) * 4);
-                ra[i] = buf_ld16(rs_in, (ok && live) ? off : OOB);
+                sink_a(i, (ok && live) ? off : OOB);
             }
             c0 += BK;
             if (c0 >= p.Cin) {
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
                 const int yh = th >> sh, yw = tw >> sh;
                 const bool ok = th >= 0 && tw >= 0 && ((th | tw) & smask) == 0 && yh < p.H && yw < p.W;
                 const unsigned off = (unsigned)((((a_pix[i] + yh) * p.W + yw) * p.Cin + c0 + c4 * 4) * 4);
-                ra[i] = buf_ld16(rs_in, (ok && live) ? off : OOB);
+                sink_a(i, (ok && live) ? off : OOB);
             }
             c0 += BK;
             if (c0 >= p.Cin) {
@@ -183,24 +186,36 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
                 const int ih = a_ih0[i] + th, iw = a_iw0[i] + tw;
                 const bool ok = tap_ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
                 const unsigned off = (unsigned)((a_pix[i] + th * p.W + tw) * 16);
-                ra[i] = buf_ld16(rs_in, (ok && live) ? off : OOB);
+                sink_a(i, (ok && live) ? off : OOB);
             }
         }
 #pragma unroll
-        for (int i = 0; i < BR; ++i) rb[i] = buf_ld16(rs_w, (wrow[i] == OOB || !live) ? OOB : wrow[i] + (unsigned)(kt * BK * 4));
+        for (int i = 0; i < BR; ++i) sink_b(i, (wrow[i] == OOB || !live) ? OOB : wrow[i] + (unsigned)(kt * BK * 4));
+    };
+    constexpr int NSET = (NS == 3 && !DL) ? 2 : 1;
+    f32x4 rA[NSET][DL ? 1 : AR], rB[NSET][DL ? 1 : BR];
+    auto load_tile = [&](int kt, auto set_c) {               // register staging
+        constexpr int SET = decltype(set_c)::value;
+        gather_tile(kt, [&](int i, unsigned off) { rA[SET][DL ? 0 : i] = buf_ld16(rs_in, off); },
+                    [&](int i, unsigned off) { rB[SET][DL ? 0 : i] = buf_ld16(rs_w, off); });
     };
     auto store_tile = [&](int buf, auto set_c) {
         constexpr int SET = decltype(set_c)::value;
-        const f32x4 (&ra)[AR] = rA[SET];
-        const f32x4 (&rb)[BR] = rB[SET];
-        float* a = As + buf * BM * PITCH;
-        float* b = Bs + buf * BN * PITCH;
+        float* a = As + buf * BM * RP;
+        float* b = Bs + buf * BN * RP;
 #pragma unroll
         for (int i = 0; i < AR; ++i)
-            *reinterpret_cast<f32x4*>(a + (rbase + 32 * i) * PITCH + c4 * 4) = ra[i];
+            *reinterpret_cast<f32x4*>(a + (rbase + 32 * i) * RP + c4 * 4) = rA[SET][DL ? 0 : i];
 #pragma unroll
         for (int i = 0; i < BR; ++i)
-            *reinterpret_cast<f32x4*>(b + (rbase + 32 * i) * PITCH + c4 * 4) = rb[i];
+            *reinterpret_cast<f32x4*>(b + (rbase + 32 * i) * RP + c4 * 4) = rB[SET][DL ? 0 : i];
+    };
+    auto dma_tile = [&](int kt, int buf) {                   // global -> LDS, asynchronous (tracked by vmcnt)
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        float* a = As + (buf * BM + 8 * wave) * RP;          // wave-uniform; lane l lands at +16*l bytes = row l/8, slot l%8
+        float* b = Bs + (buf * BN + 8 * wave) * RP;
+        gather_tile(kt, [&](int i, unsigned off) { __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr)(a + 32 * i * RP), 16, (int)off, 0, 0, 0); },
+                    [&](int i, unsigned off) { __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(b + 32 * i * RP), 16, (int)off, 0, 0, 0); });
     };
 
     f32x16 acc[TM][TN];
@@ -212,19 +227,22 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int frag_row = lane & 31, khalf = lane >> 5;
-    const int a_frag_off = (wm * (BM / 2) + frag_row) * PITCH + khalf * 4;
-    const int b_frag_off = (wn * (BN / 2) + frag_row) * PITCH + khalf * 4;
+    const int a_frag_off = (wm * (BM / 2) + frag_row) * RP;
+    const int b_frag_off = (wn * (BN / 2) + frag_row) * RP;
+    int goff[4];                  // float offset of K group g's float4 (k = 8g + 4*khalf ..) inside a row
+#pragma unroll
+    for (int g = 0; g < 4; ++g) goff[g] = DL ? (((2 * g + khalf) ^ ((frag_row >> 1) & 7)) * 4) : (g * 8 + khalf * 4);
 
     auto compute = [&](int buf) {
-        const float* a = As + buf * BM * PITCH + a_frag_off;
-        const float* b = Bs + buf * BN * PITCH + b_frag_off;
+        const float* a = As + buf * BM * RP + a_frag_off;
+        const float* b = Bs + buf * BN * RP + b_frag_off;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * PITCH + g * 8);
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * RP + goff[g]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * PITCH + g * 8);
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * RP + goff[g]);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -257,8 +275,28 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
         }
     }
     using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, NS == 3 ? 1 : 0>;
-    if constexpr (NS == 3) {
+    using I1 = std::integral_constant<int, (NS == 3 && !DL) ? 1 : 0>;
+    if constexpr (DL) {
+        constexpr int D = NS - 1;                          // prefetch distance in K tiles
+        constexpr int WAIT = 0xF70 | ((AR + BR) * (D - 1));   // s_waitcnt vmcnt((AR+BR)*(D-1)): everything but the newest D-1 tiles
+        const int nt = kt_end - kt_beg;
+#pragma unroll
+        for (int d = 0; d < D; ++d) dma_tile(kt_beg + d, d);
+        __builtin_amdgcn_s_waitcnt(WAIT);
+        __builtin_amdgcn_s_barrier();
+        YM_STAMP(1);
+        int buf = 0, nb = D;                               // nb = (buf + D) % NS: the buffer tile t-1 was read from
+        for (int t = 0; t < nt; ++t) {
+            dma_tile(kt_beg + t + D, nb);
+            compute(buf);
+            __builtin_amdgcn_s_waitcnt(WAIT);              // tile t+1 of THIS wave has landed ...
+            __builtin_amdgcn_s_barrier();                  // ... and of every wave; everyone is done reading tile t
+            buf = buf == NS - 1 ? 0 : buf + 1;
+            nb = nb == NS - 1 ? 0 : nb + 1;
+        }
+        __builtin_amdgcn_s_waitcnt(0xF70);                 // the past-the-end prefetches still write LDS: drain before reuse
+        __builtin_amdgcn_s_barrier();
+    } else if constexpr (NS == 3) {
         // register sets alternate; tile t+2 is requested while tile t is computed and tile t+1 moves registers -> LDS
         const int nt = kt_end - kt_beg;
         load_tile(kt_beg, I0{});
@@ -588,16 +626,18 @@ int make_plan(const ym_conv_desc* d, Plan* pl) {
     return YM_OK;
 }
 
-template <int BM, int BN, int MODE, int NS = 2>
+template <int BM, int BN, int MODE, int NS = 2, bool DL = false>
 void launch(const ConvP& p, int grid, hipStream_t st) {
-    const size_t lds = (size_t)NS * (BM + BN) * PITCH * sizeof(float);
+    size_t lds = (size_t)NS * (BM + BN) * (DL ? 32 : PITCH) * sizeof(float);
+    const size_t epi = (size_t)BM * (BN + 4) * sizeof(float);          // accumulator staging of the vector epilogue
+    if (lds < epi) lds = epi;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_f32<BM, BN, MODE, NS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_f32<BM, BN, MODE, NS, DL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, MODE, NS>), dim3(grid), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, MODE, NS, DL>), dim3(grid), dim3(256), lds, st, p);
 }
 
 }  // namespace
@@ -675,16 +715,26 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
     hipStream_t st = (hipStream_t)s;
     if (d->kwaves > 0) return ym_launch_conv_wave(p, pl.bm, pl.bn, d->kwaves, st);
     const int grid = pl.grid();
+    // stages: 0/2 register-staged double buffer, 3 register-staged ring of 3 (64-wide tiles), 22/23/24 direct-to-LDS ring of 2/3/4
+#define YM_TILE_CASE(BM_, BN_, MODE_, HAS3_)                                                          \
+    do {                                                                                              \
+        if (d->stages == 23) launch<BM_, BN_, MODE_, 3, true>(p, grid, st);                           \
+        else if (d->stages == 22) launch<BM_, BN_, MODE_, 2, true>(p, grid, st);                      \
+        else if (d->stages == 3 && HAS3_) launch<BM_, BN_, MODE_, HAS3_ ? 3 : 2>(p, grid, st);        \
+        else launch<BM_, BN_, MODE_, 2>(p, grid, st);                                                 \
+    } while (0)
     if (d->transposed) {
-        if (pl.bm == 128 && pl.bn == 128) launch<128, 128, 2>(p, grid, st);
-        else if (pl.bm == 128 && pl.bn == 64) launch<128, 64, 2>(p, grid, st);
-        else if (pl.bm == 64 && pl.bn == 128) launch<64, 128, 2>(p, grid, st);
-        else { if (d->stages == 3) launch<64, 64, 2, 3>(p, grid, st); else launch<64, 64, 2>(p, grid, st); }
+        if (pl.bm == 128 && pl.bn == 128) YM_TILE_CASE(128, 128, 2, false);
+        else if (pl.bm == 128 && pl.bn == 64) YM_TILE_CASE(128, 64, 2, false);
+        else if (pl.bm == 64 && pl.bn == 128) YM_TILE_CASE(64, 128, 2, false);
+        else YM_TILE_CASE(64, 64, 2, true);
     } else if (d->Cin == 4) launch<128, 64, 1>(p, grid, st);
-    else if (pl.bm == 128 && pl.bn == 128) launch<128, 128, 0>(p, grid, st);
-    else if (pl.bm == 128 && pl.bn == 64) { if (d->stages == 3) launch<128, 64, 0, 3>(p, grid, st); else launch<128, 64, 0>(p, grid, st); }
-    else if (pl.bm == 64 && pl.bn == 128) { if (d->stages == 3) launch<64, 128, 0, 3>(p, grid, st); else launch<64, 128, 0>(p, grid, st); }
-    else { if (d->stages == 3) launch<64, 64, 0, 3>(p, grid, st); else launch<64, 64, 0>(p, grid, st); }
+    else if (pl.bm == 128 && pl.bn == 128) YM_TILE_CASE(128, 128, 0, false);
+    else if (pl.bm == 128 && pl.bn == 64) YM_TILE_CASE(128, 64, 0, true);
+    else if (pl.bm == 64 && pl.bn == 128) YM_TILE_CASE(64, 128, 0, true);
+    else if (d->stages == 24) launch<64, 64, 0, 4, true>(p, grid, st);
+    else YM_TILE_CASE(64, 64, 0, true);
+#undef YM_TILE_CASE
     rc = ym_check_launch("conv_igemm_f32");
     if (rc != YM_OK) return rc;
     if (pl.ksplit > 1 && !p.counters) {

@@ -444,13 +444,19 @@ class InferEngine:
                     cands.append(((tm, tn), ks, 0, 2, (0, 0)))
                     if (tm, tn) != (128, 128) and nkt // ks >= 3:
                         cands.append(((tm, tn), ks, 0, 3, (0, 0)))
+                    if not c.stem:                       # direct-to-LDS staging, ring of 2 / 3 (/ 4)
+                        cands.append(((tm, tn), ks, 0, 22, (0, 0)))
+                        if nkt // ks >= 3:
+                            cands.append(((tm, tn), ks, 0, 23, (0, 0)))
+                        if (tm, tn) == (64, 64) and nkt // ks >= 4:
+                            cands.append(((tm, tn), ks, 0, 24, (0, 0)))
                 # workgroup-quantisation fix: split the tiles of the last partial round (over 256 CUs x 1 or 2 workgroups)
                 if not c.stem and d.nseg == 1 and d.tile_counters and 256 < wgs <= hip.TILE_COUNTERS:
                     for r in sorted({wgs % 256, wgs % 512} - {0}):
                         for ts in (2, 3, 4, 6, 8):
                             if ts * 2 > nkt or r * ts > 2048:
                                 continue
-                            for stg in ((2, 3) if (tm, tn) != (128, 128) and nkt // ts >= 3 else (2,)):
+                            for stg in ((2, 3, 22, 23) if (tm, tn) != (128, 128) and nkt // ts >= 3 else (2, 22)):
                                 cands.append(((tm, tn), 1, 0, stg, (r, ts)))
             if not c.stem:
                 for tm, tn in ((32, 32), (64, 32), (32, 64), (64, 64)):

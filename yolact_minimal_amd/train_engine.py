@@ -59,13 +59,16 @@ def _configure_conv(d, key):
                 if ks > 1 and (wgs >= 1024 or ks * 2 > nkt or wgs * ks > 8192):
                     continue
                 cands.append(((tm, tn), ks, 0, 2, (0, 0)))
+                cands.append(((tm, tn), ks, 0, 22, (0, 0)))         # direct-to-LDS staging
                 if (tm, tn) == (64, 64) and nkt // ks >= 3:
                     cands.append(((tm, tn), ks, 0, 3, (0, 0)))
+                    cands.append(((tm, tn), ks, 0, 23, (0, 0)))
             if 256 < wgs <= hip.TILE_COUNTERS:          # split the last partial round of tiles (ym_conv_desc.tail_tiles)
                 for r in sorted({wgs % 256, wgs % 512} - {0}):
                     for ts in (2, 3, 4, 6, 8):
                         if ts * 2 <= nkt and r * ts <= 2048:
                             cands.append(((tm, tn), 1, 0, 2, (r, ts)))
+                            cands.append(((tm, tn), 1, 0, 22, (r, ts)))
         best = (1e30, (0, 0), 0, 0, 0, (0, 0))
         for tile, ks, kwv, stg, tail in cands:
             d.tile_m, d.tile_n, d.ksplit, d.kwaves, d.stages = tile[0], tile[1], ks, kwv, stg
