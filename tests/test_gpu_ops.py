@@ -204,7 +204,8 @@ def test_conv_tail_split(case):
     (1, 1024, 13, 13, 256, 1, 1, 0, 1, True, (64, 64), 5),      # uneven slices
 ])
 def test_conv_direct_to_lds_parity(case):
-    """stages 22 / 23 / 24: operand tiles DMA'd global -> LDS (`buffer_load ... lds`, XOR-swizzled chunks, ring of 2 / 3 / 4).
+    """stages 22 / 23 / 24: operand tiles DMA'd global -> LDS (`buffer_load ... lds`, XOR-swizzled chunks, ring of 2 / 3 / 4);
+    33 / 34: the same with software-pipelined fragment reads across the tile barrier.
     Same MFMA order as the register-staged kernel -> bit-identical output."""
     b, cin, h, w, cout, k, stride, pad, act, use_res, tile, ksplit = case
     g = torch.Generator().manual_seed(hash(case) % 1000)
@@ -215,7 +216,7 @@ def test_conv_direct_to_lds_parity(case):
     ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
     res = torch.randn(b, cout, ho, wo, generator=g) if use_res else None
     base = run_conv(x, wt, scale, shift, res, stride, pad, act, tile, ksplit, 0, 2)
-    for stages in (22, 23) + ((24,) if tile == (64, 64) else ()):
+    for stages in (22, 23) + ((24, 33, 34) if tile == (64, 64) else ()):
         got = run_conv(x, wt, scale, shift, res, stride, pad, act, tile, ksplit, 0, stages)
         assert torch.equal(got, base), stages
     torch.testing.assert_close(base, ref_conv(x, wt, scale, shift, res, stride, pad, act), rtol=1e-4, atol=1e-5)

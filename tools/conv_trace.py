@@ -27,7 +27,7 @@ for spec in ((1, 34, 34, 256, 1024, 1, 1, 1), (1, 34, 34, 1024, 256, 1, 1, 0), (
     d.tail_tiles, d.tail_ksplit = (hit[5], hit[6]) if len(hit) > 6 else (0, 0)
     d.tile_counters = counters.data_ptr()
     print(sig, hit)
-    for stg in (2, 3, 22, 23):
+    for stg in (2, 22, 23, 33, 34):
         d.stages = stg
         for _ in range(3):
             hip.conv2d_fwd(d, ws)

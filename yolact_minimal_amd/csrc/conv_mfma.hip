@@ -62,7 +62,11 @@ __device__ __forceinline__ void buf_st16_sc1(__amdgpu_buffer_rsrc_t r, unsigned 
 // avoided by an XOR swizzle of the 16-byte chunks instead: chunk c of row r lives in slot c ^ ((r >> 1) & 7), so the 16 rows a
 // ds_read_b128 phase touches cover all 16 distinct (row parity, slot) bank groups.  The ring is NS deep with loads NS-1 tiles
 // ahead; the waits are explicit `s_waitcnt vmcnt(n)` + `s_barrier` (a __syncthreads() would drain every outstanding DMA).
-template <int BM, int BN, int MODE, int NS, bool DL = false>
+// PF (with DL): software-pipelined fragments.  The LDS -> register reads of K group g+1 are issued before the MFMAs of group g
+// and the reads of the NEXT tile's first group before the end-of-tile barrier (tile t+1 is required to have landed one barrier
+// early: ring of NS >= 3 with NS-2 tiles still in flight), so the dependent MFMA chain of a wave never waits on LDS or on the
+// barrier round trip: measured 1500 -> ~1100 cycles per K tile for a workgroup that has its CU to itself (the bs=1 regime).
+template <int BM, int BN, int MODE, int NS, bool DL = false, bool PF = false>
 __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
     constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave (wave tile = BM/2 x BN/2)
     constexpr int AR = BM / 32, BR = BN / 32;   // staging rows per thread
@@ -126,11 +130,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
             a_pix[i] = 0;
         }
     }
-    unsigned wrow[BR];           // byte offset of this thread's float4 in weight row n (OOB -> zeros)
+    unsigned wrow[BR];           // byte offset of this thread's float4 in weight row n
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
         const int n = n0 + rbase + 32 * i;
-        wrow[i] = (n < p.Cout) ? (unsigned)((n * p.Kpad + c4 * 4) * 4) : OOB;
+        wrow[i] = (n < p.Cout) ? (unsigned)((n * p.Kpad + c4 * 4) * 4) : p.w_bytes;      // past Cout: parked at the buffer's end
     }
 
     // tap walker for MODE 0 (uniform across the block)
@@ -143,39 +147,43 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
     }
 
     // One K tile of both operands: `sink_a(i, byte_offset)` / `sink_b(i, byte_offset)` receive the source offset of this lane's
-    // 16 bytes of staging row i (OOB -> zeros).  Prefetches past the end are issued anyway (never consumed): an UNCONDITIONAL
-    // load count is what keeps the vmcnt waits counted.
+    // 16 bytes of staging row i.  The per-tile integer work is kept to an add + or per row: everything that depends on the filter
+    // tap (bounds test, pixel offset) is refreshed only when the tap changes (every Cin/32 tiles; never for a 1x1 conv), rows
+    // that must read zeros carry an all-ones mask (offset | 0xFFFFFFF0 is beyond any buffer -> the raw buffer load returns 0), and
+    // weight rows past Cout sit at the END of the buffer so that adding the K offset keeps them out of range.  Tiles past the end
+    // of this block's K range are fetched like any other (the counted vmcnt waits need an unconditional load count) and never
+    // consumed, so they need no special casing — a buffer load cannot fault.
+    unsigned a_tapbase[AR], a_mask[AR];
+    bool tap_dirty = true;
     auto gather_tile = [&](int kt, auto&& sink_a, auto&& sink_b) {
-        const bool live = kt < kt_end;
-        if (MODE == 0) {
-            const int tap_off = (kh * p.W + kw);
+        if (MODE == 0 || MODE == 2) {
+            if (tap_dirty) {                                  // block-uniform
+                tap_dirty = false;
 #pragma unroll
-            for (int i = 0; i < AR; ++i) {
-                const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
-                const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-                const unsigned off = (unsigned)(((a_pix[i] + tap_off) * p.Cin + c0 + c4 * 4) * 4);
-                sink_a(i, (ok && live) ? off : OOB);
+                for (int i = 0; i < AR; ++i) {
+                    if (MODE == 0) {
+                        const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+                        const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                        a_tapbase[i] = (unsigned)(((a_pix[i] + kh * p.W + kw) * p.Cin + c4 * 4) * 4);
+                        a_mask[i] = ok ? 0u : OOB;
+                    } else {
+                        const int sh = p.stride >> 1, smask = p.stride - 1;     // stride is 1 or 2
+                        const int th = a_ih0[i] - kh, tw = a_iw0[i] - kw;
+                        const int yh = th >> sh, yw = tw >> sh;
+                        const bool ok = th >= 0 && tw >= 0 && ((th | tw) & smask) == 0 && yh < p.H && yw < p.W;
+                        a_tapbase[i] = (unsigned)((((a_pix[i] + yh) * p.W + yw) * p.Cin + c4 * 4) * 4);
+                        a_mask[i] = ok ? 0u : OOB;
+                    }
+                }
             }
+            const unsigned c0b = (unsigned)(c0 * 4);
+#pragma unroll
+            for (int i = 0; i < AR; ++i) sink_a(i, (a_tapbase[i] + c0b) | a_mask[i]);
             c0 += BK;
             if (c0 >= p.Cin) {
                 c0 = 0;
                 if (++kw == p.KW) { kw = 0; ++kh; }
-            }
-        } else if (MODE == 2) {
-            const int sh = p.stride >> 1;            // stride is 1 or 2
-            const int smask = p.stride - 1;
-#pragma unroll
-            for (int i = 0; i < AR; ++i) {
-                const int th = a_ih0[i] - kh, tw = a_iw0[i] - kw;
-                const int yh = th >> sh, yw = tw >> sh;
-                const bool ok = th >= 0 && tw >= 0 && ((th | tw) & smask) == 0 && yh < p.H && yw < p.W;
-                const unsigned off = (unsigned)((((a_pix[i] + yh) * p.W + yw) * p.Cin + c0 + c4 * 4) * 4);
-                sink_a(i, (ok && live) ? off : OOB);
-            }
-            c0 += BK;
-            if (c0 >= p.Cin) {
-                c0 = 0;
-                if (++kw == p.KW) { kw = 0; ++kh; }
+                tap_dirty = true;
             }
         } else {
             const int tap = kt * 8 + c4;  // Cin == 4: one tap per float4
@@ -186,11 +194,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
                 const int ih = a_ih0[i] + th, iw = a_iw0[i] + tw;
                 const bool ok = tap_ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
                 const unsigned off = (unsigned)((a_pix[i] + th * p.W + tw) * 16);
-                sink_a(i, (ok && live) ? off : OOB);
+                sink_a(i, ok ? off : OOB);
             }
         }
+        const unsigned kb = (unsigned)(kt * BK * 4);
 #pragma unroll
-        for (int i = 0; i < BR; ++i) sink_b(i, (wrow[i] == OOB || !live) ? OOB : wrow[i] + (unsigned)(kt * BK * 4));
+        for (int i = 0; i < BR; ++i) sink_b(i, wrow[i] + kb);
     };
     constexpr int NSET = (NS == 3 && !DL) ? 2 : 1;
     f32x4 rA[NSET][DL ? 1 : AR], rB[NSET][DL ? 1 : BR];
@@ -226,6 +235,15 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // A wave with ONE 32x32 accumulator tile (the 64x64 workgroup tile) would issue 16 MFMAs per K tile that all depend on each
+    // other through the accumulator: measured ~88 cycles per dependent v_mfma_f32_32x32x2 (64 of work + a forwarding bubble),
+    // i.e. 1400 instead of 1024 cycles per K tile when the wave has its SIMD to itself (the bs=1 regime).  Two accumulators that
+    // take alternate K steps make consecutive MFMAs independent; they are summed once after the K loop.
+    constexpr bool DUAL = TM * TN == 1;
+    f32x16 acc_odd;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_odd[r] = 0.f;
+
     const int frag_row = lane & 31, khalf = lane >> 5;
     const int a_frag_off = (wm * (BM / 2) + frag_row) * RP;
     const int b_frag_off = (wn * (BN / 2) + frag_row) * RP;
@@ -244,12 +262,18 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * RP + goff[g]);
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s) {
+                if constexpr (DUAL) {
+                    if (s & 1) acc_odd = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][s], fb[0][s], acc_odd, 0, 0, 0);
+                    else acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][s], fb[0][s], acc[0][0], 0, 0, 0);
+                } else {
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+                }
+            }
         }
     };
     // Epilogue operands of the plain path (BN scale/shift, residual rows) are requested BEFORE the K loop: at bs=1 a launch
@@ -276,7 +300,68 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
     }
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, (NS == 3 && !DL) ? 1 : 0>;
-    if constexpr (DL) {
+    if constexpr (DL && PF) {
+        static_assert(NS >= 3, "fragment prefetch needs a ring of 3+");
+        constexpr int D = NS - 1;
+        constexpr int WAIT = 0xF70 | ((AR + BR) * (D - 2));   // tiles <= t+1 landed at the barrier that ends tile t-1
+        const int nt = kt_end - kt_beg;
+        auto read_frag = [&](int buf, int g, f32x4 (&fa)[TM], f32x4 (&fb)[TN]) {
+            const float* a = As + buf * BM * RP + a_frag_off + goff[g];
+            const float* b = Bs + buf * BN * RP + b_frag_off + goff[g];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * RP);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * RP);
+        };
+        auto mfma_group = [&](const f32x4 (&fa)[TM], const f32x4 (&fb)[TN]) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                if constexpr (DUAL) {
+                    if (s4 & 1) acc_odd = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][s4], fb[0][s4], acc_odd, 0, 0, 0);
+                    else acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][s4], fb[0][s4], acc[0][0], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s4], fb[j][s4], acc[i][j], 0, 0, 0);
+                }
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < D; ++d) dma_tile(kt_beg + d, d);
+        __builtin_amdgcn_s_waitcnt(WAIT);
+        __builtin_amdgcn_s_barrier();
+        YM_STAMP(1);
+        f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+        read_frag(0, 0, fa0, fb0);
+        int buf = 0, nb = D;
+        for (int t = 0; t < nt; ++t) {
+            const int buf1 = buf == NS - 1 ? 0 : buf + 1;
+            dma_tile(kt_beg + t + D, nb);
+            read_frag(buf, 1, fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_frag(buf, 2, fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            read_frag(buf, 3, fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_frag(buf1, 0, fa0, fb0);                  // first group of tile t+1 (landed one barrier ago)
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(fa1, fb1);
+            __builtin_amdgcn_s_waitcnt(WAIT);
+            __builtin_amdgcn_s_barrier();
+            buf = buf1;
+            nb = nb == NS - 1 ? 0 : nb + 1;
+        }
+        __builtin_amdgcn_s_waitcnt(0xF70);
+        __builtin_amdgcn_s_barrier();
+    } else if constexpr (DL) {
         constexpr int D = NS - 1;                          // prefetch distance in K tiles
         constexpr int WAIT = 0xF70 | ((AR + BR) * (D - 1));   // s_waitcnt vmcnt((AR+BR)*(D-1)): everything but the newest D-1 tiles
         const int nt = kt_end - kt_beg;
@@ -334,6 +419,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
         }
     }
 
+    if constexpr (DUAL) acc[0][0] += acc_odd;
     YM_STAMP(2);
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) --
     if (p.vec) {
@@ -626,18 +712,18 @@ int make_plan(const ym_conv_desc* d, Plan* pl) {
     return YM_OK;
 }
 
-template <int BM, int BN, int MODE, int NS = 2, bool DL = false>
+template <int BM, int BN, int MODE, int NS = 2, bool DL = false, bool PF = false>
 void launch(const ConvP& p, int grid, hipStream_t st) {
     size_t lds = (size_t)NS * (BM + BN) * (DL ? 32 : PITCH) * sizeof(float);
     const size_t epi = (size_t)BM * (BN + 4) * sizeof(float);          // accumulator staging of the vector epilogue
     if (lds < epi) lds = epi;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_f32<BM, BN, MODE, NS, DL>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_f32<BM, BN, MODE, NS, DL, PF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, MODE, NS, DL>), dim3(grid), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, MODE, NS, DL, PF>), dim3(grid), dim3(256), lds, st, p);
 }
 
 }  // namespace
@@ -676,7 +762,7 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
     p.stride = d->stride; p.pad = d->pad; p.Ho = d->Ho; p.Wo = d->Wo; p.Kpad = d->k_pad;
     {
         const unsigned long long ib = (unsigned long long)d->B * d->H * d->W * d->Cin * 4ull, wb = (unsigned long long)d->Cout * d->k_pad * 4ull;
-        YM_REQUIRE(ib < 0xFFFFFFF0ull && wb < 0xFFFFFFF0ull, "conv: input / weight tensor must be < 4 GiB (32-bit buffer offsets)");
+        YM_REQUIRE(ib < 0xFFFFFFF0ull && wb < 0x7FFFFFF0ull, "conv: input must be < 4 GiB and the packed weight < 2 GiB (32-bit buffer offsets)");
         p.in_bytes = (unsigned)ib; p.w_bytes = (unsigned)wb;
     }
     p.M = pl.M; p.HoWo = d->Ho * d->Wo; p.nkt = pl.nkt; p.ksplit = pl.ksplit; p.kt_per_split = pl.kt_per_split;
@@ -715,7 +801,8 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
     hipStream_t st = (hipStream_t)s;
     if (d->kwaves > 0) return ym_launch_conv_wave(p, pl.bm, pl.bn, d->kwaves, st);
     const int grid = pl.grid();
-    // stages: 0/2 register-staged double buffer, 3 register-staged ring of 3 (64-wide tiles), 22/23/24 direct-to-LDS ring of 2/3/4
+    // stages: 0/2 register-staged double buffer, 3 register-staged ring of 3 (64-wide tiles), 22/23/24 direct-to-LDS ring of 2/3/4,
+    // 33/34 direct-to-LDS ring of 3/4 with software-pipelined fragments (64x64 forward tile)
 #define YM_TILE_CASE(BM_, BN_, MODE_, HAS3_)                                                          \
     do {                                                                                              \
         if (d->stages == 23) launch<BM_, BN_, MODE_, 3, true>(p, grid, st);                           \
@@ -733,6 +820,8 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
     else if (pl.bm == 128 && pl.bn == 64) YM_TILE_CASE(128, 64, 0, true);
     else if (pl.bm == 64 && pl.bn == 128) YM_TILE_CASE(64, 128, 0, true);
     else if (d->stages == 24) launch<64, 64, 0, 4, true>(p, grid, st);
+    else if (d->stages == 33) launch<64, 64, 0, 3, true, true>(p, grid, st);
+    else if (d->stages == 34) launch<64, 64, 0, 4, true, true>(p, grid, st);
     else YM_TILE_CASE(64, 64, 0, true);
 #undef YM_TILE_CASE
     rc = ym_check_launch("conv_igemm_f32");

@@ -450,13 +450,16 @@ class InferEngine:
                             cands.append(((tm, tn), ks, 0, 23, (0, 0)))
                         if (tm, tn) == (64, 64) and nkt // ks >= 4:
                             cands.append(((tm, tn), ks, 0, 24, (0, 0)))
+                        if (tm, tn) == (64, 64) and nkt // ks >= 2:    # + software-pipelined fragments
+                            cands.append(((tm, tn), ks, 0, 33, (0, 0)))
+                            cands.append(((tm, tn), ks, 0, 34, (0, 0)))
                 # workgroup-quantisation fix: split the tiles of the last partial round (over 256 CUs x 1 or 2 workgroups)
                 if not c.stem and d.nseg == 1 and d.tile_counters and 256 < wgs <= hip.TILE_COUNTERS:
                     for r in sorted({wgs % 256, wgs % 512} - {0}):
                         for ts in (2, 3, 4, 6, 8):
                             if ts * 2 > nkt or r * ts > 2048:
                                 continue
-                            for stg in ((2, 3, 22, 23) if (tm, tn) != (128, 128) and nkt // ts >= 3 else (2, 22)):
+                            for stg in ((2, 3, 22, 23) + ((33, 34) if (tm, tn) == (64, 64) else ()) if (tm, tn) != (128, 128) and nkt // ts >= 3 else (2, 22)):
                                 cands.append(((tm, tn), 1, 0, stg, (r, ts)))
             if not c.stem:
                 for tm, tn in ((32, 32), (64, 32), (32, 64), (64, 64)):
