@@ -171,7 +171,18 @@ def test_train_step_matches_reference_golden(golden_dir):
     l64, g64, _ = _oracle_grads(net, sd0, img, boxes, masks, torch.float64)
 
     net = net.to(DEV)
-    losses = net(img.to(DEV), [b.to(DEV) for b in boxes], [m.to(DEV) for m in masks])
+    from yolact_minimal_amd import train_engine as TE
+    seen, conv_bias = {}, TE._conv_bias
+
+    def spy(x, conv, *a, **k):                       # keep the ReLU outputs of the FPN prediction convs (see `flipped` below)
+        y = conv_bias(x, conv, *a, **k)
+        seen[id(conv)] = y.detach()
+        return y
+    TE._conv_bias = spy
+    try:
+        losses = net(img.to(DEV), [b.to(DEV) for b in boxes], [m.to(DEV) for m in masks])
+    finally:
+        TE._conv_bias = conv_bias
     sum(losses).backward()
     got = np.array([float(l.detach()) for l in losses])
     np.testing.assert_allclose(got, g['losses'], rtol=2e-4)          # the reference's own numbers
@@ -187,8 +198,27 @@ def test_train_step_matches_reference_golden(golden_dir):
             if k.startswith(('prediction_layers', 'semantic_seg_conv', 'fpn.pred_layers', 'fpn.downsample_layers'))}
     # (tools/diag_chain.py shows the same FPN/seg/proto chain exact to 4e-7 on well-conditioned inputs; in the full
     #  net the P3 branch inherits forward noise amplified by the 8-sample BatchNorms)
-    bad = {k: v for k, v in tail.items() if v[0] > max(1e-2, 4 * v[1])}
-    assert not bad, bad
+    # A ReLU whose fp64 pre-activation is inside the forward noise (~5e-4 here) can come out on the other side on the GPU: that
+    # is a DISCRETE change of that layer's gradient (its 0/1 mask differs in one unit), not rounding — found with
+    # tools/diag_ohem.py: one flip (|ref| = 1.4e-4) in the 2x256x4x4 P4 map moves d(fpn.pred_layers.1) by 5-8 %.  Layers
+    # whose own output flipped are held to the conditioning bound above only.
+    with torch.no_grad():
+        p64 = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+        tn = R.TrainNet(p64)
+        x = F.max_pool2d(F.relu(tn.bn(tn.conv(img.double(), 'backbone.conv1', 2, 3), 'backbone.bn1')), 3, 2, 1)
+        outs = []
+        for li, nblk in enumerate(R.resnet_layers_from_sd(p64)):
+            for bi in range(nblk):
+                x = tn.bottleneck(x, f'backbone.layers.{li}.{bi}', 2 if (bi == 0 and li > 0) else 1)
+            outs.append(x)
+        levels = R.fpn(outs[1], outs[2], outs[3], p64)
+    flipped = set()
+    for lv, conv in enumerate(net.fpn.pred_layers):
+        gpu = seen[id(conv[0])].cpu().double().permute(0, 3, 1, 2)
+        if bool(((gpu > 0) != (levels[lv] > 0)).any()):
+            flipped.add(f'fpn.pred_layers.{lv}.0')
+    bad = {k: v for k, v in tail.items() if v[0] > max(1e-2, 4 * v[1]) and k.rsplit('.', 1)[0] not in flipped}
+    assert not bad, (bad, flipped)
     gc1 = net.backbone.conv1.weight.grad.cpu().numpy()
     assert np.abs(gc1 - g['grad_conv1']).max() <= 0.1 * np.abs(g['grad_conv1']).max()
     np.testing.assert_allclose(net.backbone.bn1.running_mean.cpu().numpy(), g['run_mean_stem'], rtol=1e-4, atol=1e-6)
@@ -415,3 +445,41 @@ def test_trainer_checkpoint_resume_continues_the_run(tmp_path):
     torch.testing.assert_close(a.opt.flat, b.opt.flat, rtol=1e-4, atol=1e-6)
     net = Yolact(cfg)
     net.load_state_dict(torch.load(str(tmp_path / 'ckpt.pt'))['model'], strict=True)
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,hw,b', [(256, 256, 3, 1, 4, 2), (64, 128, 3, 2, 20, 2), (256, 96, 3, 1, 9, 1),
+                                                    (1024, 256, 1, 1, 12, 2), (128, 256, 1, 2, 12, 1)])
+def test_conv_dgrad_staging_variants_agree(cin, cout, k, stride, hw, b):
+    """Data gradient (transposed gather, MODE 2) under every operand-staging variant of the tuned table (register double
+    buffer / ring of 3, direct-to-LDS ring of 2 / 3) and a K split: identical results, equal to autograd of F.conv2d."""
+    from yolact_minimal_amd import train_engine as T
+    from yolact_minimal_amd.engine import tuned_table
+    g = torch.Generator().manual_seed(cin + cout + k + hw)
+    pad = k // 2
+    x = torch.randn(b, cin, hw, hw, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * (1 / (cin * k * k) ** 0.5)
+    ho = (hw + 2 * pad - k) // stride + 1
+    dy = torch.randn(b, cout, ho, ho, generator=g)
+    xr = x.double().requires_grad_()
+    (F.conv2d(xr, w.double(), None, stride, pad) * dy.double()).sum().backward()
+    cout_pad = (cout + 31) // 32 * 32
+    dz = torch.zeros(b, ho, ho, cout_pad)
+    dz[..., :cout] = dy.permute(0, 2, 3, 1)
+    key = f'T_M{b * hw * hw}_N{cin}_C{cout_pad}_k{k}_s{stride}'
+    table = tuned_table()
+    saved = table.get(key)
+    outs = {}
+    try:
+        for name, cfg_ in (('reg2', [64, 64, 1, 0, 2, 0, 0]), ('reg3', [64, 64, 1, 0, 3, 0, 0]), ('dl2', [64, 64, 1, 0, 22, 0, 0]),
+                           ('dl3', [64, 64, 1, 0, 23, 0, 0]), ('dl2_128', [128, 128, 1, 0, 22, 0, 0]), ('dl2_ks3', [64, 64, 3, 0, 22, 0, 0])):
+            table[key] = cfg_
+            outs[name] = T._conv_dgrad(dz.to(DEV), w.to(DEV), cout_pad, (b, hw, hw, cin), stride, pad).cpu()
+    finally:
+        if saved is None:
+            table.pop(key, None)
+        else:
+            table[key] = saved
+    want = xr.grad.permute(0, 2, 3, 1)
+    for name, o in outs.items():
+        torch.testing.assert_close(o.double(), want, rtol=1e-4, atol=1e-5, msg=lambda m, name=name: f'{name}: {m}')
+    assert torch.equal(outs['reg2'], outs['dl2']) and torch.equal(outs['reg2'], outs['reg3']) and torch.equal(outs['reg2'], outs['dl3'])
