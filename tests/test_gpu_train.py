@@ -483,3 +483,20 @@ def test_conv_dgrad_staging_variants_agree(cin, cout, k, stride, hw, b):
     for name, o in outs.items():
         torch.testing.assert_close(o.double(), want, rtol=1e-4, atol=1e-5, msg=lambda m, name=name: f'{name}: {m}')
     assert torch.equal(outs['reg2'], outs['dl2']) and torch.equal(outs['reg2'], outs['reg3']) and torch.equal(outs['reg2'], outs['dl3'])
+
+
+@pytest.mark.parametrize('cfg_name', ['res50_coco', 'swin_tiny_coco'])
+def test_two_rank_training_keeps_replicas_identical(cfg_name):
+    """Two real processes (torch.distributed.run, gloo so that both ranks may share this box's single GPU) run the HIP
+    training step with the flat-buffer gradient reducer: different shards, different initial seeds -> after 3 steps every rank
+    holds bit-identical parameters and momentum (weights broadcast from rank 0, gradients averaged bucket by bucket)."""
+    import subprocess
+    import sys
+    from tests.conftest import REPO
+    env = dict(os.environ, YM_DIST_BACKEND='gloo', YM_CHECK_CFG=cfg_name, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29541', os.path.join(REPO, 'tools', 'ddp_check.py')]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    line = [l for l in out.stdout.splitlines() if l.startswith('DDP_CHECK')][-1]
+    assert ' OK ' in line and 'world 2' in line, line

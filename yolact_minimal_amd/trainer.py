@@ -27,7 +27,7 @@ def init_distributed(backend=None):
     force = os.environ.get('YM_FORCE_DIST', '0') == '1'      # exercise the collective path with a single rank (tests)
     if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            backend = os.environ.get('YM_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         dist.init_process_group(backend=backend, init_method='env://')
     return rank, world, local_rank
 
