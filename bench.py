@@ -264,12 +264,14 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', args.local_rank or 0))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
+    local_rank %= torch.cuda.device_count()          # (tests run two gloo ranks on a 1-GPU box; one rank per GPU otherwise)
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     dist = None
     if world > 1 or os.environ.get('YM_FORCE_DIST', '0') == '1':
         import torch.distributed as dist
-        dist.init_process_group(backend='nccl', init_method='env://')   # nccl == RCCL on ROCm
+        # nccl == RCCL on ROCm; YM_DIST_BACKEND=gloo only for the 2-ranks-on-one-GPU control-flow test
+        dist.init_process_group(backend=os.environ.get('YM_DIST_BACKEND', 'nccl'), init_method='env://')
 
     def barrier():
         if dist is not None:

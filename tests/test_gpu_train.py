@@ -500,3 +500,24 @@ def test_two_rank_training_keeps_replicas_identical(cfg_name):
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
     line = [l for l in out.stdout.splitlines() if l.startswith('DDP_CHECK')][-1]
     assert ' OK ' in line and 'world 2' in line, line
+
+
+def test_bench_two_ranks_control_flow():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one JSON line from rank 0, barrier + MAX over
+    ranks, whole-job img/s), with gloo so that both ranks can share this box's GPU: inference replicas + the 2-rank training leg."""
+    import json
+    import subprocess
+    import sys
+    from tests.conftest import REPO
+    env = dict(os.environ, YM_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29547', os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--cfg',
+           'res50_coco', '--img_size', '256', '--train-batch', '2', '--train-steps', '2']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, lines                       # exactly ONE JSON line (rank 0)
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['value'] > 0 and d['scaling'] == 'weak' and d['config']['global_batch'] == 2
+    assert d['extra']['train']['global_batch'] == 4 and d['extra']['train']['finite'] and 'ddp2' in d['extra']['train']['parallelism']
+    assert d['cpu_baseline'] is None                    # the CPU leg runs at N=1 only
