@@ -47,6 +47,8 @@ def parse():
     ap.add_argument('--train-batch', type=int, default=8, help='images per GPU per training step')
     ap.add_argument('--train-steps', type=int, default=6)
     ap.add_argument('--no-train', action='store_true', help='skip the DDP training measurement')
+    ap.add_argument('--pipeline', action='store_true', help='bs=1: serving order (post-processing of image i overlaps the forward of '
+                    'image i+1 on a second stream); measured 304 vs 311 img/s sequential on MI355X, so it is not the default')
     ap.add_argument('--local_rank', type=int, default=None)
     return ap.parse_args()
 
@@ -84,6 +86,24 @@ class Workload:
             for _ in range(self.batch):
                 r = nms(cls, box, coef, proto, self.anchors, self.cfg)
                 after_nms(r[0], r[1], r[2], r[3], r[4], 480, 640, self.cfg)
+
+
+class PipelinedWorkload(Workload):
+    """bs=1 serving order (`yolact_minimal_amd.serving.ServingPipeline`): the forward of image i+1 is in flight on one stream
+    while nms + after_nms of image i run on another.  One step = one forward submitted + one image post-processed, so K steps
+    are K complete forward + nms + after_nms passes (the trailing forward also finishes inside the timed region)."""
+
+    def __init__(self, net, cfg, batch, img_size, device, **kw):
+        super().__init__(net, cfg, batch, img_size, device, **kw)
+        from yolact_minimal_amd.serving import ServingPipeline
+        assert batch == 1
+        self.pipe = ServingPipeline(net, cfg, img_size, device)
+
+    def step(self):
+        p = self.pipe
+        p.submit(self.img)
+        if p.submitted - p.collected == 2:
+            p.collect(480, 640, post_inputs=self.head)
 
 
 def timed(workload, steps, warmup, barrier):
@@ -278,7 +298,8 @@ def main():
             dist.barrier()
 
     net, cfg = build_net(args.cfg, args.img_size, device)
-    wl = Workload(net, cfg, args.batch, args.img_size, device, with_post=not args.no_post)
+    pipelined = args.batch == 1 and not args.no_post and args.pipeline
+    wl = (PipelinedWorkload if pipelined else Workload)(net, cfg, args.batch, args.img_size, device, with_post=not args.no_post)
     elapsed = timed(wl, args.steps, args.warmup, barrier)
     if dist is not None:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -312,7 +333,11 @@ def main():
                         kernel='conv_igemm_f32 (all instantiations)', launches_per_step=launches,
                         flops_per_launch=round(flops / launches), avg_launch_us=round(conv_secs / launches * 1e6, 2),
                         conv_ms_per_step=round(conv_secs * 1e3, 3))
-        extra = dict(forward_only_ms=round(t_fwd * 1e3, 3),
+        seq = None
+        if pipelined:                                 # the reference's strictly sequential per-image order, for comparison
+            sq = Workload(net, cfg, args.batch, args.img_size, device, with_post=True)
+            seq = args.batch * args.steps / timed(sq, args.steps, 2, lambda: None)
+        extra = dict(sequential_img_s=round(seq, 2) if seq else None, forward_only_ms=round(t_fwd * 1e3, 3),
                      forward_only_img_s=round(args.batch / t_fwd, 1),
                      forward_tflops=round(flops / t_fwd / 1e12, 2),
                      gflop_per_img=round(flops / args.batch / 1e9, 1))
@@ -352,7 +377,9 @@ def main():
             'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'{args.cfg} 544x544 (the reference\'s "550-class" size) bs={args.batch} inference: '
-                                   f'forward + nms + after_nms(480x640) per image' if not args.no_post else
+                                   f'forward + nms + after_nms(480x640) per image'
+                                   + (', serving order: post-processing of image i overlaps the forward of image i+1 (2 streams)'
+                                      if pipelined else '') if not args.no_post else
                                    f'{args.cfg} 544x544 bs={args.batch} forward only',
                        'global_batch': args.batch * world, 'parallelism': f'replicas x{world} (inference does not shard)',
                        'weights': 'seeded random init', 'post_inputs': 'synthetic dense head outputs (17.8k candidates)'},
