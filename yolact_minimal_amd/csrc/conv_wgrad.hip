@@ -25,6 +25,7 @@ struct WgradP {
     float* ws;          // [msplit][Cout][Ktot]
     int B, H, W, Cinp, Cout, KH, KW, stride, pad, Ho, Wo;
     int M, HoWo, Ktot, tiles_n, tiles_k, msplit, m_per_split;
+    int incr;          // 1: pixel coordinates advanced incrementally (a 32-pixel step wraps at most two image rows + one image)
     unsigned x_bytes, dy_bytes;
     unsigned mg_howo, sh_howo, mg_wo, sh_wo;   // division by invariant integers (q = (mulhi(m, mg) + m) >> sh)
 };
@@ -36,6 +37,7 @@ __device__ __forceinline__ f32x4 buf_ld16(__amdgpu_buffer_rsrc_t r, unsigned byt
 }
 __device__ __forceinline__ unsigned fastdiv(unsigned m, unsigned mg, unsigned sh) { return (__umulhi(m, mg) + m) >> sh; }
 
+template <int INCR>
 __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ys = smem;                       // [2][TBM][LP]
@@ -62,21 +64,51 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradP p) {
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
     f32x4 ry[4], rx[4];
-    // branch-free: raw buffer loads return zeros beyond the descriptor (rows past the slice, padding taps, tile tails),
-    // and the prefetch is issued unconditionally so the compiler keeps counted vmcnt waits.
+    // Branch-free operand fetch (raw buffer loads return zeros beyond the descriptor: rows past the slice, padding taps, tile
+    // tails) with the per-step integer work kept small: the output-pixel coordinates (b, oh, ow) of each staging row are carried
+    // across steps and ADVANCED by the 32-pixel step (a couple of compares) instead of being re-derived with two divisions per
+    // row per step; everything that does not depend on the pixel (tap, channel, column masks) is hoisted.  INCR = 0 keeps the
+    // division path for maps so small that one step wraps more than two image rows.
+    int pb[4], poh[4], pow_[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned m = (unsigned)(m_beg + r0 + 8 * i);
+        const unsigned b = fastdiv(m, p.mg_howo, p.sh_howo);
+        const unsigned rem = m - b * p.HoWo;
+        const unsigned oh = fastdiv(rem, p.mg_wo, p.sh_wo);
+        pb[i] = (int)b; poh[i] = (int)oh; pow_[i] = (int)(rem - oh * p.Wo);
+    }
+    const unsigned ymask = n_ok ? 0u : OOB, xmask = k_ok ? 0u : OOB;
+    const unsigned ycol = (unsigned)(ncol * 4), xcol = (unsigned)(ci * 4);
+    const int dq = TBM / p.Wo, dr = TBM - dq * p.Wo;                  // a 32-pixel step = dq rows + dr columns
     auto load = [&](int mt) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = mt + r0 + 8 * i;
-            const bool live = m < m_end;
-            ry[i] = buf_ld16(rs_y, (live && n_ok) ? (unsigned)((m * p.Cout + ncol) * 4) : OOB);
-            const unsigned b = fastdiv((unsigned)m, p.mg_howo, p.sh_howo);
-            const unsigned rem = (unsigned)m - b * p.HoWo;
-            const unsigned oh = fastdiv(rem, p.mg_wo, p.sh_wo);
-            const unsigned ow = rem - oh * p.Wo;
-            const int ih = (int)oh * p.stride - p.pad + kh, iw = (int)ow * p.stride - p.pad + kw;
-            const bool ok = live && k_ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            rx[i] = buf_ld16(rs_x, ok ? (unsigned)(((((int)b * p.H + ih) * p.W + iw) * p.Cinp + ci) * 4) : OOB);
+            const unsigned dead = m < m_end ? 0u : OOB;
+            ry[i] = buf_ld16(rs_y, ((unsigned)(m * p.Cout) * 4u + ycol) | ymask | dead);
+            const int ih = poh[i] * p.stride - p.pad + kh, iw = pow_[i] * p.stride - p.pad + kw;
+            const unsigned inside = ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) ? 0u : OOB;
+            rx[i] = buf_ld16(rs_x, ((unsigned)(((pb[i] * p.H + ih) * p.W + iw) * p.Cinp) * 4u + xcol) | xmask | dead | inside);
+            if (INCR) {                                                // advance this row by TBM pixels
+                int ow = pow_[i] + dr, oh = poh[i] + dq;
+                const bool c = ow >= p.Wo;
+                ow -= c ? p.Wo : 0;
+                oh += c ? 1 : 0;
+                bool c2 = oh >= p.Ho;
+                oh -= c2 ? p.Ho : 0;
+                pb[i] += c2 ? 1 : 0;
+                c2 = oh >= p.Ho;                                       // (a step may wrap two image rows' worth on small maps)
+                oh -= c2 ? p.Ho : 0;
+                pb[i] += c2 ? 1 : 0;
+                pow_[i] = ow; poh[i] = oh;
+            } else {
+                const unsigned mn = (unsigned)(m + TBM);
+                const unsigned b = fastdiv(mn, p.mg_howo, p.sh_howo);
+                const unsigned rem = mn - b * p.HoWo;
+                const unsigned oh = fastdiv(rem, p.mg_wo, p.sh_wo);
+                pb[i] = (int)b; poh[i] = (int)oh; pow_[i] = (int)(rem - oh * p.Wo);
+            }
         }
     };
     auto store = [&](int buf) {
@@ -220,10 +252,15 @@ extern "C" int ym_conv2d_wgrad(const ym_wgrad_desc* d, void* workspace, size_t w
     const size_t lds = (size_t)4 * TBM * LP * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_f32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_f32<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_f32<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv_wgrad_f32, dim3(pl.tiles_n * pl.tiles_k * pl.msplit), dim3(256), lds, st, p);
+    // incremental coordinates need: (rows advanced per step) + 1 < 2 * Ho, so that two conditional wraps suffice
+    p.incr = (TBM / d->Wo + 2 <= 2 * d->Ho) ? 1 : 0;
+    const dim3 wgrid(pl.tiles_n * pl.tiles_k * pl.msplit);
+    if (p.incr) hipLaunchKernelGGL(conv_wgrad_f32<1>, wgrid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL(conv_wgrad_f32<0>, wgrid, dim3(256), lds, st, p);
     rc = ym_check_launch("conv_wgrad_f32");
     if (rc != YM_OK) return rc;
     const size_t total = (size_t)d->Cout_real * pl.Ktot;

@@ -96,7 +96,11 @@ def _configure_wgrad(d, key):
     if hit is None and _TUNING:
         big = scratch(torch.device('cuda', torch.cuda.current_device()), 1 << 28)
         best = (1e30, 0)
-        for ms in (0, 1, 2, 4, 8, 16, 32, 64, 128, 256):
+        tiles = -(-d.Cout // 128) * -(-(d.KH * d.KW * d.Cin) // 128)
+        # pixel splits that make the grid a whole number of rounds of the chip (2 workgroups of 68 KB LDS per CU = 512 slots):
+        # power-of-two splits alone left e.g. 756 workgroups = 1.5 rounds for the layer3 3x3 (msplit 14 -> 504 = one round)
+        fill = {max(1, round(256 * j / tiles)) for j in (1, 2, 3, 4, 6, 8, 12, 16)} | {max(1, (256 * j) // tiles) for j in (2, 4, 6, 8)}
+        for ms in sorted({0, 1, 2, 4, 8, 16, 32, 64, 128, 256} | {m_ for m_ in fill if m_ <= 256}):
             d.msplit = ms
             need = hip.lib().ym_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
             if need == 0 or need > big.numel():
