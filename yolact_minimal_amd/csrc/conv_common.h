@@ -39,6 +39,9 @@ struct ConvP {
     int M, HoWo, nkt, ksplit, kt_per_split, tiles_m, tiles_n;
     int main_blocks, main_tiles, tail_split, tail_ktps;
     FastDiv fd_ksplit, fd_tail, fd_tiles_n, fd_howo, fd_wo, fd_cin, fd_kw;
+    int m_fastest;     // tile order inside an XCD's chunk: 0 = n fastest (neighbours share the input panel), 1 = m fastest (neighbours
+                       // share the WEIGHT panel: chosen when the weights are the larger operand, so that the 8 XCD L2s partition them)
+    FastDiv fd_tiles_m;
     long long* trace;  // debug builds (-DYM_TRACE, tools/conv_trace.py): per-workgroup s_memtime stamps [grid][4]   // blocks >= main_blocks: tile main_tiles + t / tail_split, slice t % tail_split
     unsigned in_bytes, w_bytes, ws_bytes;   // sizes of `in` / `w` for the raw-buffer descriptors (out-of-range reads return 0)
     int nseg;
