@@ -7,6 +7,8 @@ import torch
 
 from oracle import yolact_ref as R
 from tests.test_oracle_golden import make_net
+from yolact_minimal_amd.config import build_cfg
+from yolact_minimal_amd.modules.yolact import Yolact
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -90,3 +92,51 @@ def test_weight_reload_invalidates_packed_weights():
         net.load_state_dict(sd)
         b = net(img)
     torch.testing.assert_close(b[1], a[1] + 1.0, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('name', ['res50_pascal', 'res101_custom'])
+def test_other_class_counts_forward_post_and_loss(name):
+    """Configs whose class count is not COCO's 81 (pascal: 21, custom: `CUSTOM_CLASSES`): forward, nms / after_nms and the
+    training loss against the oracle — head segment widths, softmax rows, the loss kernels' class dimension and the padded
+    semantic-segmentation channels all follow cfg.num_classes."""
+    from yolact_minimal_amd.utils.output_utils import nms, after_nms
+    size = 96
+    cfg = build_cfg(name, 'train', size, train_bs=2, bs_per_gpu=2)      # train mode also creates semantic_seg_conv
+    torch.manual_seed(11)
+    net = Yolact(cfg).eval()
+    with torch.no_grad():
+        sd0 = net.state_dict()
+        R.randomize_bn_(sd0, 1)
+        R.randomize_bias_(sd0, 2)
+        net.load_state_dict(sd0)
+    nc = cfg.num_classes
+    assert nc != 81
+    img = torch.randn(2, 3, size, size, generator=torch.Generator().manual_seed(5))
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        want = R.forward_eval(img, sd)
+    net = net.to(DEV)
+    with torch.no_grad():
+        got = net(img.to(DEV))
+    assert got[0].shape[-1] == nc
+    for a, b, key in zip(got, want, ('class_pred', 'box_pred', 'coef_pred', 'proto_out')):
+        _close(a, b.numpy(), key)
+    # post-processing on synthetic head outputs with this class count
+    cls, box, coef, proto = R.synth_head_outputs(len(net.anchors) // 4, num_classes=nc, proto_hw=size // 4, seed=2, bg_bias=3.0)
+    anchors = torch.tensor(net.anchors).reshape(-1, 4)
+    r = R.nms(cls, box, coef, proto, anchors, stable=True)
+    g = nms(cls.to(DEV), box.to(DEV), coef.to(DEV), proto.to(DEV), net.anchors, cfg)
+    assert torch.equal(g[0].cpu(), r[0]) and torch.equal(g[1].cpu(), r[1])
+    ra = R.after_nms(r[0], r[1], r[2], r[3], r[4], 70, 90)
+    ga = after_nms(g[0], g[1], g[2], g[3], g[4], 70, 90, cfg)
+    assert torch.equal(ga[2].cpu(), ra[2]) and float((ga[3].cpu() != ra[3]).float().mean()) < 1e-4
+    # training loss (train mode, batch statistics) vs the oracle's TrainNet + compute_loss
+    net.train()
+    boxes, masks = R.synth_targets(2, size, num_classes=nc - 1, seed=8)
+    params = {k: v.clone() for k, v in sd.items()}
+    out = R.TrainNet(params).forward(img)
+    ref_losses = R.compute_loss(*out, boxes, masks, anchors, stable=True)
+    losses = net(img.to(DEV), [b.to(DEV) for b in boxes], [m.to(DEV) for m in masks])
+    np.testing.assert_allclose(np.array([float(l.detach()) for l in losses]), np.array([float(l) for l in ref_losses]), rtol=5e-4)
+    sum(losses).backward()
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters())
