@@ -92,6 +92,12 @@ typedef struct {
                              /* to finish an output tile sums the slices (in slice order: deterministic) and runs the  */
                              /* epilogue in the same launch; NULL = separate reduce launch.  One buffer may be shared  */
                              /* by launches that are ordered on one stream, never by concurrent ones.                  */
+    int32_t nlevels;         /* 0 = one image size.  1..5 = "pyramid" input: `in` holds nlevels feature maps of DIFFERENT sizes back   */
+    int32_t level_h[5];      /* to back, level-major ([level][B][h][w][Cin]); the same filter runs over all of them in ONE launch   */
+    int32_t level_w[5];      /* (the shared PredictionModule of modules/yolact.py:149-157 is one conv per level in the reference). */
+                             /* Stride 1, pad = K/2 only; H/W/Ho/Wo of the descriptor are ignored, M = sum_l B*h_l*w_l.  A plain   */
+                             /* output (one segment, batch_stride 0) keeps the input's row order; a segmented output places level l's pixel p of image b at        */
+                             /* out[b*batch_stride + (sum_{j<l} h_j*w_j + p)*pitch] = the reference's cat over levels (:155-157).     */
     int32_t tail_tiles;      /* workgroup-quantisation fix (needs tile_counters, ksplit <= 1, plain NHWC output): the   */
     int32_t tail_ksplit;     /* LAST tail_tiles output tiles are each split into tail_ksplit K slices, so that e.g. 580  */
                              /* tiles on 256 CUs become 512 whole tiles + 68x4 quarter tiles instead of 2-or-3 per CU.   */
@@ -102,6 +108,7 @@ typedef struct {
  * (modules/resnet.py:88-90), conv+bias+ReLU of FPN / ProtoNet (modules/yolact.py:62-68,37-47) and,
  * with three segments, the bbox/conf/coef convs + tanh + permute/reshape/cat of
  * PredictionModule.forward + Yolact.forward (modules/yolact.py:27-30,155-157). */
+size_t ym_sizeof_conv_desc(void);                      /* for bindings: must equal their mirror of ym_conv_desc */
 size_t ym_conv2d_workspace_bytes(const ym_conv_desc* d);
 int ym_conv2d_tile_counters(const ym_conv_desc* d);   /* output tiles of the chosen plan (0 if K is not split) */
 int ym_conv2d_fuses_bn_stats(const ym_conv_desc* d);

@@ -35,7 +35,8 @@ def test_struct_layout_matches_c():
     """ctypes mirrors of ym_conv_desc / ym_conv_seg / ym_nms_cfg have the C sizes (x86-64 SysV)."""
     from yolact_minimal_amd import hip
     assert ctypes.sizeof(hip.ConvSeg) == 32
-    assert ctypes.sizeof(hip.ConvDesc) == 40 + 13 * 4 + 4 + 3 * 32 + 6 * 4 + 16 + 8 + 8
+    assert ctypes.sizeof(hip.ConvDesc) == 40 + 13 * 4 + 4 + 3 * 32 + 6 * 4 + 16 + 8 + 44 + 8 + 4   # (+4: tail padding to 8)
+    assert hip.lib().ym_sizeof_conv_desc() == ctypes.sizeof(hip.ConvDesc)
     assert ctypes.sizeof(hip.WgradDesc) == 24 + 14 * 4
     assert ctypes.sizeof(hip.NmsCfg) == 32
 

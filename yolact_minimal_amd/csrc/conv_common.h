@@ -11,6 +11,7 @@ constexpr int BK = 32;   // K step in floats (one 128-byte row of either operand
 struct FastDiv {
     unsigned mg, sh, d;
     __host__ static FastDiv make(unsigned d) {
+        if (d == 0) d = 1;
         unsigned s = 0;
         while ((1ull << s) < d) ++s;
         return FastDiv{(unsigned)(((1ull << 32) * ((1ull << s) - d)) / d + 1), s, d};
@@ -37,23 +38,42 @@ struct ConvP {
     int* counters;     // optional per-output-tile arrival counters: fused split-K finish (see ym_conv_desc.tile_counters)
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, Kpad;
     int M, HoWo, nkt, ksplit, kt_per_split, tiles_m, tiles_n;
-    int main_blocks, main_tiles, tail_split, tail_ktps;
+    int main_blocks, main_tiles, tail_split, tail_ktps;   // blocks >= main_blocks: tile main_tiles + t / tail_split, slice t % tail_split
     FastDiv fd_ksplit, fd_tail, fd_tiles_n, fd_howo, fd_wo, fd_cin, fd_kw;
+    int nlev;          // pyramid input (ym_conv_desc.nlevels): per level its size, first GEMM row, first output pixel of an image
+    int lev_h[5], lev_w[5], lev_m[6], lev_pix[6];
     int m_fastest;     // tile order inside an XCD's chunk: 0 = n fastest (neighbours share the input panel), 1 = m fastest (neighbours
                        // share the WEIGHT panel: chosen when the weights are the larger operand, so that the 8 XCD L2s partition them)
     FastDiv fd_tiles_m;
-    long long* trace;  // debug builds (-DYM_TRACE, tools/conv_trace.py): per-workgroup s_memtime stamps [grid][4]   // blocks >= main_blocks: tile main_tiles + t / tail_split, slice t % tail_split
+    long long* trace;  // debug builds (-DYM_TRACE, tools/conv_trace.py): per-workgroup s_memtime stamps [grid][4]
     unsigned in_bytes, w_bytes, ws_bytes;   // sizes of `in` / `w` for the raw-buffer descriptors (out-of-range reads return 0)
     int nseg;
     int vec;   // 1: single segment, plain NHWC [M][Cout], Cout % 4 == 0, 16-byte aligned -> vectorised epilogue
     SegDev seg[3];
 };
 
+// GEMM row m -> (image b, output pixel inside the image); pyramid inputs place level l's pixels after those of levels < l
+__device__ __forceinline__ void row_to_image_pixel(const ConvP& p, int m, int& b, int& pix) {
+    if (p.nlev > 0) {
+        int base = 0, hw = p.lev_h[0] * p.lev_w[0], pix0 = 0;
+#pragma unroll
+        for (int q = 1; q < 5; ++q)
+            if (q < p.nlev && m >= p.lev_m[q]) { base = p.lev_m[q]; hw = p.lev_h[q] * p.lev_w[q]; pix0 = p.lev_pix[q]; }
+        const int local = m - base;
+        b = local / hw;
+        pix = pix0 + (local - b * hw);
+    } else {
+        b = (int)p.fd_howo.div((unsigned)m);
+        pix = m - b * p.HoWo;
+    }
+}
+
 __device__ __forceinline__ void epilogue_store(const ConvP& p, int m, int n, float acc) {
     float v = acc;
     v = __builtin_fmaf(v, p.scale ? p.scale[n] : 1.f, p.shift ? p.shift[n] : 0.f);
     if (p.residual) v += p.residual[(size_t)m * p.Cout + n];
-    const int b = m / p.HoWo, pix = m - b * p.HoWo;
+    int b, pix;
+    row_to_image_pixel(p, m, b, pix);
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         if (s < p.nseg && n >= p.seg[s].n0 && n < p.seg[s].n1) {

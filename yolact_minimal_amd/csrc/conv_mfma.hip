@@ -66,7 +66,8 @@ __device__ __forceinline__ void buf_st16_sc1(__amdgpu_buffer_rsrc_t r, unsigned 
 // and the reads of the NEXT tile's first group before the end-of-tile barrier (tile t+1 is required to have landed one barrier
 // early: ring of NS >= 3 with NS-2 tiles still in flight), so the dependent MFMA chain of a wave never waits on LDS or on the
 // barrier round trip: measured 1500 -> ~1100 cycles per K tile for a workgroup that has its CU to itself (the bs=1 regime).
-template <int BM, int BN, int MODE, int NS, bool DL = false, bool PF = false>
+// RG: pyramid input (ym_conv_desc.nlevels): every staging row carries its own map size.
+template <int BM, int BN, int MODE, int NS, bool DL = false, bool PF = false, bool RG = false>
 __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
     constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave (wave tile = BM/2 x BN/2)
     constexpr int AR = BM / 32, BR = BN / 32;   // staging rows per thread
@@ -109,10 +110,25 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
     const int rbase = tid >> 3;  // 0..31
     int a_pix[AR];               // (b*H + ih0)*W + iw0   (may be negative; only used when in range); MODE 2: b*H
     int a_ih0[AR], a_iw0[AR];
+    int a_h[RG ? AR : 1], a_w[RG ? AR : 1];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
         const int m = m0 + rbase + 32 * i;
         if (m < p.M) {
+            if constexpr (RG) {                          // which level does this GEMM row belong to?
+                int base = 0, h = p.lev_h[0], w = p.lev_w[0];
+#pragma unroll
+                for (int q = 1; q < 5; ++q)
+                    if (q < p.nlev && m >= p.lev_m[q]) { base = p.lev_m[q]; h = p.lev_h[q]; w = p.lev_w[q]; }
+                const int local = m - base, hw = h * w;
+                const int b = local / hw, rem = local - b * hw;
+                const int oh = rem / w, ow = rem - oh * w;
+                a_ih0[i] = oh - p.pad;
+                a_iw0[i] = ow - p.pad;
+                a_pix[i] = base + (b * h + a_ih0[i]) * w + a_iw0[i];
+                a_h[i] = h; a_w[i] = w;
+                continue;
+            }
             unsigned ub, urem, uoh, uow;
             p.fd_howo.divmod((unsigned)m, ub, urem);
             p.fd_wo.divmod(urem, uoh, uow);
@@ -130,6 +146,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
             a_ih0[i] = -(1 << 20);
             a_iw0[i] = -(1 << 20);
             a_pix[i] = 0;
+            if constexpr (RG) { a_h[i] = 1; a_w[i] = 1; }
         }
     }
     unsigned wrow[BR];           // byte offset of this thread's float4 in weight row n
@@ -165,8 +182,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
                 for (int i = 0; i < AR; ++i) {
                     if (MODE == 0) {
                         const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
-                        const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-                        a_tapbase[i] = (unsigned)(((a_pix[i] + kh * p.W + kw) * p.Cin + c4 * 4) * 4);
+                        const int Hh = RG ? a_h[RG ? i : 0] : p.H, Ww = RG ? a_w[RG ? i : 0] : p.W;
+                        const bool ok = (unsigned)ih < (unsigned)Hh && (unsigned)iw < (unsigned)Ww;
+                        a_tapbase[i] = (unsigned)(((a_pix[i] + kh * Ww + kw) * p.Cin + c4 * 4) * 4);
                         a_mask[i] = ok ? 0u : OOB;
                     } else {
                         const int sh = p.stride >> 1, smask = p.stride - 1;     // stride is 1 or 2
@@ -545,6 +563,16 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
         YM_STAMP(3);
         return;
     }
+    // (image, pixel) of each of the tile's BM rows, once per row instead of once per element
+    int* rowinfo = reinterpret_cast<int*>(smem);
+    __syncthreads();
+    if (tid < BM) {
+        int b = 0, pix = 0;
+        if (m0 + tid < p.M) row_to_image_pixel(p, m0 + tid, b, pix);
+        rowinfo[2 * tid] = b;
+        rowinfo[2 * tid + 1] = pix;
+    }
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * (BN / 2) + j * 32 + frag_row;
@@ -581,8 +609,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
                     if (m < p.M) {
                         float v = __builtin_fmaf(acc[i][j][r], sc, sh);
                         if (p.residual) v += p.residual[(size_t)m * p.Cout + n];
-                        const int b = (int)p.fd_howo.div((unsigned)m), pix = m - b * p.HoWo;
-                        optr[(size_t)b * obs + (size_t)pix * opitch] = ym_apply_act(v, oact);
+                        const int row = m - m0;
+                        optr[(size_t)rowinfo[2 * row] * obs + (size_t)rowinfo[2 * row + 1] * opitch] = ym_apply_act(v, oact);
                     }
                 }
             }
@@ -625,8 +653,9 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce(const ConvP p) {
 bool vec_epilogue(const ym_conv_desc* d) {
     const ym_conv_seg& g = d->seg[0];
     const bool aligned = (((uintptr_t)g.out | (uintptr_t)d->residual | (uintptr_t)d->scale | (uintptr_t)d->shift) & 15) == 0;
-    return d->nseg == 1 && g.n_begin == 0 && g.n_end == d->Cout && g.pitch == d->Cout &&
-           g.batch_stride == (int64_t)d->Ho * d->Wo * d->Cout && d->Cout % 4 == 0 && aligned;
+    const bool rows_in_order = d->nlevels ? g.batch_stride == 0      // pyramid: the plain output keeps the input's row order
+                                          : g.batch_stride == (int64_t)d->Ho * d->Wo * d->Cout;
+    return d->nseg == 1 && g.n_begin == 0 && g.n_end == d->Cout && g.pitch == d->Cout && rows_in_order && d->Cout % 4 == 0 && aligned;
 }
 
 struct Plan {
@@ -651,16 +680,26 @@ int make_plan(const ym_conv_desc* d, Plan* pl) {
         YM_REQUIRE(d->Cin % 32 == 0 && d->kwaves == 0, "conv(dgrad): dy channels must be padded to a multiple of 32; workgroup kernel only");
         YM_REQUIRE(d->H == (d->Ho + 2 * d->pad - d->KH) / d->stride + 1 && d->W == (d->Wo + 2 * d->pad - d->KW) / d->stride + 1,
                    "conv(dgrad): H/W (dy) inconsistent with Ho/Wo (dx)");
-    } else {
+    } else if (d->nlevels == 0) {
         YM_REQUIRE(d->Ho == (d->H + 2 * d->pad - d->KH) / d->stride + 1 && d->Wo == (d->W + 2 * d->pad - d->KW) / d->stride + 1,
                    "conv: Ho/Wo inconsistent with H/W/K/stride/pad");
+    }
+    long long M_levels = 0;
+    if (d->nlevels != 0) {
+        YM_REQUIRE(d->nlevels >= 1 && d->nlevels <= 5, "conv: nlevels must be 0..5");
+        YM_REQUIRE(!d->transposed && d->kwaves == 0 && d->Cin % 32 == 0 && d->stride == 1 && d->KH == d->KW && (d->KH & 1) &&
+                   d->pad == d->KH / 2, "conv(pyramid): stride 1, odd square filter, pad = K/2, Cin %% 32 == 0, workgroup kernel");
+        for (int l = 0; l < d->nlevels; ++l) {
+            YM_REQUIRE(d->level_h[l] > 0 && d->level_w[l] > 0, "conv(pyramid): bad level %d", l);
+            M_levels += (long long)d->B * d->level_h[l] * d->level_w[l];
+        }
     }
     YM_REQUIRE(d->nseg >= 1 && d->nseg <= 3, "conv: nseg must be 1..3");
     for (int s = 0; s < d->nseg; ++s)
         YM_REQUIRE(d->seg[s].out && d->seg[s].n_end > d->seg[s].n_begin && d->seg[s].n_end <= d->Cout,
                    "conv: bad segment %d", s);
-    const long long M = (long long)d->B * d->Ho * d->Wo;
-    YM_REQUIRE(M * (long long)d->Cout < (1ll << 31) && (long long)d->B * d->H * d->W * d->Cin < (1ll << 31) * 1ll,
+    const long long M = d->nlevels ? M_levels : (long long)d->B * d->Ho * d->Wo;
+    YM_REQUIRE(M * (long long)d->Cout < (1ll << 31) && (d->nlevels ? M : (long long)d->B * d->H * d->W) * d->Cin < (1ll << 31) * 1ll,
                "conv: tensor too large for 32-bit indexing");
     pl->M = (int)M;
     pl->nkt = d->k_pad / BK;
@@ -714,21 +753,23 @@ int make_plan(const ym_conv_desc* d, Plan* pl) {
     return YM_OK;
 }
 
-template <int BM, int BN, int MODE, int NS = 2, bool DL = false, bool PF = false>
+template <int BM, int BN, int MODE, int NS = 2, bool DL = false, bool PF = false, bool RG = false>
 void launch(const ConvP& p, int grid, hipStream_t st) {
     size_t lds = (size_t)NS * (BM + BN) * (DL ? 32 : PITCH) * sizeof(float);
     const size_t epi = (size_t)BM * (BN + 4) * sizeof(float);          // accumulator staging of the vector epilogue
     if (lds < epi) lds = epi;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_f32<BM, BN, MODE, NS, DL, PF>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_f32<BM, BN, MODE, NS, DL, PF, RG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, MODE, NS, DL, PF>), dim3(grid), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, MODE, NS, DL, PF, RG>), dim3(grid), dim3(256), lds, st, p);
 }
 
 }  // namespace
+
+extern "C" size_t ym_sizeof_conv_desc(void) { return sizeof(ym_conv_desc); }
 
 extern "C" size_t ym_conv2d_workspace_bytes(const ym_conv_desc* d) {
     Plan pl;
@@ -763,9 +804,20 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
     p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW;
     p.stride = d->stride; p.pad = d->pad; p.Ho = d->Ho; p.Wo = d->Wo; p.Kpad = d->k_pad;
     {
-        const unsigned long long ib = (unsigned long long)d->B * d->H * d->W * d->Cin * 4ull, wb = (unsigned long long)d->Cout * d->k_pad * 4ull;
+        const unsigned long long ib = (d->nlevels ? (unsigned long long)pl.M : (unsigned long long)d->B * d->H * d->W) * d->Cin * 4ull, wb = (unsigned long long)d->Cout * d->k_pad * 4ull;
         YM_REQUIRE(ib < 0xFFFFFFF0ull && wb < 0x7FFFFFF0ull, "conv: input must be < 4 GiB and the packed weight < 2 GiB (32-bit buffer offsets)");
         p.in_bytes = (unsigned)ib; p.w_bytes = (unsigned)wb;
+    }
+    p.nlev = d->nlevels;
+    {
+        int m_acc = 0, pix_acc = 0;
+        for (int l = 0; l < 5; ++l) {
+            const bool on = l < d->nlevels;
+            p.lev_h[l] = on ? d->level_h[l] : 1; p.lev_w[l] = on ? d->level_w[l] : 1;
+            p.lev_m[l] = m_acc; p.lev_pix[l] = pix_acc;
+            if (on) { m_acc += d->B * d->level_h[l] * d->level_w[l]; pix_acc += d->level_h[l] * d->level_w[l]; }
+        }
+        p.lev_m[5] = m_acc; p.lev_pix[5] = pix_acc;
     }
     p.M = pl.M; p.HoWo = d->Ho * d->Wo; p.nkt = pl.nkt; p.ksplit = pl.ksplit; p.kt_per_split = pl.kt_per_split;
     p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.nseg = d->nseg;
@@ -816,7 +868,12 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
         else if (d->stages == 3 && HAS3_) launch<BM_, BN_, MODE_, HAS3_ ? 3 : 2>(p, grid, st);        \
         else launch<BM_, BN_, MODE_, 2>(p, grid, st);                                                 \
     } while (0)
-    if (d->transposed) {
+    if (d->nlevels > 0) {                               // pyramid input: register-staged double buffer
+        if (pl.bm == 128 && pl.bn == 128) launch<128, 128, 0, 2, false, false, true>(p, grid, st);
+        else if (pl.bm == 128 && pl.bn == 64) launch<128, 64, 0, 2, false, false, true>(p, grid, st);
+        else if (pl.bm == 64 && pl.bn == 128) launch<64, 128, 0, 2, false, false, true>(p, grid, st);
+        else launch<64, 64, 0, 2, false, false, true>(p, grid, st);
+    } else if (d->transposed) {
         if (pl.bm == 128 && pl.bn == 128) YM_TILE_CASE(128, 128, 2, false);
         else if (pl.bm == 128 && pl.bn == 64) YM_TILE_CASE(128, 64, 2, false);
         else if (pl.bm == 64 && pl.bn == 128) YM_TILE_CASE(64, 128, 2, false);

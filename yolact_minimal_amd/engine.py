@@ -148,6 +148,38 @@ class _Conv:
         return ho, wo
 
 
+def _bind_pyramid(layer, pyr, batch, shapes, segs):
+    """Bind a `_Conv` to a pyramid input (ym_conv_desc.nlevels): `pyr` [sum_l B*h_l*w_l, Cin] holds the levels back to back."""
+    rows, cin = pyr.shape
+    assert cin == layer.cin_pad and layer.stride == 1 and layer.pad == layer.kh // 2 and len(shapes) <= 5
+    assert rows == sum(batch * h * w for h, w in shapes)
+    d = ConvDesc()
+    d.inp = pyr.data_ptr()
+    d.B, d.H, d.W, d.Cin, d.Cout = batch, shapes[0][0], shapes[0][1], cin, layer.cout
+    d.KH, d.KW, d.stride, d.pad, d.Ho, d.Wo, d.k_pad = layer.kh, layer.kw, 1, layer.pad, shapes[0][0], shapes[0][1], layer.k_pad
+    d.nlevels = len(shapes)
+    for l, (h, w) in enumerate(shapes):
+        d.level_h[l], d.level_w[l] = h, w
+    d.nseg = len(segs)
+    for i, (n0, n1, base_ptr, bstride, pitch, act) in enumerate(segs):
+        d.seg[i].n_begin, d.seg[i].n_end = n0, n1
+        d.seg[i].out = base_ptr
+        d.seg[i].batch_stride, d.seg[i].pitch, d.seg[i].act = bstride, pitch, act
+    layer.desc = d
+    layer._bind_params()
+    layer.out_hw = shapes[0]
+    layer.flops = 2.0 * rows * layer.cout * layer.kh * layer.kw * layer.cin
+    layer.sig = f'M{rows}_N{layer.cout}_C{cin}_k{layer.kh}_s1_seg{len(segs)}_r0_L{len(shapes)}'
+    hit = tuned_table().get(layer.sig)
+    if hit:
+        layer.tile, layer.ksplit, layer.kwaves = (hit[0], hit[1]), hit[2], 0
+        layer.stages = 0
+        layer.tail = (hit[5], hit[6]) if len(hit) > 6 else (0, 0)
+    d.tile_m, d.tile_n = layer.tile
+    d.ksplit = layer.ksplit
+    d.tail_tiles, d.tail_ksplit = layer.tail
+
+
 class InferEngine:
     def __init__(self, net, batch, height, width, device, use_graph=None):
         self.net = net
@@ -303,15 +335,31 @@ class InferEngine:
         # Independent branches run on side streams (fork/join edges come from the data flow, see _add_op):
         #   stream 0: P3 + ProtoNet (the long chain)    stream 1: P5, P6, P7 + their heads
         #   stream 2: P4 + its head                       stream 3: the P3 head
+        # P3..P7 live back to back in ONE buffer (level-major), so that the shared prediction head can run over the whole
+        # pyramid in one launch per conv (ym_conv_desc.nlevels) instead of one launch per level
+        # (measured: -3 % forward time at bs=1, where every launch is latency bound; at bs=8 the per-level launches with their
+        #  individually tuned direct-to-LDS kernels are 1-2 % faster, so the pyramid launch is used for small batches only)
+        pyr_env = os.environ.get('YM_PYRAMID_HEAD', 'auto')
+        pyramid = pyr_env == '1' or (pyr_env == 'auto' and B <= 2)
+        h5, w5 = p5_1.shape[1:3]
+        shapes = [tuple(p3_1.shape[1:3]), tuple(p4_1.shape[1:3]), (h5, w5), ((h5 + 1) // 2, (w5 + 1) // 2),
+                  (((h5 + 1) // 2 + 1) // 2, ((w5 + 1) // 2 + 1) // 2)]
+        rows = [B * h * w for h, w in shapes]
+        pyr = self._buf(sum(rows), 256)
+        views, r0 = [], 0
+        for (h, w), n in zip(shapes, rows):
+            views.append(pyr[r0:r0 + n].view(B, h, w, 256))
+            r0 += n
         self._cur_stream = 1
-        p5 = self._conv(_Conv('fpn.pred_layers.2', fpn.pred_layers[2][0], act=ACT_RELU), p5_1)
-        p6 = self._conv(_Conv('fpn.downsample_layers.0', fpn.downsample_layers[0][0], act=ACT_RELU), p5)
-        p7 = self._conv(_Conv('fpn.downsample_layers.1', fpn.downsample_layers[1][0], act=ACT_RELU), p6)
+        p5 = self._conv(_Conv('fpn.pred_layers.2', fpn.pred_layers[2][0], act=ACT_RELU), p5_1, out=views[2])
+        p6 = self._conv(_Conv('fpn.downsample_layers.0', fpn.downsample_layers[0][0], act=ACT_RELU), p5, out=views[3])
+        p7 = self._conv(_Conv('fpn.downsample_layers.1', fpn.downsample_layers[1][0], act=ACT_RELU), p6, out=views[4])
         self._cur_stream = 2
-        p4 = self._conv(_Conv('fpn.pred_layers.1', fpn.pred_layers[1][0], act=ACT_RELU), p4_1)
+        p4 = self._conv(_Conv('fpn.pred_layers.1', fpn.pred_layers[1][0], act=ACT_RELU), p4_1, out=views[1])
         self._cur_stream = 0
-        p3 = self._conv(_Conv('fpn.pred_layers.0', fpn.pred_layers[0][0], act=ACT_RELU), p3_1)
+        p3 = self._conv(_Conv('fpn.pred_layers.0', fpn.pred_layers[0][0], act=ACT_RELU), p3_1, out=views[0])
         levels = [p3, p4, p5, p6, p7]
+        assert [tuple(lv.shape[1:3]) for lv in levels] == shapes
         level_stream = [3, 2, 1, 1, 1]
 
         # ProtoNet
@@ -334,12 +382,28 @@ class InferEngine:
         self.class_pred = self._buf(B, n_total, nc)
         self.box_pred = self._buf(B, n_total, 4)
         self.coef_pred = self._buf(B, n_total, cd)
+        c_conf, c_box, c_coef = na * nc, na * 4, na * cd
+        if pyramid:
+            self._cur_stream = 0
+            up = _Conv('prediction_layers.upfeature@P3-7', hd.upfeature[0], act=ACT_RELU)
+            xh = self._buf(sum(rows), 256)
+            up.refresh()
+            _bind_pyramid(up, pyr, B, shapes, [(0, 256, xh.data_ptr(), 0, 256, ACT_RELU)])
+            self.convs.append(up)
+            self._add_op('conv', up, levels, [xh])
+            fused = _Conv('prediction_layers.conf|bbox|coef@P3-7', [hd.conf_layer, hd.bbox_layer, hd.coef_layer[0]])
+            segs = [(0, c_conf, self.class_logits.data_ptr(), n_total * nc, c_conf, ACT_NONE),
+                    (c_conf, c_conf + c_box, self.box_pred.data_ptr(), n_total * 4, c_box, ACT_NONE),
+                    (c_conf + c_box, c_conf + c_box + c_coef, self.coef_pred.data_ptr(), n_total * cd, c_coef, ACT_TANH)]
+            fused.refresh()
+            _bind_pyramid(fused, xh, B, shapes, segs)
+            self.convs.append(fused)
+            self._add_op('conv', fused, [xh], [self.class_logits, self.box_pred, self.coef_pred])
         off = 0
-        for li, lv in enumerate(levels):
+        for li, lv in enumerate(levels if not pyramid else []):
             self._cur_stream = level_stream[li]
             xh = self._conv(_Conv(f'prediction_layers.upfeature@P{li + 3}', hd.upfeature[0], act=ACT_RELU), lv)
             fused = _Conv(f'prediction_layers.conf|bbox|coef@P{li + 3}', [hd.conf_layer, hd.bbox_layer, hd.coef_layer[0]])
-            c_conf, c_box, c_coef = na * nc, na * 4, na * cd
             es = 4  # bytes per float
             segs = [
                 (0, c_conf, self.class_logits.data_ptr() + off * nc * es, n_total * nc, c_conf, ACT_NONE),
@@ -433,6 +497,8 @@ class InferEngine:
                 continue
             d = c.desc
             M, nkt = d.B * d.Ho * d.Wo, d.k_pad // 32
+            if d.nlevels:
+                M = sum(d.B * d.level_h[l] * d.level_w[l] for l in range(d.nlevels))
             base = time_cfg(c, (0, 0), 0, 0)
             cands = []
             tiles = [(128, 64)] if c.stem else [(128, 128), (128, 64), (64, 128), (64, 64)]

@@ -18,7 +18,7 @@ ACT_NONE, ACT_RELU, ACT_TANH, ACT_GELU = 0, 1, 2, 3
 # every symbol include/yolact_hip.h declares (checked by tests/test_abi.py without a GPU)
 ABI_SYMBOLS = (
     'ym_abi_version', 'ym_last_error', 'ym_nchw_to_nhwc4', 'ym_pack_conv_weight', 'ym_fold_bn',
-    'ym_conv2d_workspace_bytes', 'ym_conv2d_tile_counters', 'ym_conv2d_fwd', 'ym_maxpool3x3s2_fwd', 'ym_bilinear2x_fwd',
+    'ym_sizeof_conv_desc', 'ym_conv2d_workspace_bytes', 'ym_conv2d_tile_counters', 'ym_conv2d_fwd', 'ym_maxpool3x3s2_fwd', 'ym_bilinear2x_fwd',
     'ym_softmax_rows', 'ym_nms_workspace_bytes', 'ym_detect_fast_nms', 'ym_detect_greedy_nms',
     'ym_greedy_nms_workspace_bytes', 'ym_greedy_nms', 'ym_mask_assemble', 'ym_mask_resize_binarize',
     'ym_boxes_to_pixels',
@@ -48,7 +48,8 @@ class ConvDesc(ctypes.Structure):
                 ('seg', ConvSeg * 3), ('tile_m', ctypes.c_int32), ('tile_n', ctypes.c_int32),
                 ('ksplit', ctypes.c_int32), ('kwaves', ctypes.c_int32), ('transposed', ctypes.c_int32),
                 ('stages', ctypes.c_int32), ('bn_sum', ctypes.c_void_p), ('bn_sumsq', ctypes.c_void_p),
-                ('tile_counters', ctypes.c_void_p), ('tail_tiles', ctypes.c_int32), ('tail_ksplit', ctypes.c_int32)]
+                ('tile_counters', ctypes.c_void_p), ('nlevels', ctypes.c_int32), ('level_h', ctypes.c_int32 * 5),
+                ('level_w', ctypes.c_int32 * 5), ('tail_tiles', ctypes.c_int32), ('tail_ksplit', ctypes.c_int32)]
 
 
 class WgradDesc(ctypes.Structure):
@@ -83,6 +84,10 @@ def lib():
         L.ym_nchw_to_nhwc4.argtypes = [vp, vp, i32, i32, i32, i32, vp]
         L.ym_pack_conv_weight.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp]
         L.ym_fold_bn.argtypes = [vp, vp, vp, vp, f32, vp, vp, i32, vp]
+        L.ym_sizeof_conv_desc.restype = sz
+        if L.ym_sizeof_conv_desc() != ctypes.sizeof(ConvDesc):
+            raise RuntimeError(f'libyolact_hip.so was built from a different ym_conv_desc ({L.ym_sizeof_conv_desc()} B) than '
+                               f'yolact_minimal_amd/hip.py mirrors ({ctypes.sizeof(ConvDesc)} B): rebuild the library')
         L.ym_conv2d_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
         L.ym_conv2d_workspace_bytes.restype = sz
         L.ym_conv2d_fwd.argtypes = [ctypes.POINTER(ConvDesc), vp, sz, vp]
@@ -143,7 +148,7 @@ def lib():
             fn = getattr(L, name)
             if name not in ('ym_last_error', 'ym_conv2d_workspace_bytes', 'ym_nms_workspace_bytes',
                             'ym_greedy_nms_workspace_bytes', 'ym_conv2d_wgrad_workspace_bytes',
-                            'ym_mask_loss_workspace_bytes', 'ym_loss_workspace_bytes', 'ym_mask_iou_workspace_bytes', 'ym_layernorm_bwd_workspace_bytes'):
+                            'ym_sizeof_conv_desc', 'ym_mask_loss_workspace_bytes', 'ym_loss_workspace_bytes', 'ym_mask_iou_workspace_bytes', 'ym_layernorm_bwd_workspace_bytes'):
                 fn.restype = ctypes.c_int
         _lib = L
     return _lib
