@@ -211,6 +211,41 @@ def eval_metrics_bench(device, n=100, g=15, h=480, w=640, iters=20, cpu=True):
     return out
 
 
+def train_aug_bench(device, iters=30, cpu=True):
+    """Next-row f4: `train_aug` of one COCO-like sample (480x640 uint8 image, 6 instance masks) to the 544 train size.
+    HBM view: the image + masks are read about once and [3 + k, 544, 544] floats are written."""
+    import random
+    from oracle.make_golden_augment import synth_sample        # synthetic-input generator
+    from yolact_minimal_amd.utils.augmentations import train_aug
+    img, masks, boxes, labels = synth_sample(12, 480, 640, 6)
+    g_img, g_masks = torch.from_numpy(img).to(device), torch.from_numpy(masks).to(device)
+    random.seed(3)
+    for _ in range(3):
+        train_aug(g_img, g_masks, boxes, labels, 544)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    done = 0
+    for _ in range(iters):
+        done += train_aug(g_img, g_masks, boxes, labels, 544)[0] is not None
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / iters
+    out = dict(workload='480x640 uint8 image + 6 masks -> 544x544 (photometric, mirror, crop, pad, resize, pad/crop, normalise)',
+               ms_per_sample=round(t * 1e3, 3), samples_per_s=round(1.0 / t, 1), accepted=done)
+    if cpu:
+        from oracle import augment_ref as A
+        from yolact_minimal_amd.utils.augmentations import sample_train_aug
+        random.seed(3)
+        t0 = time.perf_counter()
+        n = 0
+        for _ in range(5):
+            plan = sample_train_aug(480, 640, boxes, labels, 544)
+            if plan is not None:
+                A.apply_plan(img, masks, plan)
+                n += 1
+        out['cpu_oracle_ms_per_sample'] = round((time.perf_counter() - t0) / max(n, 1) * 1e3, 2)
+    return out
+
+
 def train_bench(cfg_name, img_size, batch, steps, warmup, world, local_rank, device, barrier):
     """DDP training: one step = forward + loss + backward (+ RCCL gradient all-reduce overlapped by DDP hooks) +
     SGD step on `batch` synthetic images per GPU (targets: 4 boxes + rectangular masks per image)."""
@@ -358,6 +393,7 @@ def main():
                                               frac_f32_mfma_peak=round(fl2 / tf2 / 1e12 / F32_MFMA_PEAK_TFLOPS, 4))
         if not args.no_extra and world == 1:
             extra['eval_metrics'] = eval_metrics_bench(device, cpu=not args.no_cpu_baseline)
+            extra['train_aug'] = train_aug_bench(device, cpu=not args.no_cpu_baseline)
             if not args.no_train and args.cfg != 'swin_tiny_coco':
                 net._engines.clear()
                 torch.cuda.empty_cache()

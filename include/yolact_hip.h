@@ -136,6 +136,22 @@ int ym_swin_window_attention_bwd(const float* qkv, const float* qkv_bias, const 
 int ym_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, ym_stream_t s);
 
+/* ---- train_aug pixel work (next row f4; reference utils/augmentations.py:60-77,138-216,230-252) ---------------------------
+ * The random decisions of one sample (drawn on the host in the reference's `random` call order):
+ *   source H x W -> mirror -> crop (cx, cy, cw, ch) -> pad to the q x q square at (px, py), border = norm_mean -> bilinear resize
+ *   to r x r -> final_mode 0: r == S | 1: paste at (fx, fy) into S x S (border = norm_mean) | 2: crop S x S at (fx, fy).
+ * photometric: optional brightness add / contrast scale (each clipped to 0..255), then BGR->HSV, S *= saturation, H += hue
+ * (wrapped to 0..360), HSV->BGR, clip.  mean / std in BGR order (config.py:66-67). */
+typedef struct {
+    int32_t H, W, mirror, cx, cy, cw, ch, q, px, py, r, S, final_mode, fx, fy, has_brightness, has_contrast;
+    float brightness, contrast, saturation, hue, mean[3], std[3];
+} ym_aug_plan;
+/* img HWC BGR (uint8 if is_u8 else float32) -> out [3][S][S] normalised RGB planes, one launch. */
+int ym_train_aug_image(const void* img_hwc_bgr, int is_u8, const ym_aug_plan* plan, float* out_chw, ym_stream_t s);
+/* masks [n][H][W] (uint8 / float32), keep [k] indices of the surviving instances -> out [k][S][S] (bilinear, border 0). */
+int ym_train_aug_masks(const void* masks, int is_u8, const int32_t* keep, int k, const ym_aug_plan* plan, float* out,
+                       ym_stream_t s);
+
 /* ---- evaluation inner products right after after_nms (next row f2) -----------------------------------------------
  * mask_iou (utils/box_utils.py:189-200): masks_a [n][P], masks_b [g][P] fp32 in {0,1} (P = img_h*img_w < 2^24) ->
  * iou [n][g] = inter / ((area_a + area_b) - inter), the reference's fp32 matmul evaluated as popcounts of bit rows

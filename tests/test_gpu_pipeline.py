@@ -124,3 +124,31 @@ def test_serving_pipeline_equals_sequential_calls():
                 assert torch.equal(x.cpu(), y.cpu())
                 n_det += x.shape[0]
     assert n_det > 0
+
+
+@pytest.mark.parametrize('seed,h,w,n,size', [(0, 96, 128, 2, 160), (3, 120, 110, 4, 160), (7, 128, 96, 3, 544), (12, 480, 640, 6, 544),
+                                               (21, 427, 640, 5, 544), (33, 100, 100, 1, 160)])
+def test_train_aug_matches_oracle_chain(seed, h, w, n, size):
+    """`train_aug` on the device (host-drawn plan + two HIP launches) vs the oracle's stage-by-stage restatement of the
+    reference chain, driven by the same `random` seed: identical boxes / labels / surviving instances, pixels within float
+    rounding, at toy sizes and at the COCO-like 480x640 -> 544 size."""
+    import random
+    from oracle import augment_ref as A
+    from oracle.make_golden_augment import synth_sample
+    from yolact_minimal_amd.utils.augmentations import sample_train_aug, train_aug
+    img, masks, boxes, labels = synth_sample(seed, h, w, n)
+    random.seed(500 + seed)
+    plan = sample_train_aug(h, w, boxes, labels, size)
+    random.seed(500 + seed)
+    for dt in (torch.uint8, torch.float32):
+        random.seed(500 + seed)
+        got = train_aug(torch.from_numpy(img).to(DEV).to(dt), torch.from_numpy(masks).to(DEV).to(dt), boxes, labels, size)
+        if plan is None:
+            assert got[0] is None
+            return
+        want_img, want_masks = A.apply_plan(img, masks, plan)
+        np.testing.assert_array_equal(got[2], plan.boxes)
+        np.testing.assert_array_equal(np.asarray(got[3]), np.asarray(plan.labels))
+        assert got[0].shape == (3, size, size) and got[1].shape == want_masks.shape
+        np.testing.assert_allclose(got[0].cpu().numpy(), want_img, rtol=0, atol=2e-3)     # (HSV round trip in float32)
+        np.testing.assert_allclose(got[1].cpu().numpy(), want_masks, rtol=0, atol=1e-5)

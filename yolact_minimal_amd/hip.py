@@ -25,7 +25,7 @@ ABI_SYMBOLS = (
     'ym_pack_conv_weight_dgrad', 'ym_conv2d_wgrad_workspace_bytes', 'ym_conv2d_wgrad', 'ym_bn_train_fwd',
     'ym_val_preprocess', 'ym_layernorm', 'ym_patch_merge_layernorm', 'ym_swin_window_attention',
     'ym_mask_loss_workspace_bytes', 'ym_mask_loss_fwd_bwd',
-    'ym_mask_iou_workspace_bytes', 'ym_mask_iou', 'ym_box_iou', 'ym_match_detections', 'ym_rle_encode',
+    'ym_mask_iou_workspace_bytes', 'ym_mask_iou', 'ym_box_iou', 'ym_match_detections', 'ym_rle_encode', 'ym_train_aug_image', 'ym_train_aug_masks',
     'ym_layernorm_bwd_workspace_bytes', 'ym_layernorm_bwd', 'ym_patch_merge_layernorm_bwd', 'ym_gelu_fwd', 'ym_gelu_bwd',
     'ym_swin_window_attention_bwd', 'ym_adamw_step',
     'ym_match_anchors', 'ym_loss_workspace_bytes', 'ym_class_box_loss', 'ym_semantic_loss',
@@ -58,6 +58,13 @@ class WgradDesc(ctypes.Structure):
                 ('Cin_real', ctypes.c_int32), ('Cout', ctypes.c_int32), ('Cout_real', ctypes.c_int32),
                 ('KH', ctypes.c_int32), ('KW', ctypes.c_int32), ('stride', ctypes.c_int32), ('pad', ctypes.c_int32),
                 ('Ho', ctypes.c_int32), ('Wo', ctypes.c_int32), ('msplit', ctypes.c_int32)]
+
+
+class AugPlanC(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ('H', 'W', 'mirror', 'cx', 'cy', 'cw', 'ch', 'q', 'px', 'py', 'r', 'S', 'final_mode',
+                                              'fx', 'fy', 'has_brightness', 'has_contrast')] + \
+               [(n, ctypes.c_float) for n in ('brightness', 'contrast', 'saturation', 'hue')] + \
+               [('mean', ctypes.c_float * 3), ('std', ctypes.c_float * 3)]
 
 
 class NmsCfg(ctypes.Structure):
@@ -132,6 +139,8 @@ def lib():
         L.ym_gelu_bwd.argtypes = [vp, vp, vp, i64, vp]
         L.ym_swin_window_attention_bwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]
         L.ym_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]
+        L.ym_train_aug_image.argtypes = [vp, i32, ctypes.POINTER(AugPlanC), vp, vp]
+        L.ym_train_aug_masks.argtypes = [vp, i32, vp, i32, ctypes.POINTER(AugPlanC), vp, vp]
         L.ym_match_anchors.argtypes = [vp, i32, vp, i32, f32, f32, vp, vp, vp, vp, vp, sz, vp]
         L.ym_loss_workspace_bytes.argtypes = [i32, i32]
         L.ym_loss_workspace_bytes.restype = sz
