@@ -295,7 +295,7 @@ def cpu_baseline(cfg_name, img_size):
     n_anchors = sum(((img_size + s - 1) // s) ** 2 * 3 for s in (8, 16, 32, 64, 128))
     cls, box, coef, proto = R.synth_head_outputs(n_anchors, proto_hw=img_size // 4, seed=1)
     anchors = R.anchors_for(img_size, cfg.scales)
-    n_img, t_fwd, t_nms, t_after = 0, 0.0, 0.0, 0.0
+    n_img, t_fwd, t_nms, t_after, best = 0, 0.0, 0.0, 0.0, 1e30
     t_start = time.perf_counter()
     with torch.no_grad():
         R.forward_eval(img, sd)                       # warm-up
@@ -304,10 +304,12 @@ def cpu_baseline(cfg_name, img_size):
             r = R.nms(cls, box, coef, proto, anchors); t2 = time.perf_counter()
             R.after_nms(r[0], r[1], r[2], r[3], r[4], 480, 640); t3 = time.perf_counter()
             t_fwd += t1 - t0; t_nms += t2 - t1; t_after += t3 - t2
+            best = min(best, t3 - t0)
             n_img += 1
-    per = (t_fwd + t_nms + t_after) / n_img
-    return dict(value=round(1.0 / per, 3), unit='img/s', cores=torch.get_num_threads(), kind='port',
-                sample=f'{n_img} images bs=1 {cfg_name}@{img_size}: oracle forward {t_fwd / n_img * 1e3:.0f} ms + nms '
+    # the host of a GPU box is shared and noisy (3x swings between runs were observed): the fastest image of the sample is the
+    # baseline, the means are kept in the sample text
+    return dict(value=round(1.0 / best, 3), unit='img/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'best of {n_img} images bs=1 {cfg_name}@{img_size} ({best * 1e3:.0f} ms); means: oracle forward {t_fwd / n_img * 1e3:.0f} ms + nms '
                        f'{t_nms / n_img * 1e3:.0f} ms + after_nms(480x640) {t_after / n_img * 1e3:.0f} ms on '
                        f'{os.cpu_count()} host cpus ({torch.get_num_threads()} torch threads)')
 
