@@ -28,7 +28,11 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ a, const float* __restrict__ b,
                                                      const float* __restrict__ c, const float* __restrict__ mean,
                                                      const float* __restrict__ invstd, long long M, int C, int relu, int act,
-                                                     double* __restrict__ out0, double* __restrict__ out1) {
+                                                     double* __restrict__ out0, double* __restrict__ out1,
+                                                     double* __restrict__ part = nullptr) {
+    // part != nullptr: every workgroup stores its column sums to part[block][2][C] (no atomics: with a large grid the 2*C
+    // contended fp64 atomics per workgroup were the bottleneck, which is why the atomic path caps the grid at 512) and
+    // k_col_finish adds the blocks in order.
     const int C4 = C >> 2;
     const int CQ = C4 < 256 ? C4 : 256;
     const int RL = 256 / CQ;
@@ -112,13 +116,54 @@ __global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ a,
             for (int r = 1; r < RL; ++r)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { s0[e] += red[0][r * CQ + cq_l][e]; s1[e] += red[1][r * CQ + cq_l][e]; }
+            if (part) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                atomicAdd(out0 + cq * 4 + e, s0[e]);
-                if (MODE != 2) atomicAdd(out1 + cq * 4 + e, s1[e]);
+                for (int e = 0; e < 4; ++e) {
+                    part[((size_t)blockIdx.x * 2 + 0) * C + cq * 4 + e] = s0[e];
+                    part[((size_t)blockIdx.x * 2 + 1) * C + cq * 4 + e] = s1[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    atomicAdd(out0 + cq * 4 + e, s0[e]);
+                    if (MODE != 2) atomicAdd(out1 + cq * 4 + e, s1[e]);
+                }
             }
         }
         __syncthreads();
+    }
+}
+
+// ordered sum of the per-workgroup partials: 16 channels x 16 block slices per workgroup, slices combined through LDS
+__global__ __launch_bounds__(256) void k_col_finish(const double* __restrict__ part, int blocks, int C, double* __restrict__ out0,
+                                                     double* __restrict__ out1) {
+    __shared__ double red[2][16][17];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        int k = sl;
+        for (; k + 48 < blocks; k += 64) {
+            double x[4], y[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                x[u] = part[((size_t)(k + 16 * u) * 2) * C + c];
+                y[u] = part[((size_t)(k + 16 * u) * 2 + 1) * C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a += x[u]; b += y[u]; }
+        }
+        for (; k < blocks; k += 16) { a += part[((size_t)k * 2) * C + c]; b += part[((size_t)k * 2 + 1) * C + c]; }
+    }
+    red[0][sl][cl] = a;
+    red[1][sl][cl] = b;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        double sa = 0.0, sb = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sa += red[0][r][cl]; sb += red[1][r][cl]; }
+        out0[c] = sa;
+        out1[c] = sb;
     }
 }
 
@@ -376,6 +421,14 @@ extern "C" int ym_bn_train_fwd_stats(const float* y, int64_t M, int C, const flo
     return ym_check_launch("bn_train_fwd_stats");
 }
 
+extern "C" size_t ym_bn_train_bwd_workspace_bytes(int64_t M, int C) {
+    const int CQ = (C / 4) < 256 ? (C / 4) : 256, RL = 256 / CQ;
+    long long grid = (M + (long long)RL * 16 - 1) / ((long long)RL * 16);
+    if (grid < 1) grid = 1;
+    if (grid > 1024) grid = 1024;
+    return (size_t)C * 16 + (size_t)grid * 2 * C * 8;
+}
+
 extern "C" int ym_bn_train_bwd(const float* dout, const float* out, const float* y, int64_t M, int C, const float* gamma,
                                const float* save_mean, const float* save_invstd, int relu, float* dy, float* dres,
                                float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, ym_stream_t s) {
@@ -386,13 +439,21 @@ extern "C" int ym_bn_train_bwd(const float* dout, const float* out, const float*
     hipStream_t st = (hipStream_t)s;
     double* db = (double*)workspace;
     double* dg = db + C;
-    (void)hipMemsetAsync(db, 0, (size_t)C * 16, st);
     const int CQ = (C / 4) < 256 ? (C / 4) : 256, RL = 256 / CQ;
     int grid = (int)((M + (long long)RL * 16 - 1) / ((long long)RL * 16));
-    if (grid > 512) grid = 512;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k_col_reduce<1>, dim3(grid), dim3(256), 0, st, dout, out, y, save_mean, save_invstd, (long long)M, C,
-                       relu, 0, db, dg);
+    const int big = grid > 1024 ? 1024 : grid;
+    if (workspace_bytes >= (size_t)C * 16 + (size_t)big * 2 * C * 8) {           // two-stage: partials, then an ordered sum
+        double* part = dg + C;
+        hipLaunchKernelGGL(k_col_reduce<1>, dim3(big), dim3(256), 0, st, dout, out, y, save_mean, save_invstd, (long long)M, C,
+                           relu, 0, db, dg, part);
+        hipLaunchKernelGGL(k_col_finish, dim3(ym_cdiv(C, 16)), dim3(256), 0, st, part, big, C, db, dg);
+    } else {
+        if (grid > 512) grid = 512;
+        (void)hipMemsetAsync(db, 0, (size_t)C * 16, st);
+        hipLaunchKernelGGL(k_col_reduce<1>, dim3(grid), dim3(256), 0, st, dout, out, y, save_mean, save_invstd, (long long)M, C,
+                           relu, 0, db, dg);
+    }
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid((size_t)M * (C / 4))), dim3(256), 0, st, dout, out, y, save_mean,
                        save_invstd, gamma, db, dg, relu, dy, dres, (long long)M, C, dgamma, dbeta);
     return ym_check_launch("bn_train_bwd");

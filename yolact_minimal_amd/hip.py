@@ -29,7 +29,7 @@ ABI_SYMBOLS = (
     'ym_layernorm_bwd_workspace_bytes', 'ym_layernorm_bwd', 'ym_patch_merge_layernorm_bwd', 'ym_gelu_fwd', 'ym_gelu_bwd',
     'ym_swin_window_attention_bwd', 'ym_adamw_step',
     'ym_match_anchors', 'ym_loss_workspace_bytes', 'ym_class_box_loss', 'ym_semantic_loss',
-    'ym_bn_train_bwd', 'ym_act_bias_bwd', 'ym_conv2d_fuses_bn_stats', 'ym_bn_train_fwd_stats', 'ym_maxpool3x3s2_bwd', 'ym_bilinear2x_bwd', 'ym_sgd_step',
+    'ym_bn_train_bwd_workspace_bytes', 'ym_bn_train_bwd', 'ym_act_bias_bwd', 'ym_conv2d_fuses_bn_stats', 'ym_bn_train_fwd_stats', 'ym_maxpool3x3s2_bwd', 'ym_bilinear2x_bwd', 'ym_sgd_step',
 )
 
 
@@ -148,6 +148,8 @@ def lib():
         L.ym_semantic_loss.argtypes = [vp, i32, i32, i32, vp, vp, i32, i32, f32, vp, vp, vp]
         L.ym_conv2d_fuses_bn_stats.argtypes = [ctypes.POINTER(ConvDesc)]
         L.ym_bn_train_fwd_stats.argtypes = [vp, i64, i32, vp, vp, f32, f32, vp, vp, vp, i32, vp, vp, vp, vp, vp]
+        L.ym_bn_train_bwd_workspace_bytes.argtypes = [i64, i32]
+        L.ym_bn_train_bwd_workspace_bytes.restype = sz
         L.ym_bn_train_bwd.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, sz, vp]
         L.ym_act_bias_bwd.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp, sz, vp]
         L.ym_maxpool3x3s2_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
@@ -157,7 +159,7 @@ def lib():
             fn = getattr(L, name)
             if name not in ('ym_last_error', 'ym_conv2d_workspace_bytes', 'ym_nms_workspace_bytes',
                             'ym_greedy_nms_workspace_bytes', 'ym_conv2d_wgrad_workspace_bytes',
-                            'ym_sizeof_conv_desc', 'ym_mask_loss_workspace_bytes', 'ym_loss_workspace_bytes', 'ym_mask_iou_workspace_bytes', 'ym_layernorm_bwd_workspace_bytes'):
+                            'ym_sizeof_conv_desc', 'ym_bn_train_bwd_workspace_bytes', 'ym_mask_loss_workspace_bytes', 'ym_loss_workspace_bytes', 'ym_mask_iou_workspace_bytes', 'ym_layernorm_bwd_workspace_bytes'):
                 fn.restype = ctypes.c_int
         _lib = L
     return _lib

@@ -345,7 +345,7 @@ class ConvBn(torch.autograd.Function):
         dres = torch.empty_like(y) if has_res else None
         dgamma = _grad_slot(gamma, (cout,))
         dbeta = _grad_slot(ctx.beta_param, (cout,)) if ctx.beta_param is not None else torch.empty(cout, device=y.device)
-        ws = scratch(y.device, cout * 16)
+        ws = scratch(y.device, hip.lib().ym_bn_train_bwd_workspace_bytes(m, cout))
         hip.check(hip.lib().ym_bn_train_bwd(hip.ptr(dout), hip.ptr(out) if relu else None, hip.ptr(y), m, cout,
                                             hip.ptr(gamma.detach()), hip.ptr(mean), hip.ptr(invstd), int(relu), hip.ptr(dy),
                                             hip.ptr(dres) if has_res else None, hip.ptr(dgamma), hip.ptr(dbeta),
