@@ -156,11 +156,15 @@ __global__ __launch_bounds__(256) void k_global_max(const float* __restrict__ x,
 // one wave per anchor row: mark = log(sum exp(x - gmax)) + gmax - x[0]; 0 for positives / neutrals
 __global__ __launch_bounds__(256) void k_ohem_mark(const float* __restrict__ cls, const int64_t* __restrict__ conf, long long rows,
                                                     int C, const float* __restrict__ gmax_part, int nparts, float* __restrict__ mark) {
-    __shared__ float s_gmax;
-    if (threadIdx.x == 0) {
+    __shared__ float s_gmax, s_w[4];
+    {                                                   // max of the partial maxima, by the whole workgroup
         float m = -INFINITY;
-        for (int i = 0; i < nparts; ++i) m = fmaxf(m, gmax_part[i]);
-        s_gmax = m;
+        for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, gmax_part[i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) s_gmax = fmaxf(fmaxf(s_w[0], s_w[1]), fmaxf(s_w[2], s_w[3]));
     }
     __syncthreads();
     const float gmax = s_gmax;
