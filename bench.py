@@ -246,6 +246,31 @@ def train_aug_bench(device, iters=30, cpu=True):
     return out
 
 
+def ann_to_mask_bench(device, iters=30, cpu=True):
+    """Next-row f4 (reader): the polygon annotations of one COCO-like image (480x640, 7 instances of 1-3 polygons) -> dense uint8
+    masks (`COCO.annToMask` per annotation in the reference).  HBM view: n*H*W bytes written once; the bitmaps live in LDS."""
+    from oracle.coco_ref import synth_polygons, segm_to_mask    # synthetic-input generator + cpu leg
+    from yolact_minimal_amd.utils.coco import anns_to_masks
+    h, w = 480, 640
+    segs = synth_polygons(21, h, w, n=7)
+    for _ in range(3):
+        anns_to_masks(segs, h, w, device)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        anns_to_masks(segs, h, w, device)
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / iters
+    out = dict(workload='7 annotations (1-3 polygons each, 3-40 vertices) -> [7, 480, 640] uint8 masks, incl. the H2D of the vertices',
+               ms_per_image=round(t * 1e3, 3), images_per_s=round(1.0 / t, 1))
+    if cpu:
+        t0 = time.perf_counter()
+        for s in segs:
+            segm_to_mask(s, h, w)
+        out['cpu_oracle_ms_per_image'] = round((time.perf_counter() - t0) * 1e3, 2)
+    return out
+
+
 def train_bench(cfg_name, img_size, batch, steps, warmup, world, local_rank, device, barrier):
     """DDP training: one step = forward + loss + backward (+ RCCL gradient all-reduce overlapped by DDP hooks) +
     SGD step on `batch` synthetic images per GPU (targets: 4 boxes + rectangular masks per image)."""
@@ -396,6 +421,7 @@ def main():
         if not args.no_extra and world == 1:
             extra['eval_metrics'] = eval_metrics_bench(device, cpu=not args.no_cpu_baseline)
             extra['train_aug'] = train_aug_bench(device, cpu=not args.no_cpu_baseline)
+            extra['ann_to_mask'] = ann_to_mask_bench(device, cpu=not args.no_cpu_baseline)
             if not args.no_train and args.cfg != 'swin_tiny_coco':
                 net._engines.clear()
                 torch.cuda.empty_cache()

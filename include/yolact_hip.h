@@ -175,6 +175,20 @@ int ym_match_detections(const float* iou_box, const float* iou_mask, const int32
 int ym_rle_encode(const float* masks, int n, int H, int W, uint32_t* counts, int cap_runs, int32_t* nruns, uint8_t* str,
                   int cap_str, int32_t* str_len, void* workspace, size_t workspace_bytes, ym_stream_t s);
 
+/* COCO annotation -> dense instance masks, next row f4 (the reader): what `self.coco.annToMask(aa)` yields per annotation in
+ * COCODetection.__getitem__ (utils/coco.py:96) = pycocotools annToRLE (frPyObjects over the polygon list, merge = union) +
+ * decode, i.e. cocoapi maskApi.c rleFrPoly / rleMerge / rleDecode.
+ * ym_poly_to_mask: xy = every polygon's vertices (x0, y0, x1, y1, ... as in the JSON, float64) back to back; polygon p owns the
+ *   vertices [poly_off[p], poly_off[p+1]) (counted in (x, y) pairs); annotation a owns the polygons [ann_off[a], ann_off[a+1]).
+ * ym_runs_to_mask: the uncompressed-RLE form ({'counts': [...]}): annotation a owns counts[run_off[a] .. run_off[a+1]).
+ * masks: [n][H][W] uint8 {0, 1}, 4-byte aligned.  W <= 4096.  Masks whose two bitmaps (see ym_ann_to_mask_workspace_bytes) do
+ * not fit the LDS need that much workspace; otherwise workspace may be NULL. */
+size_t ym_ann_to_mask_workspace_bytes(int n, int H, int W);
+int ym_poly_to_mask(const double* xy, const int32_t* poly_off, const int32_t* ann_off, int n, int H, int W, uint8_t* masks,
+                    void* workspace, size_t workspace_bytes, ym_stream_t s);
+int ym_runs_to_mask(const uint32_t* counts, const int32_t* run_off, int n, int H, int W, uint8_t* masks, void* workspace,
+                    size_t workspace_bytes, ym_stream_t s);
+
 /* ---- training: weight gradient, batch-norm with batch statistics, small backward ops, SGD -------------------
  * These replace what autograd + ATen/cuDNN execute for `loss_total.backward()` / `optimizer.step()`
  * (reference train.py:124-130) and nn.BatchNorm2d in train mode (modules/resnet.py:10-14,46). */
@@ -239,6 +253,12 @@ int ym_match_anchors(const float* gt_boxes_cls, int g, const float* anchors, int
                      float* offsets, int64_t* conf, float* anchor_box, int64_t* anchor_gt, void* workspace,
                      size_t workspace_bytes, ym_stream_t s);
 
+/* The same for a batch in one launch (workgroup = image): gt_boxes_cls / g are HOST arrays of B device pointers / gt counts;
+ * the outputs are the [B][N]... batch buffers; workspace >= 4*B*N bytes. */
+int ym_match_anchors_batch(const float* const* gt_boxes_cls, const int32_t* g, int B, const float* anchors, int N, float pos_thre,
+                           float neg_thre, float* offsets, int64_t* conf, float* anchor_box, int64_t* anchor_gt, void* workspace,
+                           size_t workspace_bytes, ym_stream_t s);
+
 /* category_loss (modules/yolact.py:205-232: OHEM hard negatives at neg_pos_ratio, softmax CE summed / total positives) and
  * box_loss (:234-239: smooth-L1 over positives / total positives) for a batch, with their gradients (d total / d input):
  * class_p [B][N][C], box_p/offsets [B][N][4], conf [B][N] -> dclass, dbox (fully overwritten), num_pos int32 [B+1]
@@ -255,6 +275,11 @@ int ym_class_box_loss(const float* class_p, const float* box_p, const float* off
  * coeff * (sigmoid - target), zero in the padding channels.  coeff = semantic_alpha / H / W / B. */
 int ym_semantic_loss(const float* seg_nhwc, int P, int pitch, int num_classes, const float* gt_masks_ds, const int64_t* gt_cls,
                      int gt_cls_stride, int g, float coeff, float* dseg, double* loss_accum, ym_stream_t s);
+/* The same for the batch in one launch: seg_nhwc / dseg [B][P][pitch]; gt_masks_ds / gt_cls / g are HOST arrays of B device
+ * pointers / gt counts (g[i] = 0: no gt, pointers ignored). */
+int ym_semantic_loss_batch(const float* seg_nhwc, int B, int P, int pitch, int num_classes, const float* const* gt_masks_ds,
+                           const int64_t* const* gt_cls, int gt_cls_stride, const int32_t* g, float coeff, float* dseg,
+                           double* loss_accum, ym_stream_t s);
 
 int ym_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, ym_stream_t s);
 int ym_bilinear2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, int align_corners, ym_stream_t s);

@@ -1,5 +1,6 @@
 """GPU parity of the training path (HIP conv fwd/dgrad/wgrad, train-mode BN, pool/upsample backward) against the
 CPU oracle's autograd and the reference's golden losses / gradient digests."""
+import ctypes
 import os
 
 import numpy as np
@@ -347,19 +348,29 @@ def test_match_anchors_kernel_bit_exact(size, n_gt, seed):
     boxes[1][1, :4] = boxes[1][0, :4]                        # duplicated gt box: both claim the same best anchor, the later wins
     n = anchors.shape[0]
     a_d = anchors.to(DEV)
-    ws = torch.empty(4 * n, dtype=torch.uint8, device=DEV)
-    for bc in boxes:
-        off = torch.empty(n, 4, device=DEV)
-        conf = torch.empty(n, dtype=torch.int64, device=DEV)
-        abox = torch.empty(n, 4, device=DEV)
-        agt = torch.empty(n, dtype=torch.int64, device=DEV)
-        L.match(cfg, bc.to(DEV), a_d, off, conf, abox, agt, ws)
+    b = len(boxes)
+    ws = torch.empty(4 * n * b, dtype=torch.uint8, device=DEV)
+    off = torch.empty(b, n, 4, device=DEV)
+    conf = torch.empty(b, n, dtype=torch.int64, device=DEV)
+    abox = torch.empty(b, n, 4, device=DEV)
+    agt = torch.empty(b, n, dtype=torch.int64, device=DEV)
+    L.match(cfg, [bc.to(DEV) for bc in boxes], a_d, off, conf, abox, agt, ws)          # one launch, workgroup = image
+    for i, bc in enumerate(boxes):
         r_off, r_conf, r_box, r_gt = R.match_anchors(bc[:, :4], anchors, bc[:, 4].long())
-        assert torch.equal(conf.cpu(), r_conf)
-        assert torch.equal(agt.cpu(), r_gt)
-        assert torch.equal(abox.cpu(), r_box)
+        assert torch.equal(conf[i].cpu(), r_conf)
+        assert torch.equal(agt[i].cpu(), r_gt)
+        assert torch.equal(abox[i].cpu(), r_box)
         assert int((r_conf > 0).sum()) >= n_gt - 1
-        torch.testing.assert_close(off.cpu(), r_off, rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(off[i].cpu(), r_off, rtol=1e-6, atol=1e-6)
+    # the single-image entry point is the B = 1 case of the same kernel
+    one = [torch.empty_like(t[0]) for t in (off, conf, abox, agt)]
+    from yolact_minimal_amd import hip
+    g0 = boxes[0].to(DEV)
+    hip.check(hip.lib().ym_match_anchors(hip.ptr(g0), g0.shape[0], hip.ptr(a_d), n, float(cfg.pos_iou_thre), float(cfg.neg_iou_thre),
+                                         hip.ptr(one[0]), hip.ptr(one[1], torch.int64), hip.ptr(one[2]), hip.ptr(one[3], torch.int64),
+                                         ctypes.c_void_p(ws.data_ptr()), ws.numel(), hip.stream_ptr()), 'ym_match_anchors')
+    for a, bfull in zip(one, (off, conf, abox, agt)):
+        assert torch.equal(a, bfull[0])
 
 
 @pytest.mark.parametrize('b,n,seed', [(2, 3000, 1), (3, 18525, 2)])

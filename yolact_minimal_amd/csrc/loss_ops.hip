@@ -25,11 +25,23 @@ __device__ __forceinline__ float iou_gt_prior(const float* g, float px1, float p
     return __fdiv_rn(inter, (area_a + area_b) - inter);
 }
 
-// ---- match() for one image (utils/box_utils.py:57-83) ------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_match(const float* __restrict__ gt, int g, const float* __restrict__ anchors, int N,
+// per-image arguments of the batched launches, passed by value (one workgroup row per image)
+constexpr int MAXB = 32;
+struct MatchBatch { const float* gt[MAXB]; int g[MAXB]; };
+struct SemanticBatch { const float* ds[MAXB]; const int64_t* cls[MAXB]; int g[MAXB]; };
+
+// ---- match() (utils/box_utils.py:57-83), workgroup = image ---------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_match(MatchBatch mb, const float* __restrict__ anchors, int N,
                                               float pos_thre, float neg_thre, float* __restrict__ offsets,
                                               int64_t* __restrict__ conf, float* __restrict__ anchor_box,
                                               int64_t* __restrict__ anchor_gt, float* __restrict__ best_v) {
+    const float* __restrict__ gt = mb.gt[blockIdx.x];
+    const int g = mb.g[blockIdx.x];
+    offsets += (size_t)blockIdx.x * N * 4;
+    conf += (size_t)blockIdx.x * N;
+    anchor_box += (size_t)blockIdx.x * N * 4;
+    anchor_gt += (size_t)blockIdx.x * N;
+    best_v += (size_t)blockIdx.x * N;
     __shared__ float s_gt[GMAX][5];
     __shared__ float s_rv[NT / 64];
     __shared__ int s_ri[NT / 64];
@@ -281,49 +293,68 @@ __global__ __launch_bounds__(256) void k_ce_loss(const float* __restrict__ cls, 
     if (lane == 0 && acc != 0.0) atomicAdd(loss, acc * (double)coeff);
 }
 
-// ---- semantic segmentation loss for one image (:293-313) -------------------------------------------------------------------
-// seg: NHWC [P][pitch] logits (first nc channels real), ds: [g][P] binarised down-sampled gt masks, cls: [g] class ids.
-__global__ __launch_bounds__(256) void k_semantic_loss(const float* __restrict__ seg, int P, int pitch, int nc,
-                                                        const float* __restrict__ ds, const int64_t* __restrict__ gt_cls_src,
-                                                        int gt_stride, int g, float coeff, float* __restrict__ dseg,
+// ---- semantic segmentation loss (:293-313), thread = (pixel, channel), blockIdx.y = image -----------------------------------
+// seg: NHWC [B][P][pitch] logits (first nc channels real), per image ds: [g][P] binarised down-sampled gt masks, cls: [g] class ids.
+__global__ __launch_bounds__(256) void k_semantic_loss(const float* __restrict__ seg, int P, int pitch, int nc, SemanticBatch sb,
+                                                        int gt_stride, float coeff, float* __restrict__ dseg,
                                                         double* __restrict__ loss) {
+    const int img = blockIdx.y, g = sb.g[img];
+    const float* __restrict__ ds = sb.ds[img];
+    const int64_t* __restrict__ cls = sb.cls[img];
+    const size_t total = (size_t)P * pitch;
+    const float* x = seg + (size_t)img * total;
+    float* dx = dseg + (size_t)img * total;
     double acc = 0.0;
-    for (int pix = blockIdx.x * 256 + threadIdx.x; pix < P; pix += gridDim.x * 256) {
-        uint32_t bits[8] = {0, 0, 0, 0, 0, 0, 0, 0};              // classes present at this pixel (nc <= 256)
-        for (int j = 0; j < g; ++j) {
-            if (ds[(size_t)j * P + pix] > 0.f) {
-                const int c = (int)gt_cls_src[(size_t)j * gt_stride];
-                bits[c >> 5] |= 1u << (c & 31);
-            }
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int pix = (int)(e / (unsigned)pitch), c = (int)(e - (size_t)pix * pitch);
+        float gval = 0.f;
+        if (c < nc) {
+            float t = 0.f;                                        // target = max over the gts of class c at this pixel
+            for (int j = 0; j < g; ++j)
+                if ((int)cls[(size_t)j * gt_stride] == c && ds[(size_t)j * P + pix] > 0.f) t = 1.f;
+            const float v = x[e];
+            acc += (double)(fmaxf(v, 0.f) - v * t + log1pf(expf(-fabsf(v))));
+            gval = (1.f / (1.f + expf(-v)) - t) * coeff;
         }
-        const float* x = seg + (size_t)pix * pitch;
-        float* dx = dseg + (size_t)pix * pitch;
-        for (int c = 0; c < pitch; ++c) {
-            float gval = 0.f;
-            if (c < nc) {
-                const float v = x[c], t = (bits[c >> 5] >> (c & 31)) & 1u ? 1.f : 0.f;
-                acc += (double)(fmaxf(v, 0.f) - v * t + log1pf(expf(-fabsf(v))));
-                gval = (1.f / (1.f + expf(-v)) - t) * coeff;
-            }
-            dx[c] = gval;
-        }
+        dx[e] = gval;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if ((threadIdx.x & 63) == 0 && acc != 0.0) atomicAdd(loss, acc * (double)coeff);
+    __shared__ double s_acc[4];
+    if ((threadIdx.x & 63) == 0) s_acc[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double t = (s_acc[0] + s_acc[1]) + (s_acc[2] + s_acc[3]);
+        if (t != 0.0) atomicAdd(loss, t * (double)coeff);
+    }
 }
 
 }  // namespace
 
+extern "C" int ym_match_anchors_batch(const float* const* gt_boxes_cls, const int32_t* g, int B, const float* anchors, int N,
+                                      float pos_thre, float neg_thre, float* offsets, int64_t* conf, float* anchor_box,
+                                      int64_t* anchor_gt, void* workspace, size_t workspace_bytes, ym_stream_t s) {
+    YM_REQUIRE(gt_boxes_cls && g && anchors && offsets && conf && anchor_box && anchor_gt && workspace, "match_anchors: null pointer");
+    YM_REQUIRE(B > 0 && N > 0, "match_anchors: need B > 0, N > 0");
+    for (int i = 0; i < B; ++i) YM_REQUIRE(gt_boxes_cls[i] && g[i] >= 1 && g[i] <= GMAX, "match_anchors: 1 <= g <= %d", GMAX);
+    if (workspace_bytes < (size_t)B * N * 4) { ym_set_error("match_anchors: workspace < 4*B*N bytes"); return YM_ENOSPC; }
+    for (int b0 = 0; b0 < B; b0 += MAXB) {
+        const int nb = B - b0 < MAXB ? B - b0 : MAXB;
+        MatchBatch mb;
+        for (int i = 0; i < nb; ++i) { mb.gt[i] = gt_boxes_cls[b0 + i]; mb.g[i] = g[b0 + i]; }
+        hipLaunchKernelGGL(k_match, dim3(nb), dim3(NT), 0, (hipStream_t)s, mb, anchors, N, pos_thre, neg_thre,
+                           offsets + (size_t)b0 * N * 4, conf + (size_t)b0 * N, anchor_box + (size_t)b0 * N * 4,
+                           anchor_gt + (size_t)b0 * N, (float*)workspace + (size_t)b0 * N);
+    }
+    return ym_check_launch("match_anchors");
+}
+
 extern "C" int ym_match_anchors(const float* gt_boxes_cls, int g, const float* anchors, int N, float pos_thre, float neg_thre,
                                 float* offsets, int64_t* conf, float* anchor_box, int64_t* anchor_gt, void* workspace,
                                 size_t workspace_bytes, ym_stream_t s) {
-    YM_REQUIRE(gt_boxes_cls && anchors && offsets && conf && anchor_box && anchor_gt && workspace, "match_anchors: null pointer");
-    YM_REQUIRE(g >= 1 && g <= GMAX && N > 0, "match_anchors: 1 <= g <= %d", GMAX);
-    if (workspace_bytes < (size_t)N * 4) { ym_set_error("match_anchors: workspace < 4*N bytes"); return YM_ENOSPC; }
-    hipLaunchKernelGGL(k_match, dim3(1), dim3(NT), 0, (hipStream_t)s, gt_boxes_cls, g, anchors, N, pos_thre, neg_thre, offsets, conf,
-                       anchor_box, anchor_gt, (float*)workspace);
-    return ym_check_launch("match_anchors");
+    const int32_t g1 = g;
+    return ym_match_anchors_batch(&gt_boxes_cls, &g1, 1, anchors, N, pos_thre, neg_thre, offsets, conf, anchor_box, anchor_gt,
+                                  workspace, workspace_bytes, s);
 }
 
 extern "C" size_t ym_loss_workspace_bytes(int B, int N) {
@@ -361,13 +392,33 @@ extern "C" int ym_class_box_loss(const float* class_p, const float* box_p, const
     return ym_check_launch("class_box_loss");
 }
 
+extern "C" int ym_semantic_loss_batch(const float* seg_nhwc, int B, int P, int pitch, int num_classes,
+                                      const float* const* gt_masks_ds, const int64_t* const* gt_cls, int gt_cls_stride,
+                                      const int32_t* g, float coeff, float* dseg, double* loss_accum, ym_stream_t s) {
+    YM_REQUIRE(seg_nhwc && dseg && loss_accum && g && B > 0 && P > 0 && pitch >= num_classes && num_classes <= 256,
+               "semantic_loss: bad args");
+    for (int i = 0; i < B; ++i) YM_REQUIRE(g[i] == 0 || (gt_masks_ds && gt_cls && gt_masks_ds[i] && gt_cls[i]), "semantic_loss: null gt");
+    const size_t total = (size_t)P * pitch;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    for (int b0 = 0; b0 < B; b0 += MAXB) {
+        const int nb = B - b0 < MAXB ? B - b0 : MAXB;
+        SemanticBatch sb;
+        for (int i = 0; i < nb; ++i) {
+            sb.g[i] = g[b0 + i];
+            sb.ds[i] = sb.g[i] ? gt_masks_ds[b0 + i] : nullptr;
+            sb.cls[i] = sb.g[i] ? gt_cls[b0 + i] : nullptr;
+        }
+        hipLaunchKernelGGL(k_semantic_loss, dim3(grid, nb), dim3(256), 0, (hipStream_t)s, seg_nhwc + (size_t)b0 * total, P, pitch,
+                           num_classes, sb, gt_cls_stride, coeff, dseg + (size_t)b0 * total, loss_accum);
+    }
+    return ym_check_launch("semantic_loss");
+}
+
 extern "C" int ym_semantic_loss(const float* seg_nhwc, int P, int pitch, int num_classes, const float* gt_masks_ds,
                                 const int64_t* gt_cls, int gt_cls_stride, int g, float coeff, float* dseg, double* loss_accum,
                                 ym_stream_t s) {
-    YM_REQUIRE(seg_nhwc && dseg && loss_accum && P > 0 && pitch >= num_classes && num_classes <= 256, "semantic_loss: bad args");
-    YM_REQUIRE(g == 0 || (gt_masks_ds && gt_cls), "semantic_loss: null gt");
-    int grid = (P + 255) / 256;
-    hipLaunchKernelGGL(k_semantic_loss, dim3(grid), dim3(256), 0, (hipStream_t)s, seg_nhwc, P, pitch, num_classes, gt_masks_ds, gt_cls,
-                       gt_cls_stride, g, coeff, dseg, loss_accum);
-    return ym_check_launch("semantic_loss");
+    const int32_t g1 = g;
+    return ym_semantic_loss_batch(seg_nhwc, 1, P, pitch, num_classes, &gt_masks_ds, &gt_cls, gt_cls_stride, &g1, coeff, dseg,
+                                  loss_accum, s);
 }

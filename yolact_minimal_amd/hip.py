@@ -25,10 +25,11 @@ ABI_SYMBOLS = (
     'ym_pack_conv_weight_dgrad', 'ym_conv2d_wgrad_workspace_bytes', 'ym_conv2d_wgrad', 'ym_bn_train_fwd',
     'ym_val_preprocess', 'ym_layernorm', 'ym_patch_merge_layernorm', 'ym_swin_window_attention',
     'ym_mask_loss_workspace_bytes', 'ym_mask_loss_fwd_bwd',
-    'ym_mask_iou_workspace_bytes', 'ym_mask_iou', 'ym_box_iou', 'ym_match_detections', 'ym_rle_encode', 'ym_train_aug_image', 'ym_train_aug_masks',
+    'ym_mask_iou_workspace_bytes', 'ym_mask_iou', 'ym_box_iou', 'ym_match_detections', 'ym_rle_encode', 'ym_ann_to_mask_workspace_bytes', 'ym_poly_to_mask', 'ym_runs_to_mask', 'ym_train_aug_image', 'ym_train_aug_masks',
     'ym_layernorm_bwd_workspace_bytes', 'ym_layernorm_bwd', 'ym_patch_merge_layernorm_bwd', 'ym_gelu_fwd', 'ym_gelu_bwd',
     'ym_swin_window_attention_bwd', 'ym_adamw_step',
-    'ym_match_anchors', 'ym_loss_workspace_bytes', 'ym_class_box_loss', 'ym_semantic_loss',
+    'ym_match_anchors', 'ym_match_anchors_batch', 'ym_loss_workspace_bytes', 'ym_class_box_loss', 'ym_semantic_loss',
+    'ym_semantic_loss_batch',
     'ym_bn_train_bwd_workspace_bytes', 'ym_bn_train_bwd', 'ym_act_bias_bwd', 'ym_conv2d_fuses_bn_stats', 'ym_bn_train_fwd_stats', 'ym_maxpool3x3s2_bwd', 'ym_bilinear2x_bwd', 'ym_sgd_step',
 )
 
@@ -131,6 +132,10 @@ def lib():
         L.ym_box_iou.argtypes = [vp, i32, vp, i32, vp, vp]
         L.ym_match_detections.argtypes = [vp, vp, vp, vp, i32, i32, vp, i32, i32, vp, vp]
         L.ym_rle_encode.argtypes = [vp, i32, i32, i32, vp, i32, vp, vp, i32, vp, vp, sz, vp]
+        L.ym_ann_to_mask_workspace_bytes.argtypes = [i32, i32, i32]
+        L.ym_ann_to_mask_workspace_bytes.restype = sz
+        L.ym_poly_to_mask.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]
+        L.ym_runs_to_mask.argtypes = [vp, vp, i32, i32, i32, vp, vp, sz, vp]
         L.ym_layernorm_bwd_workspace_bytes.argtypes = [i32]
         L.ym_layernorm_bwd_workspace_bytes.restype = sz
         L.ym_layernorm_bwd.argtypes = [vp, vp, vp, f32, i64, i32, vp, vp, vp, vp, sz, vp]
@@ -142,6 +147,8 @@ def lib():
         L.ym_train_aug_image.argtypes = [vp, i32, ctypes.POINTER(AugPlanC), vp, vp]
         L.ym_train_aug_masks.argtypes = [vp, i32, vp, i32, ctypes.POINTER(AugPlanC), vp, vp]
         L.ym_match_anchors.argtypes = [vp, i32, vp, i32, f32, f32, vp, vp, vp, vp, vp, sz, vp]
+        L.ym_match_anchors_batch.argtypes = [vp, vp, i32, vp, i32, f32, f32, vp, vp, vp, vp, vp, sz, vp]
+        L.ym_semantic_loss_batch.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, vp, f32, vp, vp, vp]
         L.ym_loss_workspace_bytes.argtypes = [i32, i32]
         L.ym_loss_workspace_bytes.restype = sz
         L.ym_class_box_loss.argtypes = [vp, vp, vp, vp, i32, i32, i32, f32, f32, i32, vp, vp, vp, vp, vp, vp, sz, vp]
@@ -159,7 +166,8 @@ def lib():
             fn = getattr(L, name)
             if name not in ('ym_last_error', 'ym_conv2d_workspace_bytes', 'ym_nms_workspace_bytes',
                             'ym_greedy_nms_workspace_bytes', 'ym_conv2d_wgrad_workspace_bytes',
-                            'ym_sizeof_conv_desc', 'ym_bn_train_bwd_workspace_bytes', 'ym_mask_loss_workspace_bytes', 'ym_loss_workspace_bytes', 'ym_mask_iou_workspace_bytes', 'ym_layernorm_bwd_workspace_bytes'):
+                            'ym_sizeof_conv_desc', 'ym_bn_train_bwd_workspace_bytes', 'ym_mask_loss_workspace_bytes', 'ym_loss_workspace_bytes', 'ym_mask_iou_workspace_bytes', 'ym_layernorm_bwd_workspace_bytes',
+                            'ym_ann_to_mask_workspace_bytes'):
                 fn.restype = ctypes.c_int
         _lib = L
     return _lib

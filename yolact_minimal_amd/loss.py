@@ -3,10 +3,10 @@
 Reference: `compute_loss` `/root/reference/modules/yolact.py:166-203`, `category_loss :205-232`, `box_loss :234-239`,
 `lincomb_mask_loss :241-291`, `semantic_seg_loss :293-313`, `match`/`encode` `utils/box_utils.py:57-114`.
 
-  match            -> `ym_match_anchors` (one launch per image, labels + encoded offsets + matched boxes)
+  match            -> `ym_match_anchors_batch` (one launch, workgroup = image: labels + encoded offsets + matched boxes)
   category + box   -> `ym_class_box_loss` (OHEM ranking by radix select, softmax CE, smooth-L1; gradients in the same pass)
   mask             -> `ym_mask_loss_fwd_bwd` (f32 MFMA: coefficient x prototype GEMM, sigmoid, crop, BCE, both gradient GEMMs)
-  semantic seg     -> `ym_semantic_loss` (target built on the fly from the down-sampled gt masks)
+  semantic seg     -> `ym_semantic_loss_batch` (one launch; target built on the fly from the down-sampled gt masks)
 
 The losses are terminal nodes of the graph, so each kernel also writes d(loss)/d(input); the autograd Functions below only
 scale those by the incoming gradient.  Same arithmetic and normalisations as the reference (each rank normalises by its LOCAL
@@ -24,13 +24,23 @@ def _vp(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def match(cfg, box_class_i, anchors, out_offsets, out_conf, out_anchor_box, out_anchor_gt, ws):
-    """`match()` for one image straight into row i of the batch buffers."""
-    g = box_class_i.shape[0]
-    hip.check(hip.lib().ym_match_anchors(
-        hip.ptr(box_class_i), g, hip.ptr(anchors), anchors.shape[0], float(cfg.pos_iou_thre), float(cfg.neg_iou_thre),
-        hip.ptr(out_offsets), hip.ptr(out_conf, torch.int64), hip.ptr(out_anchor_box), hip.ptr(out_anchor_gt, torch.int64),
-        _vp(ws), ws.numel(), hip.stream_ptr()), 'ym_match_anchors')
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def _int_array(values):
+    return (ctypes.c_int32 * len(values))(*[int(v) for v in values])
+
+
+def match(cfg, box_class, anchors, out_offsets, out_conf, out_anchor_box, out_anchor_gt, ws):
+    """`match()` for every image of the batch in one launch (workgroup = image), straight into the [B, N, ...] batch buffers."""
+    gts = list(box_class)
+    for bc in gts:
+        hip.ptr(bc)                                                     # contiguous fp32 CUDA tensors [g_i, 5], or raise
+    hip.check(hip.lib().ym_match_anchors_batch(
+        _ptr_array(gts), _int_array([bc.shape[0] for bc in gts]), len(gts), hip.ptr(anchors), anchors.shape[0],
+        float(cfg.pos_iou_thre), float(cfg.neg_iou_thre), hip.ptr(out_offsets), hip.ptr(out_conf, torch.int64),
+        hip.ptr(out_anchor_box), hip.ptr(out_anchor_gt, torch.int64), _vp(ws), ws.numel(), hip.stream_ptr()), 'ym_match_anchors_batch')
 
 
 class _ClassBoxLossFn(torch.autograd.Function):
@@ -128,15 +138,19 @@ class _SemanticLossFn(torch.autograd.Function):
             x, pitch = x.contiguous(), nc
         dseg = torch.empty(b, mh, mw, pitch, device=dev, dtype=torch.float32)
         acc = torch.zeros(1, dtype=torch.float64, device=dev)
+        gs = [int(m.shape[0]) for m in mask_gt]
+        ds = torch.empty(max(sum(gs), 1), mh, mw, device=dev, dtype=torch.float32)        # every image's down-sampled gt masks
+        cls = torch.cat([bc[:, -1] for bc in box_class]).long() if sum(gs) else torch.zeros(1, dtype=torch.int64, device=dev)
+        ds_i, cls_i, at = [], [], 0
         for i in range(b):
-            g = mask_gt[i].shape[0]
-            ds = torch.empty(g, mh, mw, device=dev, dtype=torch.float32)
-            if g:
-                hip.mask_resize_binarize(mask_gt[i].contiguous().float(), mh, mw, ds)
-            cls = box_class[i][:, -1].long()                                          # [g] int64 class ids
-            hip.check(hip.lib().ym_semantic_loss(
-                _vp(x[i]), mh * mw, pitch, nc, _vp(ds), _vp(cls), 1, g, float(coeff), _vp(dseg[i]), _vp(acc),
-                hip.stream_ptr()), 'ym_semantic_loss')
+            if gs[i]:
+                hip.mask_resize_binarize(mask_gt[i].contiguous().float(), mh, mw, ds[at:at + gs[i]])
+            ds_i.append(ds[at:at + gs[i]] if gs[i] else ds[:0])
+            cls_i.append(cls[at:at + gs[i]] if gs[i] else cls[:0])
+            at += gs[i]
+        hip.check(hip.lib().ym_semantic_loss_batch(
+            _vp(x), b, mh * mw, pitch, nc, _ptr_array(ds_i), _ptr_array(cls_i), 1, _int_array(gs), float(coeff), _vp(dseg), _vp(acc),
+            hip.stream_ptr()), 'ym_semantic_loss_batch')
         ctx.save_for_backward(dseg)
         ctx.nc = nc
         return acc.float().reshape(())
@@ -160,10 +174,9 @@ def compute_loss(cfg, anchors, class_p, box_p, coef_p, proto_p, seg_p, box_class
     anchor_box = torch.empty(b, n, 4, device=device)
     anchor_gt = torch.empty(b, n, dtype=torch.int64, device=device)
     num_pos = torch.empty(b + 1, dtype=torch.int32, device=device)
-    ws = torch.empty(n * 4, dtype=torch.uint8, device=device)
+    ws = torch.empty(b * n * 4, dtype=torch.uint8, device=device)
     anchors = anchors.contiguous().float()
-    for i in range(b):
-        match(cfg, box_class[i].contiguous().float(), anchors, offsets[i], conf_gt[i], anchor_box[i], anchor_gt[i], ws)
+    match(cfg, [bc.contiguous().float() for bc in box_class], anchors, offsets, conf_gt, anchor_box, anchor_gt, ws)
     loss_c, loss_b = _ClassBoxLossFn.apply(class_p, box_p, offsets, conf_gt, num_pos, cfg.conf_alpha, cfg.bbox_alpha, 3)
     counts = num_pos.tolist()                                                         # the one host read of the step
     loss_m = lincomb_mask_loss(cfg, conf_gt > 0, anchor_gt, coef_p, proto_p, mask_gt, anchor_box, counts)
