@@ -115,7 +115,7 @@ def synth_polygons(seed, h, w, n=6):
         for _ in range(int(rng.integers(1, 4))):
             k = int(rng.integers(3, 41))
             cx, cy = rng.uniform(0, w), rng.uniform(0, h)
-            rad = rng.uniform(2, 0.45 * min(h, w))
+            rad = rng.uniform(0.5, max(2.0, 0.45 * min(h, w)))
             ang = np.sort(rng.uniform(0, 2 * np.pi, k))
             r = rad * rng.uniform(0.4, 1.0, k)
             xs = np.round(cx + r * np.cos(ang), 2)

@@ -76,6 +76,7 @@ def test_dataset_modes_end_to_end(tmp_path):
     from yolact_minimal_amd.utils.augmentations import val_aug
     ann = C.write_synth_dataset(str(tmp_path), n_images=6, seed=4)
     cfg = _cfg(str(tmp_path), ann, 64)
+    tcfg = _cfg(str(tmp_path), ann, 256)        # multi_scale_resize draws 256..768: a 64 px train crop would reject most samples
 
     val = K.COCODetection(cfg, 'val', device=DEV)
     idx = K.COCO(ann, device=DEV)
@@ -90,20 +91,20 @@ def test_dataset_modes_end_to_end(tmp_path):
     imgs, boxes, masks, h, w = K.val_collate([val[0]])
     assert tuple(imgs.shape) == (1, 3, 64, 64) and masks.dtype == torch.float32 and boxes.dtype == torch.float32
 
-    train = K.COCODetection(cfg, 'train', device=DEV, rng=random.Random(11))
+    train = K.COCODetection(tcfg, 'train', device=DEV, rng=random.Random(11))
     loader = K.BatchLoader(train, 3, K.train_collate, shuffle=True, seed=1, threads=2)
     nb = 0
     for imgs, targets, masks in loader:
         nb += 1
-        assert tuple(imgs.shape) == (3, 3, 64, 64) and len(targets) == len(masks) == 3
+        assert tuple(imgs.shape) == (3, 3, 256, 256) and len(targets) == len(masks) == 3
         for t, m in zip(targets, masks):
-            assert t.shape[1] == 5 and m.shape[0] == t.shape[0] and tuple(m.shape[1:]) == (64, 64) and m.dtype == torch.float32
+            assert t.shape[1] == 5 and m.shape[0] == t.shape[0] and tuple(m.shape[1:]) == (256, 256) and m.dtype == torch.float32
             assert t.is_cuda and float(t[:, :4].min()) >= 0 and float(t[:, :4].max()) <= 1
     assert nb == len(loader) == 2
 
     # the same seed replays the same augmented batches (random draws happen in sample order on the consumer thread)
     def run():
-        ds = K.COCODetection(cfg, 'train', device=DEV, rng=random.Random(5))
+        ds = K.COCODetection(tcfg, 'train', device=DEV, rng=random.Random(5))
         return [b[0].clone() for b in K.BatchLoader(ds, 2, K.train_collate, shuffle=True, seed=2, threads=3)]
     for a, b in zip(run(), run()):
         assert torch.equal(a, b)
