@@ -244,6 +244,23 @@ int ym_mask_loss_fwd_bwd(const float* proto, const float* coef_pos, const float*
                          const float* gt_masks_ds, const int64_t* anchor_idx, int n, int Hp, int Wp, float wscale, float gscale,
                          double* loss_accum, float* dproto, float* dcoef_full, void* workspace, size_t workspace_bytes,
                          ym_stream_t s);
+/* The same for a batch in one launch pair (workgroup row = image), reading the positives' coefficients / matched boxes /
+ * matched gt index straight from the per-image full tensors through anchor_idx (no gathered copies): items is a HOST array. */
+typedef struct {
+    const float* proto;          /* [Hp*Wp][32] */
+    const float* coef_full;      /* [N][32] coefficient predictions of the image */
+    const float* anchor_box;     /* [N][4]  matched gt box per anchor (ym_match_anchors) */
+    const int64_t* anchor_gt;    /* [N]     matched gt index per anchor */
+    const float* gt_masks_ds;    /* [n_gt][Hp*Wp] in {0,1} */
+    const int64_t* anchor_idx;   /* [n]     anchors trained on (the positives, sub-sampled to masks_to_train) */
+    int32_t n;                   /* 0 <= n <= 128; 0: the item is skipped */
+    float wscale;                /* positives / n */
+    float* dproto;               /* [Hp*Wp][32] overwritten (untouched when n == 0) */
+    float* dcoef_full;           /* [N][32] rows anchor_idx overwritten */
+} ym_mask_loss_item;
+size_t ym_mask_loss_batch_workspace_bytes(int B);
+int ym_mask_loss_batch(const ym_mask_loss_item* items, int B, int Hp, int Wp, float gscale, double* loss_accum, void* workspace,
+                       size_t workspace_bytes, ym_stream_t s);
 
 /* match() for ONE image (utils/box_utils.py:57-83, encode :104-114): gt_boxes_cls [g][5] = (x1,y1,x2,y2,class) in [0,1]
  * coordinates, anchors [N][4] (cx,cy,w,h).  Writes offsets [N][4], conf [N] int64 (class+1 / 0 background / -1 neutral),

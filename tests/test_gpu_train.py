@@ -305,21 +305,24 @@ def test_bench_under_torchrun_with_rccl_single_rank(tmp_path):
 
 
 def test_mask_loss_kernel_matches_oracle_autograd():
-    """`ym_mask_loss_fwd_bwd` (GEMM + sigmoid + crop + BCE + both gradient GEMMs) vs fp64 autograd of the oracle's mask_loss."""
+    """`ym_mask_loss_batch` (GEMM + sigmoid + crop + BCE + both gradient GEMMs, one launch pair for the batch) vs fp64 autograd
+    of the oracle's mask_loss; the batch holds an image without positives; the single-image entry point agrees."""
+    from yolact_minimal_amd import hip
     from yolact_minimal_amd.loss import lincomb_mask_loss
     g = torch.Generator().manual_seed(11)
-    b, hp, n_anchor, size = 2, 34, 300, 136
+    b, hp, n_anchor, size = 3, 34, 300, 136
     proto = torch.relu(torch.randn(b, hp, hp, 32, generator=g))
     coef = torch.tanh(torch.randn(b, n_anchor, 32, generator=g))
     boxes, masks = R.synth_targets(b, size, n_gt=3, seed=4)
     pos = torch.zeros(b, n_anchor, dtype=torch.bool)
     anchor_gt = torch.zeros(b, n_anchor, dtype=torch.int64)
     anchor_box = torch.zeros(b, n_anchor, 4)
-    for i in range(b):
-        sel = torch.randperm(n_anchor, generator=g)[:37 + 20 * i]
+    for i in (0, 2):                                         # image 1 has no positives
+        sel = torch.randperm(n_anchor, generator=g)[:37 + 10 * i]
         pos[i, sel] = True
         anchor_gt[i, sel] = torch.randint(0, 3, (sel.numel(),), generator=g)
         anchor_box[i] = boxes[i][anchor_gt[i], :4]
+    anchor_box[1] = boxes[1][anchor_gt[1], :4]
     cfg = build_cfg('res50_coco', 'train', 128)
     pr, cf = proto.double().requires_grad_(), coef.double().requires_grad_()
     ref = R.mask_loss(pos, anchor_gt, cf, pr, [m.double() for m in masks], anchor_box.double())
@@ -330,6 +333,25 @@ def test_mask_loss_kernel_matches_oracle_autograd():
     np.testing.assert_allclose(float(got.detach()), float(ref.detach()), rtol=2e-5)
     torch.testing.assert_close(pg.grad.cpu().double() / 1.7, pr.grad, rtol=1e-4, atol=1e-7)
     torch.testing.assert_close(cg.grad.cpu().double() / 1.7, cf.grad, rtol=1e-4, atol=1e-7)
+    assert float(pg.grad[1].abs().max()) == 0.0 and float(cg.grad[1].abs().max()) == 0.0
+
+    # single-image entry point (gathered operands) = the same kernel with one item
+    i = 2
+    idx = torch.nonzero(pos[i]).flatten().to(DEV)
+    ds = torch.empty(3, hp, hp, device=DEV)
+    hip.mask_resize_binarize(masks[i].to(DEV), hp, hp, ds)
+    coeff = cfg.mask_alpha / hp / hp / int(pos.sum())
+    dproto, dcoef = torch.zeros(hp, hp, 32, device=DEV), torch.zeros(n_anchor, 32, device=DEV)
+    acc = torch.zeros(1, dtype=torch.float64, device=DEV)
+    ws = torch.empty(hip.lib().ym_mask_loss_workspace_bytes(), dtype=torch.uint8, device=DEV)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    hip.check(hip.lib().ym_mask_loss_fwd_bwd(
+        hip.ptr(proto[i].to(DEV)), hip.ptr(coef[i].to(DEV)[idx].contiguous()), hip.ptr(anchor_box[i].to(DEV)[idx].contiguous()),
+        hip.ptr(anchor_gt[i].to(DEV)[idx].to(torch.int32).contiguous(), torch.int32), hip.ptr(ds), hip.ptr(idx, torch.int64),
+        idx.shape[0], hp, hp, 1.0, float(coeff), vp(acc), hip.ptr(dproto), hip.ptr(dcoef), vp(ws), ws.numel(), hip.stream_ptr()),
+        'ym_mask_loss_fwd_bwd')
+    torch.testing.assert_close(dproto, pg.grad[i] / 1.7, rtol=1e-5, atol=1e-9)
+    torch.testing.assert_close(dcoef, cg.grad[i] / 1.7, rtol=1e-5, atol=1e-9)
 
 
 def _loss_inputs(b, size, n_gt, seed):

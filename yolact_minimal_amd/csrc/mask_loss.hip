@@ -1,4 +1,4 @@
-// lincomb_mask_loss (reference modules/yolact.py:241-291) forward AND backward for one image, on the f32 MFMA pipe.
+// lincomb_mask_loss (reference modules/yolact.py:241-291) forward AND backward on the f32 MFMA pipe, blockIdx.y = image.
 //
 //   loss_i = sum_p  w_p * sum_pix BCE( crop_p( sigmoid(proto[pix] . coef[p]) ), gt_p[pix] )      w_p = scale / area_p
 //   dproto[pix][k] = sum_p g[p][pix] * coef[p][k]        dcoef[p][k] = sum_pix g[p][pix] * proto[pix][k]
@@ -17,18 +17,27 @@ namespace {
 
 constexpr int MAXP = 128;
 
+constexpr int MLB = 16;                 // images per launch (per-image arguments travel by value)
+
+struct MLItem {
+    const float* proto;      // [P][32]
+    const float* coef;       // rows of 32 coefficients: row q of the positives, or row rows[q] of the full [N][32] tensor
+    const float* boxes;      // [.][4]  matched gt boxes (crop window + area), indexed like coef
+    const int* gt_idx32;     // [n] which downsampled gt mask each positive is trained against (gathered form), or null:
+    const int64_t* gt_idx64; //     [N] int64, indexed through rows
+    const int64_t* rows;     // [n] anchor index of each positive (null: coef / boxes are already gathered)
+    const float* dsmask;     // [n_gt][P]  {0,1}
+    float* dproto;           // [P][32]
+    float* part;             // [nwaves][MAXP][32] per-wave dcoef partials
+    int n;
+    float wscale;            // old_num_pos / num_pos (sub-sampling correction) — multiplies 1/area
+};
+
 struct MLP {
-    const float* proto;     // [P][32]
-    const float* coef;      // [n][32]
-    const float* boxes;     // [n][4]  gt boxes of the positives (crop window + area)
-    const int* gt_idx;      // [n]     which downsampled gt mask each positive is trained against
-    const float* dsmask;    // [n_gt][P]  {0,1}
-    float* dproto;          // [P][32]
-    float* part;            // [nwaves][MAXP][32] per-wave dcoef partials
-    double* loss;           // accumulated (atomicAdd)
-    int n, Hp, Wp, P, ntiles;
-    float wscale;           // old_num_pos / num_pos (sub-sampling correction) — multiplies 1/area
-    float gscale;           // d(total loss)/d(loss_i) = mask_alpha / Hp / Wp / total_pos
+    MLItem it[MLB];
+    double* loss;            // accumulated (atomicAdd)
+    int Hp, Wp, P, ntiles;
+    float gscale;            // d(total loss)/d(loss_i) = mask_alpha / Hp / Wp / total_pos
 };
 
 __device__ __forceinline__ void crop_span(float a, float b, float size, float& lo, float& hi) {
@@ -38,21 +47,31 @@ __device__ __forceinline__ void crop_span(float a, float b, float size, float& l
     hi = hi + 1.f; hi = hi > size ? size : hi;
 }
 
-__global__ __launch_bounds__(256) void k_mask_loss(const MLP p) {
+__global__ __launch_bounds__(256) void k_mask_loss(const MLP pb) {
     __shared__ float s_win[MAXP][4];     // x1, x2, y1, y2
     __shared__ float s_w[MAXP];          // wscale / area
     __shared__ int s_gt[MAXP];
+    __shared__ int s_row[MAXP];          // coefficient row of each positive
+    struct {                             // this image's view, same field names as before
+        const float *proto, *coef, *dsmask; float *dproto, *part; double* loss; int n, Hp, Wp, P, ntiles; float wscale, gscale;
+    } p;
+    const MLItem& it = pb.it[blockIdx.y];
+    p.proto = it.proto; p.coef = it.coef; p.dsmask = it.dsmask; p.dproto = it.dproto; p.part = it.part; p.loss = pb.loss;
+    p.n = it.n; p.Hp = pb.Hp; p.Wp = pb.Wp; p.P = pb.P; p.ntiles = pb.ntiles; p.wscale = it.wscale; p.gscale = pb.gscale;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int i = tid; i < MAXP; i += 256) {
         if (i < p.n) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(p.boxes + (size_t)i * 4);
+            const int src = it.rows ? (int)it.rows[i] : i;
+            s_row[i] = src;
+            const f32x4 b = *reinterpret_cast<const f32x4*>(it.boxes + (size_t)src * 4);
             float x1, x2, y1, y2;
             crop_span(b[0], b[2], (float)p.Wp, x1, x2);
             crop_span(b[1], b[3], (float)p.Hp, y1, y2);
             s_win[i][0] = x1; s_win[i][1] = x2; s_win[i][2] = y1; s_win[i][3] = y2;
             s_w[i] = p.wscale / ((b[2] - b[0]) * (b[3] - b[1]));
-            s_gt[i] = p.gt_idx[i];
+            s_gt[i] = it.gt_idx32 ? it.gt_idx32[i] : (int)it.gt_idx64[src];
         } else {
+            s_row[i] = 0;
             s_win[i][0] = 1.f; s_win[i][1] = 0.f; s_win[i][2] = 1.f; s_win[i][3] = 0.f;   // empty window
             s_w[i] = 0.f; s_gt[i] = 0;
         }
@@ -61,6 +80,7 @@ __global__ __launch_bounds__(256) void k_mask_loss(const MLP p) {
     const int row = lane & 31, h = lane >> 5;
     const int nptile = (p.n + 31) / 32;
     const int wave_id = blockIdx.x * 4 + wv, nwaves = gridDim.x * 4;
+    if (p.n == 0) return;                                             // image without positives (uniform)
 
     f32x16 dc[4];                       // dcoef partial [p tile][D layout: i = p, j = k]
 #pragma unroll
@@ -89,7 +109,7 @@ __global__ __launch_bounds__(256) void k_mask_loss(const MLP p) {
             f32x4 cf[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                cf[g] = pp < p.n ? *reinterpret_cast<const f32x4*>(p.coef + (size_t)pp * 32 + g * 8 + h * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                cf[g] = pp < p.n ? *reinterpret_cast<const f32x4*>(p.coef + (size_t)s_row[pp] * 32 + g * 8 + h * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 
             // ---- orientation 1: Z^T[i = positive][j = pixel]: loss + G (lane = pixel) -> dproto ------------------------
             f32x16 zt;
@@ -118,7 +138,7 @@ __global__ __launch_bounds__(256) void k_mask_loss(const MLP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int q = pt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float cq = q < p.n ? p.coef[(size_t)q * 32 + row] : 0.f;
+                const float cq = q < p.n ? p.coef[(size_t)s_row[q] * 32 + row] : 0.f;
                 dp = __builtin_amdgcn_mfma_f32_32x32x2f32(zt[r], cq, dp, 0, 0, 0);
             }
 
@@ -177,22 +197,76 @@ __global__ __launch_bounds__(256) void k_mask_loss(const MLP p) {
     if (lane == 0 && loss_acc != 0.0) atomicAdd(p.loss, loss_acc);
 }
 
-// dcoef_full[anchor_idx[q]][k] = sum over waves (fixed order) of the partials
-__global__ __launch_bounds__(256) void k_mask_loss_reduce(const float* __restrict__ part, int nwaves, int n,
-                                                           const int64_t* __restrict__ anchor_idx, float* __restrict__ dcoef_full) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= n * 32) return;
-    const int q = e >> 5, k = e & 31;
+// dcoef_full[anchor_idx[q]][k] = sum over the waves' partials in a fixed order: workgroup = (positive q, image), thread = (slice of
+// the waves, k); 8 slices are combined through LDS
+struct MLReduce { const float* part[MLB]; const int64_t* anchor_idx[MLB]; float* dcoef_full[MLB]; int n[MLB]; };
+
+__global__ __launch_bounds__(256) void k_mask_loss_reduce(const MLReduce rb, int nwaves) {
+    __shared__ float s[8][32];
+    const int img = blockIdx.y, q = blockIdx.x;
+    if (q >= rb.n[img]) return;
+    const int k = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const float* part = rb.part[img];
+    const int per = (nwaves + 7) / 8;
     float v = 0.f;
-    for (int w = 0; w < nwaves; ++w) v += part[((size_t)w * MAXP + q) * 32 + k];
-    dcoef_full[(size_t)anchor_idx[q] * 32 + k] = v;
+    for (int w = sl * per; w < min(nwaves, (sl + 1) * per); ++w) v += part[((size_t)w * MAXP + q) * 32 + k];
+    s[sl][k] = v;
+    __syncthreads();
+    if (sl == 0) {
+        float t = s[0][k];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) t += s[i][k];
+        rb.dcoef_full[img][(size_t)rb.anchor_idx[img][q] * 32 + k] = t;
+    }
 }
 
-constexpr int ML_BLOCKS = 64;    // 256 waves, each walking ~P/32/256 pixel tiles
+constexpr int ML_BLOCKS = 64;    // 256 waves per image, each walking ~P/32/256 pixel tiles
+constexpr size_t ML_PART_BYTES = (size_t)ML_BLOCKS * 4 * MAXP * 32 * sizeof(float);
+
+int launch_chunk(const ym_mask_loss_item* items, int nb, const float* const* coef, const float* const* boxes, const int* const* gt32,
+                 int Hp, int Wp, float gscale, double* loss_accum, char* workspace, hipStream_t st) {
+    MLP p;
+    MLReduce r;
+    int nmax = 0;
+    for (int i = 0; i < nb; ++i) {
+        const ym_mask_loss_item& a = items[i];
+        MLItem& it = p.it[i];
+        it.proto = a.proto; it.dsmask = a.gt_masks_ds; it.dproto = a.dproto; it.n = a.n; it.wscale = a.wscale;
+        it.part = (float*)(workspace + (size_t)i * ML_PART_BYTES);
+        if (coef) { it.coef = coef[i]; it.boxes = boxes[i]; it.gt_idx32 = gt32[i]; it.gt_idx64 = nullptr; it.rows = nullptr; }
+        else { it.coef = a.coef_full; it.boxes = a.anchor_box; it.gt_idx32 = nullptr; it.gt_idx64 = a.anchor_gt; it.rows = a.anchor_idx; }
+        r.part[i] = it.part; r.anchor_idx[i] = a.anchor_idx; r.dcoef_full[i] = a.dcoef_full; r.n[i] = a.n;
+        if (a.n > nmax) nmax = a.n;
+    }
+    if (nmax == 0) return YM_OK;
+    p.loss = loss_accum; p.Hp = Hp; p.Wp = Wp; p.P = Hp * Wp; p.ntiles = (p.P + 31) / 32; p.gscale = gscale;
+    hipLaunchKernelGGL(k_mask_loss, dim3(ML_BLOCKS, nb), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(k_mask_loss_reduce, dim3(nmax, nb), dim3(256), 0, st, r, ML_BLOCKS * 4);
+    return ym_check_launch("mask_loss");
+}
 
 }  // namespace
 
-extern "C" size_t ym_mask_loss_workspace_bytes(void) { return (size_t)ML_BLOCKS * 4 * MAXP * 32 * sizeof(float) + 256; }
+extern "C" size_t ym_mask_loss_workspace_bytes(void) { return ML_PART_BYTES + 256; }
+extern "C" size_t ym_mask_loss_batch_workspace_bytes(int B) { return (size_t)(B < MLB ? (B > 0 ? B : 1) : MLB) * ML_PART_BYTES + 256; }
+
+extern "C" int ym_mask_loss_batch(const ym_mask_loss_item* items, int B, int Hp, int Wp, float gscale, double* loss_accum,
+                                  void* workspace, size_t workspace_bytes, ym_stream_t s) {
+    YM_REQUIRE(items && B > 0 && Hp > 0 && Wp > 0 && loss_accum && workspace, "mask_loss_batch: bad args");
+    for (int i = 0; i < B; ++i) {
+        const ym_mask_loss_item& a = items[i];
+        YM_REQUIRE(a.n >= 0 && a.n <= MAXP, "mask_loss: at most %d positives per image (cfg.masks_to_train), got %d", MAXP, a.n);
+        YM_REQUIRE(a.n == 0 || (a.proto && a.coef_full && a.anchor_box && a.anchor_gt && a.gt_masks_ds && a.anchor_idx && a.dproto && a.dcoef_full),
+                   "mask_loss_batch: null pointer in item %d", i);
+    }
+    if (workspace_bytes < ym_mask_loss_batch_workspace_bytes(B)) { ym_set_error("mask_loss_batch: workspace too small"); return YM_ENOSPC; }
+    for (int b0 = 0; b0 < B; b0 += MLB) {
+        const int nb = B - b0 < MLB ? B - b0 : MLB;
+        const int rc = launch_chunk(items + b0, nb, nullptr, nullptr, nullptr, Hp, Wp, gscale, loss_accum, (char*)workspace, (hipStream_t)s);
+        if (rc != YM_OK) return rc;
+    }
+    return YM_OK;
+}
 
 extern "C" int ym_mask_loss_fwd_bwd(const float* proto, const float* coef_pos, const float* box_pos, const int32_t* gt_idx,
                                     const float* gt_masks_ds, const int64_t* anchor_idx, int n, int Hp, int Wp, float wscale,
@@ -203,14 +277,9 @@ extern "C" int ym_mask_loss_fwd_bwd(const float* proto, const float* coef_pos, c
     YM_REQUIRE(proto && coef_pos && box_pos && gt_idx && gt_masks_ds && anchor_idx && loss_accum && dproto && dcoef_full && workspace,
                "mask_loss: null pointer");
     if (workspace_bytes < ym_mask_loss_workspace_bytes()) { ym_set_error("mask_loss: workspace too small"); return YM_ENOSPC; }
-    MLP p;
-    p.proto = proto; p.coef = coef_pos; p.boxes = box_pos; p.gt_idx = gt_idx; p.dsmask = gt_masks_ds; p.dproto = dproto;
-    p.part = (float*)workspace; p.loss = loss_accum;
-    p.n = n; p.Hp = Hp; p.Wp = Wp; p.P = Hp * Wp; p.ntiles = (p.P + 31) / 32;
-    p.wscale = wscale; p.gscale = gscale;
-    hipStream_t st = (hipStream_t)s;
-    hipLaunchKernelGGL(k_mask_loss, dim3(ML_BLOCKS), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(k_mask_loss_reduce, dim3((n * 32 + 255) / 256), dim3(256), 0, st, (const float*)workspace, ML_BLOCKS * 4, n,
-                       anchor_idx, dcoef_full);
-    return ym_check_launch("mask_loss_fwd_bwd");
+    ym_mask_loss_item a{};
+    a.proto = proto; a.gt_masks_ds = gt_masks_ds; a.anchor_idx = anchor_idx; a.n = n; a.wscale = wscale; a.dproto = dproto;
+    a.dcoef_full = dcoef_full;
+    const int* g32 = gt_idx;
+    return launch_chunk(&a, 1, &coef_pos, &box_pos, &g32, Hp, Wp, gscale, loss_accum, (char*)workspace, (hipStream_t)s);
 }

@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     'ym_boxes_to_pixels',
     'ym_pack_conv_weight_dgrad', 'ym_conv2d_wgrad_workspace_bytes', 'ym_conv2d_wgrad', 'ym_bn_train_fwd',
     'ym_val_preprocess', 'ym_layernorm', 'ym_patch_merge_layernorm', 'ym_swin_window_attention',
-    'ym_mask_loss_workspace_bytes', 'ym_mask_loss_fwd_bwd',
+    'ym_mask_loss_workspace_bytes', 'ym_mask_loss_fwd_bwd', 'ym_mask_loss_batch_workspace_bytes', 'ym_mask_loss_batch',
     'ym_mask_iou_workspace_bytes', 'ym_mask_iou', 'ym_box_iou', 'ym_match_detections', 'ym_rle_encode', 'ym_ann_to_mask_workspace_bytes', 'ym_poly_to_mask', 'ym_runs_to_mask', 'ym_train_aug_image', 'ym_train_aug_masks',
     'ym_layernorm_bwd_workspace_bytes', 'ym_layernorm_bwd', 'ym_patch_merge_layernorm_bwd', 'ym_gelu_fwd', 'ym_gelu_bwd',
     'ym_swin_window_attention_bwd', 'ym_adamw_step',
@@ -66,6 +66,12 @@ class AugPlanC(ctypes.Structure):
                                               'fx', 'fy', 'has_brightness', 'has_contrast')] + \
                [(n, ctypes.c_float) for n in ('brightness', 'contrast', 'saturation', 'hue')] + \
                [('mean', ctypes.c_float * 3), ('std', ctypes.c_float * 3)]
+
+
+class MaskLossItem(ctypes.Structure):
+    _fields_ = [('proto', ctypes.c_void_p), ('coef_full', ctypes.c_void_p), ('anchor_box', ctypes.c_void_p),
+                ('anchor_gt', ctypes.c_void_p), ('gt_masks_ds', ctypes.c_void_p), ('anchor_idx', ctypes.c_void_p),
+                ('n', ctypes.c_int32), ('wscale', ctypes.c_float), ('dproto', ctypes.c_void_p), ('dcoef_full', ctypes.c_void_p)]
 
 
 class NmsCfg(ctypes.Structure):
@@ -126,6 +132,9 @@ def lib():
         L.ym_mask_loss_workspace_bytes.argtypes = []
         L.ym_mask_loss_workspace_bytes.restype = sz
         L.ym_mask_loss_fwd_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp, vp, vp, sz, vp]
+        L.ym_mask_loss_batch_workspace_bytes.argtypes = [i32]
+        L.ym_mask_loss_batch_workspace_bytes.restype = sz
+        L.ym_mask_loss_batch.argtypes = [ctypes.POINTER(MaskLossItem), i32, i32, i32, f32, vp, vp, sz, vp]
         L.ym_mask_iou_workspace_bytes.argtypes = [i32, i32, i64]
         L.ym_mask_iou_workspace_bytes.restype = sz
         L.ym_mask_iou.argtypes = [vp, i32, vp, i32, i64, vp, vp, sz, vp]
@@ -166,7 +175,7 @@ def lib():
             fn = getattr(L, name)
             if name not in ('ym_last_error', 'ym_conv2d_workspace_bytes', 'ym_nms_workspace_bytes',
                             'ym_greedy_nms_workspace_bytes', 'ym_conv2d_wgrad_workspace_bytes',
-                            'ym_sizeof_conv_desc', 'ym_bn_train_bwd_workspace_bytes', 'ym_mask_loss_workspace_bytes', 'ym_loss_workspace_bytes', 'ym_mask_iou_workspace_bytes', 'ym_layernorm_bwd_workspace_bytes',
+                            'ym_sizeof_conv_desc', 'ym_bn_train_bwd_workspace_bytes', 'ym_mask_loss_workspace_bytes', 'ym_mask_loss_batch_workspace_bytes', 'ym_loss_workspace_bytes', 'ym_mask_iou_workspace_bytes', 'ym_layernorm_bwd_workspace_bytes',
                             'ym_ann_to_mask_workspace_bytes'):
                 fn.restype = ctypes.c_int
         _lib = L

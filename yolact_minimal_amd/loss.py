@@ -5,7 +5,8 @@ Reference: `compute_loss` `/root/reference/modules/yolact.py:166-203`, `category
 
   match            -> `ym_match_anchors_batch` (one launch, workgroup = image: labels + encoded offsets + matched boxes)
   category + box   -> `ym_class_box_loss` (OHEM ranking by radix select, softmax CE, smooth-L1; gradients in the same pass)
-  mask             -> `ym_mask_loss_fwd_bwd` (f32 MFMA: coefficient x prototype GEMM, sigmoid, crop, BCE, both gradient GEMMs)
+  mask             -> `ym_mask_loss_batch` (f32 MFMA: coefficient x prototype GEMM, sigmoid, crop, BCE, both gradient GEMMs;
+                      one launch pair for the batch)
   semantic seg     -> `ym_semantic_loss_batch` (one launch; target built on the fly from the down-sampled gt masks)
 
 The losses are terminal nodes of the graph, so each kernel also writes d(loss)/d(input); the autograd Functions below only
@@ -67,36 +68,41 @@ class _ClassBoxLossFn(torch.autograd.Function):
 
 
 class _MaskLossFn(torch.autograd.Function):
-    """Forward + backward of the mask term in one HIP pass per image (`ym_mask_loss_fwd_bwd`): the coefficient x prototype
-    GEMM, sigmoid, crop, BCE and both gradient GEMMs run on the f32 MFMA; autograd only scales the stored gradients."""
+    """Forward + backward of the mask term for the whole batch in one HIP launch pair (`ym_mask_loss_batch`, workgroup row =
+    image): the coefficient x prototype GEMM, sigmoid, crop, BCE and both gradient GEMMs run on the f32 MFMA; the positives'
+    coefficients / matched boxes / gt indices are read in place through the anchor indices.  Autograd only scales the stored
+    gradients."""
 
     @staticmethod
-    def forward(ctx, proto_p, coef_p, per_image, coeff):
+    def forward(ctx, proto_p, coef_p, anchor_box, anchor_gt, per_image, coeff):
         b, hp, wp, _ = proto_p.shape
         dev = proto_p.device
         proto_c, coef_c = proto_p.detach().contiguous(), coef_p.detach().contiguous()
         dproto = torch.zeros_like(proto_c)
         dcoef = torch.zeros_like(coef_c)
         acc = torch.zeros(1, dtype=torch.float64, device=dev)
-        ws_bytes = hip.lib().ym_mask_loss_workspace_bytes()
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        ws = torch.empty(hip.lib().ym_mask_loss_batch_workspace_bytes(b), dtype=torch.uint8, device=dev)
+        items = (hip.MaskLossItem * b)()
         for i, item in enumerate(per_image):
+            it = items[i]
             if item is None:
+                it.n = 0
                 continue
-            idx, gt_idx, boxes, dsmask, wscale = item
-            cpos = coef_c[i][idx].contiguous()
-            hip.check(hip.lib().ym_mask_loss_fwd_bwd(
-                hip.ptr(proto_c[i]), hip.ptr(cpos), hip.ptr(boxes), hip.ptr(gt_idx, torch.int32), hip.ptr(dsmask),
-                hip.ptr(idx, torch.int64), idx.shape[0], hp, wp, float(wscale), float(coeff), ctypes.c_void_p(acc.data_ptr()),
-                hip.ptr(dproto[i]), hip.ptr(dcoef[i]), ctypes.c_void_p(ws.data_ptr()), ws.numel(), hip.stream_ptr()),
-                'ym_mask_loss_fwd_bwd')
+            idx, dsmask, wscale = item
+            it.proto, it.coef_full = proto_c[i].data_ptr(), coef_c[i].data_ptr()
+            it.anchor_box, it.anchor_gt = hip.ptr(anchor_box[i]).value, hip.ptr(anchor_gt[i], torch.int64).value
+            it.gt_masks_ds, it.anchor_idx = hip.ptr(dsmask).value, hip.ptr(idx, torch.int64).value
+            it.n, it.wscale = idx.shape[0], float(wscale)
+            it.dproto, it.dcoef_full = dproto[i].data_ptr(), dcoef[i].data_ptr()
+        hip.check(hip.lib().ym_mask_loss_batch(items, b, hp, wp, float(coeff), _vp(acc), _vp(ws), ws.numel(), hip.stream_ptr()),
+                  'ym_mask_loss_batch')
         ctx.save_for_backward(dproto, dcoef)
         return (acc * coeff).float().reshape(())
 
     @staticmethod
     def backward(ctx, grad_out):
         dproto, dcoef = ctx.saved_tensors
-        return dproto * grad_out, dcoef * grad_out, None, None
+        return dproto * grad_out, dcoef * grad_out, None, None, None, None
 
 
 def lincomb_mask_loss(cfg, pos, anchor_gt, coef_p, proto_p, mask_gt, anchor_box, num_pos=None):
@@ -116,15 +122,13 @@ def lincomb_mask_loss(cfg, pos, anchor_gt, coef_p, proto_p, mask_gt, anchor_box,
         g = mask_gt[i].shape[0]
         ds = torch.empty(g, ph, pw, device=proto_p.device, dtype=torch.float32)     # bilinear(align_corners=False) then > 0.5
         hip.mask_resize_binarize(mask_gt[i].contiguous().float(), ph, pw, ds)
-        gt_i, bx = anchor_gt[i][idx], anchor_box[i][idx]
         old = n_i
         if old > cfg.masks_to_train:
             sel = torch.randperm(old)[:cfg.masks_to_train].to(idx.device)            # CPU generator, like the reference (:263)
-            idx, gt_i, bx = idx[sel], gt_i[sel], bx[sel]
-        per_image.append((idx.contiguous(), gt_i.to(torch.int32).contiguous(), bx.contiguous(), ds.reshape(g, ph * pw),
-                          old / idx.shape[0]))
+            idx = idx[sel]
+        per_image.append((idx.contiguous(), ds.reshape(g, ph * pw), old / idx.shape[0]))
     coeff = cfg.mask_alpha / ph / pw / total_pos
-    return _MaskLossFn.apply(proto_p, coef_p, per_image, coeff)
+    return _MaskLossFn.apply(proto_p, coef_p, anchor_box.contiguous().float(), anchor_gt.contiguous(), per_image, coeff)
 
 
 class _SemanticLossFn(torch.autograd.Function):
