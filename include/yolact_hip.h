@@ -255,12 +255,15 @@ typedef struct {
     const int64_t* anchor_idx;   /* [n]     anchors trained on (the positives, sub-sampled to masks_to_train) */
     int32_t n;                   /* 0 <= n <= 128; 0: the item is skipped */
     float wscale;                /* positives / n */
+    const int32_t* n_dev;        /* NULL, or a device int32 holding the image's positive count: the kernel trains on the first
+                                    min(*n_dev, n) entries of anchor_idx and uses wscale = *n_dev / that (the host never reads it) */
     float* dproto;               /* [Hp*Wp][32] overwritten (untouched when n == 0) */
     float* dcoef_full;           /* [N][32] rows anchor_idx overwritten */
 } ym_mask_loss_item;
 size_t ym_mask_loss_batch_workspace_bytes(int B);
-int ym_mask_loss_batch(const ym_mask_loss_item* items, int B, int Hp, int Wp, float gscale, double* loss_accum, void* workspace,
-                       size_t workspace_bytes, ym_stream_t s);
+/* total_pos_dev: NULL, or a device int32 by which gscale is divided (gscale = mask_alpha / Hp / Wp then). */
+int ym_mask_loss_batch(const ym_mask_loss_item* items, int B, int Hp, int Wp, float gscale, const int32_t* total_pos_dev,
+                       double* loss_accum, void* workspace, size_t workspace_bytes, ym_stream_t s);
 
 /* match() for ONE image (utils/box_utils.py:57-83, encode :104-114): gt_boxes_cls [g][5] = (x1,y1,x2,y2,class) in [0,1]
  * coordinates, anchors [N][4] (cx,cy,w,h).  Writes offsets [N][4], conf [N] int64 (class+1 / 0 background / -1 neutral),

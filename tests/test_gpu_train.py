@@ -350,8 +350,43 @@ def test_mask_loss_kernel_matches_oracle_autograd():
         hip.ptr(anchor_gt[i].to(DEV)[idx].to(torch.int32).contiguous(), torch.int32), hip.ptr(ds), hip.ptr(idx, torch.int64),
         idx.shape[0], hp, hp, 1.0, float(coeff), vp(acc), hip.ptr(dproto), hip.ptr(dcoef), vp(ws), ws.numel(), hip.stream_ptr()),
         'ym_mask_loss_fwd_bwd')
-    torch.testing.assert_close(dproto, pg.grad[i] / 1.7, rtol=1e-5, atol=1e-9)
-    torch.testing.assert_close(dcoef, cg.grad[i] / 1.7, rtol=1e-5, atol=1e-9)
+    torch.testing.assert_close(dproto, pg.grad[i] / 1.7, rtol=1e-4, atol=1e-7)      # the batch form visits the positives in a
+    torch.testing.assert_close(dcoef, cg.grad[i] / 1.7, rtol=1e-4, atol=1e-7)        # random order: summation order differs
+
+
+def test_mask_loss_subsamples_on_the_device_without_host_sync():
+    """More positives than cfg.masks_to_train: a uniformly random subset of exactly masks_to_train anchors is trained, weighted by
+    positives / masks_to_train (modules/yolact.py:261-267,287-288) — chosen on the device, the counts never visit the host."""
+    from yolact_minimal_amd.loss import lincomb_mask_loss
+    g = torch.Generator().manual_seed(3)
+    b, hp, n_anchor, size = 2, 34, 900, 136
+    proto = torch.relu(torch.randn(b, hp, hp, 32, generator=g))
+    coef = torch.tanh(torch.randn(b, n_anchor, 32, generator=g))
+    boxes, masks = R.synth_targets(b, size, n_gt=3, seed=4)
+    pos = torch.zeros(b, n_anchor, dtype=torch.bool)
+    anchor_gt = torch.randint(0, 3, (b, n_anchor), generator=g)
+    anchor_box = torch.stack([boxes[i][anchor_gt[i], :4] for i in range(b)])
+    pos[0, torch.randperm(n_anchor, generator=g)[:340]] = True          # > 100: sub-sampled
+    pos[1, torch.randperm(n_anchor, generator=g)[:60]] = True           # <= 100: all of them
+    cfg = build_cfg('res50_coco', 'train', 128)
+    full = R.mask_loss(pos, anchor_gt, coef.double(), proto.double(), [m.double() for m in masks], anchor_box.double(),
+                       masks_to_train=10 ** 6)
+    losses, chosen = [], []
+    for seed in (0, 1, 2, 3):
+        torch.manual_seed(seed)
+        pg, cg = proto.to(DEV).requires_grad_(), coef.to(DEV).requires_grad_()
+        with torch.profiler.profile() as prof:                           # no device -> host copy inside
+            got = lincomb_mask_loss(cfg, pos.to(DEV), anchor_gt.to(DEV), cg, pg, [m.to(DEV) for m in masks], anchor_box.to(DEV))
+        assert not any('Memcpy DtoH' in e.name or e.name == 'aten::item' or e.name == 'aten::_local_scalar_dense'
+                       for e in prof.events())
+        got.backward()
+        rows = (cg.grad.abs().sum(-1) > 0).cpu()
+        assert int(rows[0].sum()) == 100 and bool((rows[0] <= pos[0]).all())
+        assert torch.equal(rows[1], pos[1])
+        losses.append(float(got))
+        chosen.append(rows[0])
+    assert not torch.equal(chosen[0], chosen[1])                         # a different draw per call
+    assert abs(np.mean(losses) / float(full) - 1) < 0.15                 # the re-weighted subset estimates the full sum
 
 
 def _loss_inputs(b, size, n_gt, seed):

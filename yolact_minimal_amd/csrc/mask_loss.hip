@@ -29,6 +29,7 @@ struct MLItem {
     const float* dsmask;     // [n_gt][P]  {0,1}
     float* dproto;           // [P][32]
     float* part;             // [nwaves][MAXP][32] per-wave dcoef partials
+    const int* n_dev;        // null, or the device-side count of positives: n_eff = min(*n_dev, n), wscale = *n_dev / n_eff
     int n;
     float wscale;            // old_num_pos / num_pos (sub-sampling correction) — multiplies 1/area
 };
@@ -36,6 +37,7 @@ struct MLItem {
 struct MLP {
     MLItem it[MLB];
     double* loss;            // accumulated (atomicAdd)
+    const int* total_dev;    // null, or the device-side total positive count: gscale /= *total_dev
     int Hp, Wp, P, ntiles;
     float gscale;            // d(total loss)/d(loss_i) = mask_alpha / Hp / Wp / total_pos
 };
@@ -58,6 +60,12 @@ __global__ __launch_bounds__(256) void k_mask_loss(const MLP pb) {
     const MLItem& it = pb.it[blockIdx.y];
     p.proto = it.proto; p.coef = it.coef; p.dsmask = it.dsmask; p.dproto = it.dproto; p.part = it.part; p.loss = pb.loss;
     p.n = it.n; p.Hp = pb.Hp; p.Wp = pb.Wp; p.P = pb.P; p.ntiles = pb.ntiles; p.wscale = it.wscale; p.gscale = pb.gscale;
+    if (it.n_dev) {                      // counts that never left the device (no host synchronisation in the step)
+        const int real = *it.n_dev;
+        p.n = real < it.n ? real : it.n;
+        p.wscale = p.n > 0 ? (float)real / (float)p.n : 0.f;
+    }
+    if (pb.total_dev) p.gscale = p.gscale / (float)(*pb.total_dev);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int i = tid; i < MAXP; i += 256) {
         if (i < p.n) {
@@ -199,12 +207,14 @@ __global__ __launch_bounds__(256) void k_mask_loss(const MLP pb) {
 
 // dcoef_full[anchor_idx[q]][k] = sum over the waves' partials in a fixed order: workgroup = (positive q, image), thread = (slice of
 // the waves, k); 8 slices are combined through LDS
-struct MLReduce { const float* part[MLB]; const int64_t* anchor_idx[MLB]; float* dcoef_full[MLB]; int n[MLB]; };
+struct MLReduce { const float* part[MLB]; const int64_t* anchor_idx[MLB]; float* dcoef_full[MLB]; const int* n_dev[MLB]; int n[MLB]; };
 
 __global__ __launch_bounds__(256) void k_mask_loss_reduce(const MLReduce rb, int nwaves) {
     __shared__ float s[8][32];
     const int img = blockIdx.y, q = blockIdx.x;
-    if (q >= rb.n[img]) return;
+    int n = rb.n[img];
+    if (rb.n_dev[img]) n = min(n, *rb.n_dev[img]);
+    if (q >= n) return;
     const int k = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const float* part = rb.part[img];
     const int per = (nwaves + 7) / 8;
@@ -224,22 +234,22 @@ constexpr int ML_BLOCKS = 64;    // 256 waves per image, each walking ~P/32/256 
 constexpr size_t ML_PART_BYTES = (size_t)ML_BLOCKS * 4 * MAXP * 32 * sizeof(float);
 
 int launch_chunk(const ym_mask_loss_item* items, int nb, const float* const* coef, const float* const* boxes, const int* const* gt32,
-                 int Hp, int Wp, float gscale, double* loss_accum, char* workspace, hipStream_t st) {
+                 int Hp, int Wp, float gscale, const int32_t* total_dev, double* loss_accum, char* workspace, hipStream_t st) {
     MLP p;
     MLReduce r;
     int nmax = 0;
     for (int i = 0; i < nb; ++i) {
         const ym_mask_loss_item& a = items[i];
         MLItem& it = p.it[i];
-        it.proto = a.proto; it.dsmask = a.gt_masks_ds; it.dproto = a.dproto; it.n = a.n; it.wscale = a.wscale;
+        it.proto = a.proto; it.dsmask = a.gt_masks_ds; it.dproto = a.dproto; it.n = a.n; it.wscale = a.wscale; it.n_dev = a.n_dev;
         it.part = (float*)(workspace + (size_t)i * ML_PART_BYTES);
         if (coef) { it.coef = coef[i]; it.boxes = boxes[i]; it.gt_idx32 = gt32[i]; it.gt_idx64 = nullptr; it.rows = nullptr; }
         else { it.coef = a.coef_full; it.boxes = a.anchor_box; it.gt_idx32 = nullptr; it.gt_idx64 = a.anchor_gt; it.rows = a.anchor_idx; }
-        r.part[i] = it.part; r.anchor_idx[i] = a.anchor_idx; r.dcoef_full[i] = a.dcoef_full; r.n[i] = a.n;
+        r.part[i] = it.part; r.anchor_idx[i] = a.anchor_idx; r.dcoef_full[i] = a.dcoef_full; r.n[i] = a.n; r.n_dev[i] = a.n_dev;
         if (a.n > nmax) nmax = a.n;
     }
     if (nmax == 0) return YM_OK;
-    p.loss = loss_accum; p.Hp = Hp; p.Wp = Wp; p.P = Hp * Wp; p.ntiles = (p.P + 31) / 32; p.gscale = gscale;
+    p.loss = loss_accum; p.total_dev = total_dev; p.Hp = Hp; p.Wp = Wp; p.P = Hp * Wp; p.ntiles = (p.P + 31) / 32; p.gscale = gscale;
     hipLaunchKernelGGL(k_mask_loss, dim3(ML_BLOCKS, nb), dim3(256), 0, st, p);
     hipLaunchKernelGGL(k_mask_loss_reduce, dim3(nmax, nb), dim3(256), 0, st, r, ML_BLOCKS * 4);
     return ym_check_launch("mask_loss");
@@ -250,8 +260,8 @@ int launch_chunk(const ym_mask_loss_item* items, int nb, const float* const* coe
 extern "C" size_t ym_mask_loss_workspace_bytes(void) { return ML_PART_BYTES + 256; }
 extern "C" size_t ym_mask_loss_batch_workspace_bytes(int B) { return (size_t)(B < MLB ? (B > 0 ? B : 1) : MLB) * ML_PART_BYTES + 256; }
 
-extern "C" int ym_mask_loss_batch(const ym_mask_loss_item* items, int B, int Hp, int Wp, float gscale, double* loss_accum,
-                                  void* workspace, size_t workspace_bytes, ym_stream_t s) {
+extern "C" int ym_mask_loss_batch(const ym_mask_loss_item* items, int B, int Hp, int Wp, float gscale, const int32_t* total_pos_dev,
+                                  double* loss_accum, void* workspace, size_t workspace_bytes, ym_stream_t s) {
     YM_REQUIRE(items && B > 0 && Hp > 0 && Wp > 0 && loss_accum && workspace, "mask_loss_batch: bad args");
     for (int i = 0; i < B; ++i) {
         const ym_mask_loss_item& a = items[i];
@@ -262,7 +272,7 @@ extern "C" int ym_mask_loss_batch(const ym_mask_loss_item* items, int B, int Hp,
     if (workspace_bytes < ym_mask_loss_batch_workspace_bytes(B)) { ym_set_error("mask_loss_batch: workspace too small"); return YM_ENOSPC; }
     for (int b0 = 0; b0 < B; b0 += MLB) {
         const int nb = B - b0 < MLB ? B - b0 : MLB;
-        const int rc = launch_chunk(items + b0, nb, nullptr, nullptr, nullptr, Hp, Wp, gscale, loss_accum, (char*)workspace, (hipStream_t)s);
+        const int rc = launch_chunk(items + b0, nb, nullptr, nullptr, nullptr, Hp, Wp, gscale, total_pos_dev, loss_accum, (char*)workspace, (hipStream_t)s);
         if (rc != YM_OK) return rc;
     }
     return YM_OK;
@@ -281,5 +291,5 @@ extern "C" int ym_mask_loss_fwd_bwd(const float* proto, const float* coef_pos, c
     a.proto = proto; a.gt_masks_ds = gt_masks_ds; a.anchor_idx = anchor_idx; a.n = n; a.wscale = wscale; a.dproto = dproto;
     a.dcoef_full = dcoef_full;
     const int* g32 = gt_idx;
-    return launch_chunk(&a, 1, &coef_pos, &box_pos, &g32, Hp, Wp, gscale, loss_accum, (char*)workspace, (hipStream_t)s);
+    return launch_chunk(&a, 1, &coef_pos, &box_pos, &g32, Hp, Wp, gscale, nullptr, loss_accum, (char*)workspace, (hipStream_t)s);
 }

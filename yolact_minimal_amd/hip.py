@@ -71,7 +71,8 @@ class AugPlanC(ctypes.Structure):
 class MaskLossItem(ctypes.Structure):
     _fields_ = [('proto', ctypes.c_void_p), ('coef_full', ctypes.c_void_p), ('anchor_box', ctypes.c_void_p),
                 ('anchor_gt', ctypes.c_void_p), ('gt_masks_ds', ctypes.c_void_p), ('anchor_idx', ctypes.c_void_p),
-                ('n', ctypes.c_int32), ('wscale', ctypes.c_float), ('dproto', ctypes.c_void_p), ('dcoef_full', ctypes.c_void_p)]
+                ('n', ctypes.c_int32), ('wscale', ctypes.c_float), ('n_dev', ctypes.c_void_p), ('dproto', ctypes.c_void_p),
+                ('dcoef_full', ctypes.c_void_p)]
 
 
 class NmsCfg(ctypes.Structure):
@@ -134,7 +135,7 @@ def lib():
         L.ym_mask_loss_fwd_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp, vp, vp, sz, vp]
         L.ym_mask_loss_batch_workspace_bytes.argtypes = [i32]
         L.ym_mask_loss_batch_workspace_bytes.restype = sz
-        L.ym_mask_loss_batch.argtypes = [ctypes.POINTER(MaskLossItem), i32, i32, i32, f32, vp, vp, sz, vp]
+        L.ym_mask_loss_batch.argtypes = [ctypes.POINTER(MaskLossItem), i32, i32, i32, f32, vp, vp, vp, sz, vp]
         L.ym_mask_iou_workspace_bytes.argtypes = [i32, i32, i64]
         L.ym_mask_iou_workspace_bytes.restype = sz
         L.ym_mask_iou.argtypes = [vp, i32, vp, i32, i64, vp, vp, sz, vp]

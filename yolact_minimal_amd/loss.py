@@ -11,8 +11,8 @@ Reference: `compute_loss` `/root/reference/modules/yolact.py:166-203`, `category
 
 The losses are terminal nodes of the graph, so each kernel also writes d(loss)/d(input); the autograd Functions below only
 scale those by the incoming gradient.  Same arithmetic and normalisations as the reference (each rank normalises by its LOCAL
-positive count); the CPU `randperm` that subsamples > masks_to_train positives is kept on purpose (:263).  One host read per
-step (the per-image positive counts, needed to size the mask-loss launches).
+positive count).  No host synchronisation anywhere in the loss: the positive counts are produced and consumed on the device,
+so the host keeps enqueueing ahead of the GPU through forward, loss and backward (the reference reads them back per image).
 """
 import ctypes
 
@@ -70,11 +70,11 @@ class _ClassBoxLossFn(torch.autograd.Function):
 class _MaskLossFn(torch.autograd.Function):
     """Forward + backward of the mask term for the whole batch in one HIP launch pair (`ym_mask_loss_batch`, workgroup row =
     image): the coefficient x prototype GEMM, sigmoid, crop, BCE and both gradient GEMMs run on the f32 MFMA; the positives'
-    coefficients / matched boxes / gt indices are read in place through the anchor indices.  Autograd only scales the stored
-    gradients."""
+    coefficients / matched boxes / gt indices are read in place through the anchor indices, and the per-image / total positive
+    counts are read from device memory (no host synchronisation).  Autograd only scales the stored gradients."""
 
     @staticmethod
-    def forward(ctx, proto_p, coef_p, anchor_box, anchor_gt, per_image, coeff):
+    def forward(ctx, proto_p, coef_p, anchor_box, anchor_gt, idx, ds_masks, num_pos, alpha_hw):
         b, hp, wp, _ = proto_p.shape
         dev = proto_p.device
         proto_c, coef_c = proto_p.detach().contiguous(), coef_p.detach().contiguous()
@@ -82,53 +82,52 @@ class _MaskLossFn(torch.autograd.Function):
         dcoef = torch.zeros_like(coef_c)
         acc = torch.zeros(1, dtype=torch.float64, device=dev)
         ws = torch.empty(hip.lib().ym_mask_loss_batch_workspace_bytes(b), dtype=torch.uint8, device=dev)
+        hip.ptr(idx, torch.int64), hip.ptr(anchor_box), hip.ptr(anchor_gt, torch.int64), hip.ptr(num_pos, torch.int32)
+        cap = idx.shape[1]
         items = (hip.MaskLossItem * b)()
-        for i, item in enumerate(per_image):
+        for i in range(b):
             it = items[i]
-            if item is None:
-                it.n = 0
-                continue
-            idx, dsmask, wscale = item
             it.proto, it.coef_full = proto_c[i].data_ptr(), coef_c[i].data_ptr()
-            it.anchor_box, it.anchor_gt = hip.ptr(anchor_box[i]).value, hip.ptr(anchor_gt[i], torch.int64).value
-            it.gt_masks_ds, it.anchor_idx = hip.ptr(dsmask).value, hip.ptr(idx, torch.int64).value
-            it.n, it.wscale = idx.shape[0], float(wscale)
+            it.anchor_box, it.anchor_gt = anchor_box[i].data_ptr(), anchor_gt[i].data_ptr()
+            it.gt_masks_ds, it.anchor_idx = hip.ptr(ds_masks[i]).value, idx[i].data_ptr()
+            it.n, it.wscale, it.n_dev = cap, 1.0, num_pos.data_ptr() + 4 * i
             it.dproto, it.dcoef_full = dproto[i].data_ptr(), dcoef[i].data_ptr()
-        hip.check(hip.lib().ym_mask_loss_batch(items, b, hp, wp, float(coeff), _vp(acc), _vp(ws), ws.numel(), hip.stream_ptr()),
-                  'ym_mask_loss_batch')
+        hip.check(hip.lib().ym_mask_loss_batch(items, b, hp, wp, float(alpha_hw), ctypes.c_void_p(num_pos.data_ptr() + 4 * b),
+                                               _vp(acc), _vp(ws), ws.numel(), hip.stream_ptr()), 'ym_mask_loss_batch')
         ctx.save_for_backward(dproto, dcoef)
-        return (acc * coeff).float().reshape(())
+        return (acc * alpha_hw / num_pos[b]).float().reshape(())
 
     @staticmethod
     def backward(ctx, grad_out):
         dproto, dcoef = ctx.saved_tensors
-        return dproto * grad_out, dcoef * grad_out, None, None, None, None
+        return dproto * grad_out, dcoef * grad_out, None, None, None, None, None, None
+
+
+MAX_MASKS_PER_IMAGE = 128        # positives per image the mask-loss kernel holds (cfg.masks_to_train = 100)
 
 
 def lincomb_mask_loss(cfg, pos, anchor_gt, coef_p, proto_p, mask_gt, anchor_box, num_pos=None):
-    """`num_pos`: host list [n_0..n_{B-1}, total] of positive counts (read back once per step); computed here when absent."""
+    """`num_pos`: int32 device tensor [n_0..n_{B-1}, total] of positive counts (`ym_class_box_loss` produces it); computed here
+    when absent.  Nothing is read back to the host: the kernel takes the counts from device memory, and the reference's
+    `randperm` sub-sampling of > masks_to_train positives (:261-267, a CPU generator there) is a device-side random top-k —
+    a uniformly random subset like the reference's, from the device generator instead of the host one."""
     ph, pw = proto_p.shape[1:3]
+    b, n = pos.shape
+    dev = proto_p.device
     if num_pos is None:
         per = pos.sum(1)
-        num_pos = torch.cat([per, per.sum(0, keepdim=True)]).tolist()
-    total_pos = int(num_pos[-1])
-    per_image = []
-    for i in range(coef_p.shape[0]):
-        n_i = int(num_pos[i])
-        if n_i == 0:
-            per_image.append(None)
-            continue
-        idx = torch.nonzero_static(pos[i], size=n_i).flatten()                        # size known: no host sync
+        num_pos = torch.cat([per, per.sum(0, keepdim=True)]).to(torch.int32)
+    cap = min(int(cfg.masks_to_train), MAX_MASKS_PER_IMAGE, n)
+    keys = torch.rand(b, n, device=dev).masked_fill_(~pos, -1.0)
+    idx = keys.topk(cap, dim=1).indices.contiguous()          # the positives (random order) come first; the rest is never read
+    ds_masks = []
+    for i in range(b):
         g = mask_gt[i].shape[0]
-        ds = torch.empty(g, ph, pw, device=proto_p.device, dtype=torch.float32)     # bilinear(align_corners=False) then > 0.5
+        ds = torch.empty(g, ph, pw, device=dev, dtype=torch.float32)                 # bilinear(align_corners=False) then > 0.5
         hip.mask_resize_binarize(mask_gt[i].contiguous().float(), ph, pw, ds)
-        old = n_i
-        if old > cfg.masks_to_train:
-            sel = torch.randperm(old)[:cfg.masks_to_train].to(idx.device)            # CPU generator, like the reference (:263)
-            idx = idx[sel]
-        per_image.append((idx.contiguous(), ds.reshape(g, ph * pw), old / idx.shape[0]))
-    coeff = cfg.mask_alpha / ph / pw / total_pos
-    return _MaskLossFn.apply(proto_p, coef_p, anchor_box.contiguous().float(), anchor_gt.contiguous(), per_image, coeff)
+        ds_masks.append(ds.reshape(g, ph * pw))
+    return _MaskLossFn.apply(proto_p, coef_p, anchor_box.contiguous().float(), anchor_gt.contiguous(), idx, ds_masks,
+                             num_pos.contiguous(), cfg.mask_alpha / ph / pw)
 
 
 class _SemanticLossFn(torch.autograd.Function):
@@ -182,7 +181,6 @@ def compute_loss(cfg, anchors, class_p, box_p, coef_p, proto_p, seg_p, box_class
     anchors = anchors.contiguous().float()
     match(cfg, [bc.contiguous().float() for bc in box_class], anchors, offsets, conf_gt, anchor_box, anchor_gt, ws)
     loss_c, loss_b = _ClassBoxLossFn.apply(class_p, box_p, offsets, conf_gt, num_pos, cfg.conf_alpha, cfg.bbox_alpha, 3)
-    counts = num_pos.tolist()                                                         # the one host read of the step
-    loss_m = lincomb_mask_loss(cfg, conf_gt > 0, anchor_gt, coef_p, proto_p, mask_gt, anchor_box, counts)
+    loss_m = lincomb_mask_loss(cfg, conf_gt > 0, anchor_gt, coef_p, proto_p, mask_gt, anchor_box, num_pos)   # counts stay on the device
     loss_s = semantic_seg_loss(cfg, seg_p, mask_gt, box_class)
     return loss_c, loss_b, loss_m, loss_s

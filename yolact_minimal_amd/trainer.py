@@ -301,6 +301,7 @@ class Trainer:
         self.opt.lr = lr_at(self.cfg, self.step_idx)
         if self.buffers_flat is not None and self.world > 1:
             dist.broadcast(self.buffers_flat, 0)      # BN running stats follow rank 0, one 0.4 MB message
+        self.opt.zero_grad()                          # before the forward: the host is ahead of the device here
         losses = self.model(images, targets, masks)
         if self.nbt_flat is not None:
             self.nbt_flat += 1                        # every BatchNorm ran once (num_batches_tracked)
@@ -308,7 +309,6 @@ class Trainer:
             all_loss = torch.stack([l.detach() for l in losses])
             dist.all_reduce(all_loss)                 # 16-byte logging collective, train.py:121-122
         total = losses[0] + losses[1] + losses[2] + losses[3]
-        self.opt.zero_grad()
         total.backward()
         if self.reducer is not None:
             self.reducer.finish()
