@@ -383,7 +383,7 @@ def test_mask_loss_subsamples_on_the_device_without_host_sync():
         rows = (cg.grad.abs().sum(-1) > 0).cpu()
         assert int(rows[0].sum()) == 100 and bool((rows[0] <= pos[0]).all())
         assert torch.equal(rows[1], pos[1])
-        losses.append(float(got))
+        losses.append(float(got.detach()))
         chosen.append(rows[0])
     assert not torch.equal(chosen[0], chosen[1])                         # a different draw per call
     assert abs(np.mean(losses) / float(full) - 1) < 0.15                 # the re-weighted subset estimates the full sum

@@ -269,11 +269,13 @@ class Trainer:
     # utils/common_utils.py:41-63, so a resumed run restarts the momentum buffers and the LR warm-up) -------------------
     def state_dict(self):
         """Model weights under the reference's key names (loadable by `Yolact.load_weights` / the reference) plus the
-        optimizer's flat momentum buffer and the step counters."""
+        optimizer's flat momentum buffer, the step counters and the random generator states."""
         return {'model': {k: v.detach().clone() for k, v in self.net.state_dict().items()},
                 'momentum': self.opt.buf.detach().clone(), 'opt_steps': self.opt.steps, 'step_idx': self.step_idx,
                 'exp_avg_sq': self.opt.exp_avg_sq.detach().clone() if hasattr(self.opt, 'exp_avg_sq') else None,
-                'param_numel': [p.numel() for p in self.opt.params]}
+                'param_numel': [p.numel() for p in self.opt.params],
+                # generator states: DropPath and the mask-loss sub-sampling draw from the device generator
+                'cuda_rng': torch.cuda.get_rng_state(self.device), 'cpu_rng': torch.get_rng_state()}
 
     def load_state_dict(self, state):
         if state['param_numel'] != [p.numel() for p in self.opt.params]:
@@ -289,6 +291,9 @@ class Trainer:
             if state.get('exp_avg_sq') is not None and hasattr(self.opt, 'exp_avg_sq'):
                 self.opt.exp_avg_sq.copy_(state['exp_avg_sq'])
         self.opt.steps, self.step_idx = int(state['opt_steps']), int(state['step_idx'])
+        if state.get('cuda_rng') is not None:
+            torch.cuda.set_rng_state(state['cuda_rng'].cpu(), self.device)
+            torch.set_rng_state(state['cpu_rng'].cpu())
         self.net.mark_weights_changed()
 
     def save(self, path):
