@@ -197,6 +197,20 @@ int ym_runs_to_mask(const uint32_t* counts, const int32_t* run_off, int n, int H
 int ym_pack_conv_weight_dgrad(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, int cout_pad,
                               ym_stream_t s);
 
+/* All the weight packings of a training step in one launch (after the optimizer step every layer's forward and dgrad image is
+ * stale at once).  items_dev: DEVICE array, one entry per destination image, ordered by first_chunk:
+ *   kind 0: ym_pack_conv_weight   into dst [rows][pad_b]          (pad_a = cin_pad, pad_b = k_pad, rows >= cout zero padded)
+ *   kind 1: ym_pack_conv_weight_dgrad into dst [cin][kh][kw][pad_a] (pad_a = cout_pad)
+ * first_chunk = running sum of ceil(dst elements / 1024) over the preceding items; total_chunks = the sum over all items. */
+typedef struct {
+    const float* src;        /* OIHW weight */
+    float* dst;
+    int32_t cout, cin, kh, kw, pad_a, pad_b, rows, kind;
+    uint32_t first_chunk;
+    uint32_t reserved;
+} ym_pack_item;
+int ym_pack_conv_weights_batch(const ym_pack_item* items_dev, int n_items, int total_chunks, ym_stream_t s);
+
 typedef struct {
     const float* x;          /* forward input NHWC [B][H][W][Cin] (Cin = padded channel pitch; 4 for the stem) */
     const float* dy;         /* output gradient [B][Ho][Wo][Cout] (Cout = channel pitch, multiple of 4) */

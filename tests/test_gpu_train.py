@@ -589,3 +589,47 @@ def test_bench_two_ranks_control_flow():
     assert d['n_gpus'] == 2 and d['value'] > 0 and d['scaling'] == 'weak' and d['config']['global_batch'] == 2
     assert d['extra']['train']['global_batch'] == 4 and d['extra']['train']['finite'] and 'ddp2' in d['extra']['train']['parallelism']
     assert d['cpu_baseline'] is None                    # the CPU leg runs at N=1 only
+
+
+def test_batched_weight_packing_matches_the_per_layer_kernels():
+    """`ym_pack_conv_weights_batch` (every forward / dgrad weight image of a step in one launch) == the per-layer pack kernels,
+    and the trainer-owned cache refreshes after an optimizer step but not within one."""
+    from yolact_minimal_amd import hip, train_engine as T
+    from yolact_minimal_amd.trainer import FlatSGD
+    torch.manual_seed(0)
+    convs = [torch.nn.Conv2d(3, 64, 7, bias=False), torch.nn.Conv2d(64, 64, 3, bias=False), torch.nn.Conv2d(256, 81 * 3, 3),
+             torch.nn.Conv2d(128, 256, 1, bias=False), torch.nn.Conv2d(32, 40, 1)]
+    convs = [c.to(DEV) for c in convs]
+    opt = FlatSGD([p for c in convs for p in c.parameters()], lr=0.1)
+
+    def images():
+        out = []
+        for c in convs:
+            w = c.weight
+            cout, cin, kh, kw = w.shape
+            cin_pad, cout_pad = (4 if cin == 3 else cin), (cout + 31) // 32 * 32
+            wp, k_pad = T._pack_fwd(w, cin_pad, cout_pad)
+            ref = torch.zeros(cout_pad, k_pad, device=DEV)
+            hip.check(hip.lib().ym_pack_conv_weight(hip.ptr(w.detach().contiguous()), hip.ptr(ref), cout, cin, kh, kw, cin_pad, k_pad,
+                                                    hip.stream_ptr()), 'ym_pack_conv_weight')
+            assert torch.equal(wp.reshape(cout_pad, k_pad), ref)
+            wd = T._pack_dgrad(w, cout_pad)
+            refd = torch.empty(cin, kh * kw * cout_pad, device=DEV)
+            hip.check(hip.lib().ym_pack_conv_weight_dgrad(hip.ptr(w.detach().contiguous()), hip.ptr(refd), cout, cin, kh, kw, cout_pad,
+                                                          hip.stream_ptr()), 'ym_pack_conv_weight_dgrad')
+            assert torch.equal(wd.reshape(-1), refd.reshape(-1))
+            out.append((wp, wd))
+        return out
+
+    first = images()                                            # created one by one (single kernels)
+    again = images()                                            # same step: cache hits, the very same buffers
+    assert all(a[1].data_ptr() == b[1].data_ptr() for a, b in zip(first, again))
+    for p in opt.params:
+        p.grad = None
+        p._ym_grad_slot.normal_()
+        p._ym_in_slot = True
+    opt.step()                                                  # raw-pointer update of every weight -> one batched re-pack
+    images()                                                    # ... whose result equals the per-layer kernels on the NEW weights
+    with torch.no_grad():
+        convs[1].weight.mul_(2.0)                               # an in-place torch update bumps the version counter
+    images()

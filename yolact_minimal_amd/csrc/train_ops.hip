@@ -361,6 +361,44 @@ __global__ void k_pack_weight_dgrad(const float* __restrict__ w, float* __restri
     }
 }
 
+// Every layer's weight packing (forward [Cout_pad][k_pad] and dgrad [Cin][KH][KW][cout_pad] images) in ONE launch after an
+// optimizer step: workgroup = one 1024-element chunk of one item's destination; the item is found by bisection over the
+// chunk prefix in the device-side table.
+__global__ __launch_bounds__(256) void k_pack_weights_batch(const ym_pack_item* __restrict__ items, int n_items) {
+    int lo = 0, hi = n_items - 1;
+    while (lo < hi) {                                            // last item whose first_chunk <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].first_chunk <= blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const ym_pack_item it = items[lo];
+    const size_t base = (size_t)(blockIdx.x - it.first_chunk) * 1024;
+    const int KHW = it.kh * it.kw;
+    if (it.kind == 0) {                                          // forward image: [rows][k_pad], k = tap * cin_pad + c
+        const size_t total = (size_t)it.rows * it.pad_b;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t i = base + u * 256 + threadIdx.x;
+            if (i >= total) break;
+            const int n = (int)(i / it.pad_b), k = (int)(i - (size_t)n * it.pad_b);
+            const int tap = k / it.pad_a, c = k - tap * it.pad_a;
+            float v = 0.f;
+            if (n < it.cout && tap < KHW && c < it.cin) v = it.src[((size_t)n * it.cin + c) * KHW + tap];
+            it.dst[i] = v;
+        }
+    } else {                                                     // dgrad image: [Cin][KH][KW][cout_pad]
+        const size_t total = (size_t)it.cin * KHW * it.pad_a;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t i = base + u * 256 + threadIdx.x;
+            if (i >= total) break;
+            const int co = (int)(i % it.pad_a);
+            const size_t t = i / it.pad_a;
+            const int tap = (int)(t % KHW), ci = (int)(t / KHW);
+            it.dst[i] = co < it.cout ? it.src[((size_t)co * it.cin + ci) * KHW + tap] : 0.f;
+        }
+    }
+}
+
 // SGD with momentum and weight decay over a flat parameter buffer (torch.optim.SGD semantics, dampening 0, no nesterov):
 //   g = grad + wd * p ; buf = first ? g : mom * buf + g ; p -= lr * buf
 __global__ __launch_bounds__(256) void k_sgd(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
@@ -504,6 +542,12 @@ extern "C" int ym_pack_conv_weight_dgrad(const float* w_oihw, float* w_packed, i
     hipLaunchKernelGGL(k_pack_weight_dgrad, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)s, w_oihw, w_packed, Cout, Cin, KH,
                        KW, cout_pad);
     return ym_check_launch("pack_conv_weight_dgrad");
+}
+
+extern "C" int ym_pack_conv_weights_batch(const ym_pack_item* items_dev, int n_items, int total_chunks, ym_stream_t s) {
+    YM_REQUIRE(items_dev && n_items > 0 && total_chunks > 0, "pack_conv_weights_batch: bad args");
+    hipLaunchKernelGGL(k_pack_weights_batch, dim3(total_chunks), dim3(256), 0, (hipStream_t)s, items_dev, n_items);
+    return ym_check_launch("pack_conv_weights_batch");
 }
 
 extern "C" int ym_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,

@@ -22,7 +22,7 @@ ABI_SYMBOLS = (
     'ym_softmax_rows', 'ym_nms_workspace_bytes', 'ym_detect_fast_nms', 'ym_detect_greedy_nms',
     'ym_greedy_nms_workspace_bytes', 'ym_greedy_nms', 'ym_mask_assemble', 'ym_mask_resize_binarize',
     'ym_boxes_to_pixels',
-    'ym_pack_conv_weight_dgrad', 'ym_conv2d_wgrad_workspace_bytes', 'ym_conv2d_wgrad', 'ym_bn_train_fwd',
+    'ym_pack_conv_weight_dgrad', 'ym_pack_conv_weights_batch', 'ym_conv2d_wgrad_workspace_bytes', 'ym_conv2d_wgrad', 'ym_bn_train_fwd',
     'ym_val_preprocess', 'ym_layernorm', 'ym_patch_merge_layernorm', 'ym_swin_window_attention',
     'ym_mask_loss_workspace_bytes', 'ym_mask_loss_fwd_bwd', 'ym_mask_loss_batch_workspace_bytes', 'ym_mask_loss_batch',
     'ym_mask_iou_workspace_bytes', 'ym_mask_iou', 'ym_box_iou', 'ym_match_detections', 'ym_rle_encode', 'ym_ann_to_mask_workspace_bytes', 'ym_poly_to_mask', 'ym_runs_to_mask', 'ym_train_aug_image', 'ym_train_aug_masks',
@@ -66,6 +66,12 @@ class AugPlanC(ctypes.Structure):
                                               'fx', 'fy', 'has_brightness', 'has_contrast')] + \
                [(n, ctypes.c_float) for n in ('brightness', 'contrast', 'saturation', 'hue')] + \
                [('mean', ctypes.c_float * 3), ('std', ctypes.c_float * 3)]
+
+
+class PackItem(ctypes.Structure):
+    _fields_ = [('src', ctypes.c_void_p), ('dst', ctypes.c_void_p)] + \
+               [(n, ctypes.c_int32) for n in ('cout', 'cin', 'kh', 'kw', 'pad_a', 'pad_b', 'rows', 'kind')] + \
+               [('first_chunk', ctypes.c_uint32), ('reserved', ctypes.c_uint32)]
 
 
 class MaskLossItem(ctypes.Structure):
@@ -122,6 +128,7 @@ def lib():
         L.ym_mask_resize_binarize.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
         L.ym_boxes_to_pixels.argtypes = [vp, vp, i32, f32, vp]
         L.ym_pack_conv_weight_dgrad.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+        L.ym_pack_conv_weights_batch.argtypes = [vp, i32, i32, vp]
         L.ym_conv2d_wgrad_workspace_bytes.argtypes = [ctypes.POINTER(WgradDesc)]
         L.ym_conv2d_wgrad_workspace_bytes.restype = sz
         L.ym_conv2d_wgrad.argtypes = [ctypes.POINTER(WgradDesc), vp, sz, vp]

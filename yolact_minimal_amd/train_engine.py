@@ -172,17 +172,122 @@ class _StatsPool:
 _stats_pool = _StatsPool()
 
 
+# ---- packed weight images ---------------------------------------------------------------------------------------------------
+# Every conv needs its OIHW weight as a forward image ([Cout][k_pad]) and, in backward, as a dgrad image ([Cin][KH][KW][Cout]).
+# After an optimizer step all of them are stale at once: when the trainer's flat optimizer owns the parameters (FlatSGD sets
+# `_ym_grad_slot`, and is the only writer: it bumps `weights_epoch()`), the images live in persistent buffers and ONE
+# `ym_pack_conv_weights_batch` launch refreshes all of them on the first request of a step (181 launches -> 1 for res101).
+# Parameters driven by anything else (a torch optimizer, the reference loop verbatim) are packed per use, as before.
+_EPOCH = [0]
+
+
+def weights_changed():
+    """Raw-pointer writers of parameter memory (FlatSGD / FlatAdamW step, checkpoint load, broadcast) call this."""
+    _EPOCH[0] += 1
+
+
+class _PackCache:
+    def __init__(self):
+        self.entries = {}          # key -> dict(ref, dst, item fields, stamp)
+        self.table = None          # device copy of the ym_pack_item array
+        self.order = []
+        self.total_chunks = 0
+
+    @staticmethod
+    def _owner(weight):
+        base = weight._base if weight._base is not None else weight
+        return base if getattr(base, '_ym_grad_slot', None) is not None else None
+
+    def get(self, weight, kind, pad_a, pad_b, rows):
+        """Packed image of `weight` (kind 0: forward, 1: dgrad), or None when the parameter is not trainer-owned."""
+        owner = self._owner(weight)
+        if owner is None or not weight.is_contiguous() or os.environ.get('YM_PACK_CACHE', '1') == '0':
+            return None
+        cout, cin, kh, kw = weight.shape
+        key = (weight.data_ptr(), cout, cin, kh, kw, kind, pad_a, pad_b, rows)
+        e = self.entries.get(key)
+        stamp = (weight._version, _EPOCH[0])
+        if e is not None and e['ref']() is owner:
+            if e['stamp'] != stamp:
+                self.refresh()
+            return e['dst']
+        import weakref
+        n = rows * pad_b if kind == 0 else cin * kh * kw * pad_a
+        e = dict(ref=weakref.ref(owner),
+                 dst=torch.empty(n, device=weight.device, dtype=torch.float32), src=weight.data_ptr(), dims=(cout, cin, kh, kw),
+                 kind=kind, pad_a=pad_a, pad_b=pad_b, rows=rows, chunks=(n + 1023) // 1024, stamp=None)
+        self.entries[key] = e
+        self.table = None                                   # rebuilt at the next refresh
+        L = hip.lib()                                       # a new image is packed on its own
+        if kind == 0:
+            hip.check(L.ym_pack_conv_weight(hip.ptr(weight.detach()), hip.ptr(e['dst']), cout, cin, kh, kw, pad_a, pad_b, hip.stream_ptr()),
+                      'ym_pack_conv_weight')
+            if rows > cout:
+                e['dst'][cout * pad_b:].zero_()
+        else:
+            hip.check(L.ym_pack_conv_weight_dgrad(hip.ptr(weight.detach()), hip.ptr(e['dst']), cout, cin, kh, kw, pad_a, hip.stream_ptr()),
+                      'ym_pack_conv_weight_dgrad')
+        e['stamp'] = stamp
+        return e['dst']
+
+    def refresh(self):
+        """Re-pack every live image in one launch."""
+        dead = [k for k, e in self.entries.items() if e['ref']() is None]
+        for k in dead:
+            del self.entries[k]
+            self.table = None
+        if not self.entries:
+            return
+        any_e = next(iter(self.entries.values()))
+        dev = any_e['dst'].device
+        if self.table is None:
+            self.order = list(self.entries.values())
+            arr = (hip.PackItem * len(self.order))()
+            at = 0
+            for it, e in zip(arr, self.order):
+                it.src, it.dst = e['src'], e['dst'].data_ptr()
+                it.cout, it.cin, it.kh, it.kw = e['dims']
+                it.pad_a, it.pad_b, it.rows, it.kind, it.first_chunk = e['pad_a'], e['pad_b'], e['rows'], e['kind'], at
+                at += e['chunks']
+            self.total_chunks = at
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            self.table = host.to(dev)
+        with torch.cuda.device(dev):
+            hip.check(hip.lib().ym_pack_conv_weights_batch(ctypes.c_void_p(self.table.data_ptr()), len(self.order), self.total_chunks,
+                                                           hip.stream_ptr()), 'ym_pack_conv_weights_batch')
+        for e in self.order:
+            owner = e['ref']()
+            e['stamp'] = (owner._version, _EPOCH[0])
+
+
+_pack_cache = _PackCache()
+
+
 def _pack_fwd(weight, cin_pad, cout_pad):
     cout, cin, kh, kw = weight.shape
     k_pad = _ru(kh * kw * cin_pad, 32)
     if kh == 1 and kw == 1 and cin_pad == cin and cout_pad == cout and cin % 32 == 0 and weight.is_contiguous():
         return weight.detach().view(cout, cin), cin        # OIHW of a 1x1 conv IS the packed [Cout][K] image: no copy
+    cached = _pack_cache.get(weight, 0, cin_pad, k_pad, cout_pad)
+    if cached is not None:
+        return cached.view(cout_pad, k_pad), k_pad
     if cout_pad == cout:
         return hip.pack_conv_weight(weight.detach(), cin_pad, k_pad), k_pad
     wp = torch.zeros(cout_pad, k_pad, device=weight.device, dtype=torch.float32)
     hip.check(hip.lib().ym_pack_conv_weight(hip.ptr(weight.detach().contiguous()), hip.ptr(wp), cout, cin, kh, kw, cin_pad,
                                             k_pad, hip.stream_ptr()), 'ym_pack_conv_weight')
     return wp, k_pad
+
+
+def _pack_dgrad(weight, cout_pad):
+    cout, cin, kh, kw = weight.shape
+    cached = _pack_cache.get(weight, 1, cout_pad, 0, 0)
+    if cached is not None:
+        return cached
+    wd = torch.empty(cin, kh * kw * cout_pad, device=weight.device, dtype=torch.float32)
+    hip.check(hip.lib().ym_pack_conv_weight_dgrad(hip.ptr(weight.detach().contiguous()), hip.ptr(wd), cout, cin, kh, kw,
+                                                  cout_pad, hip.stream_ptr()), 'ym_pack_conv_weight_dgrad')
+    return wd
 
 
 def _conv_forward(x, wp, k_pad, cout_pad, kh, kw, stride, pad, shift, act, residual=None, bn_stats=None):
@@ -216,9 +321,7 @@ def _conv_dgrad(dz, weight, cout_pad, x_shape, stride, pad):
     cout, cin, kh, kw = weight.shape
     b, h, w, cin_x = x_shape
     assert cin_x == cin and cout_pad % 32 == 0
-    wd = torch.empty(cin, kh * kw * cout_pad, device=dz.device, dtype=torch.float32)
-    hip.check(hip.lib().ym_pack_conv_weight_dgrad(hip.ptr(weight.detach().contiguous()), hip.ptr(wd), cout, cin, kh, kw,
-                                                  cout_pad, hip.stream_ptr()), 'ym_pack_conv_weight_dgrad')
+    wd = _pack_dgrad(weight, cout_pad)
     dx = torch.empty(b, h, w, cin, device=dz.device, dtype=torch.float32)
     d = ConvDesc()
     d.inp, d.weight = dz.data_ptr(), wd.data_ptr()

@@ -17,6 +17,7 @@ import torch
 import torch.distributed as dist
 
 from . import hip
+from .train_engine import weights_changed
 
 
 def init_distributed(backend=None):
@@ -113,6 +114,7 @@ class FlatSGD:
                                         float(self.lr), float(self.momentum), float(self.weight_decay),
                                         int(self.steps == 0), hip.stream_ptr()), 'ym_sgd_step')
         self.steps += 1
+        weights_changed()                           # the packed weight images of train_engine are stale now
         for p in self.params:
             p._ym_in_slot = False                   # the next step() gathers again unless a hook already did
 
@@ -134,6 +136,7 @@ class FlatAdamW(FlatSGD):
                                           self.flat.numel(), float(self.lr), float(self.betas[0]), float(self.betas[1]),
                                           float(self.eps), float(self.weight_decay), int(self.steps), hip.stream_ptr()),
                   'ym_adamw_step')
+        weights_changed()
         for p in self.params:
             p._ym_in_slot = False
 
@@ -260,6 +263,7 @@ class Trainer:
             self.reducer = FlatGradReducer(self.opt, world)
         self.step_idx = 0
         self.net.mark_weights_changed()              # parameters were re-pointed at the flat buffer
+        weights_changed()
 
     @property
     def module(self):
@@ -295,6 +299,7 @@ class Trainer:
             torch.cuda.set_rng_state(state['cuda_rng'].cpu(), self.device)
             torch.set_rng_state(state['cpu_rng'].cpu())
         self.net.mark_weights_changed()
+        weights_changed()
 
     def save(self, path):
         torch.save(self.state_dict(), path)
