@@ -301,12 +301,13 @@ __global__ __launch_bounds__(256) void k_semantic_loss(const float* __restrict__
     const int img = blockIdx.y, g = sb.g[img];
     const float* __restrict__ ds = sb.ds[img];
     const int64_t* __restrict__ cls = sb.cls[img];
-    const size_t total = (size_t)P * pitch;
+    const unsigned total = (unsigned)P * (unsigned)pitch;        // < 2^31 (checked by the caller): 32-bit index arithmetic
     const float* x = seg + (size_t)img * total;
     float* dx = dseg + (size_t)img * total;
     double acc = 0.0;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        const int pix = (int)(e / (unsigned)pitch), c = (int)(e - (size_t)pix * pitch);
+    for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
+        const unsigned pix = e / (unsigned)pitch;
+        const int c = (int)(e - pix * (unsigned)pitch);
         float gval = 0.f;
         if (c < nc) {
             float t = 0.f;                                        // target = max over the gts of class c at this pixel
@@ -398,9 +399,10 @@ extern "C" int ym_semantic_loss_batch(const float* seg_nhwc, int B, int P, int p
     YM_REQUIRE(seg_nhwc && dseg && loss_accum && g && B > 0 && P > 0 && pitch >= num_classes && num_classes <= 256,
                "semantic_loss: bad args");
     for (int i = 0; i < B; ++i) YM_REQUIRE(g[i] == 0 || (gt_masks_ds && gt_cls && gt_masks_ds[i] && gt_cls[i]), "semantic_loss: null gt");
+    YM_REQUIRE((long long)P * pitch < (1ll << 31), "semantic_loss: P * pitch must stay below 2^31");
     const size_t total = (size_t)P * pitch;
     int grid = (int)((total + 255) / 256);
-    if (grid > 4096) grid = 4096;
+    if (grid > 96) grid = 96;                // one fp64 atomic per workgroup on ONE address: few workgroups, each looping
     for (int b0 = 0; b0 < B; b0 += MAXB) {
         const int nb = B - b0 < MAXB ? B - b0 : MAXB;
         SemanticBatch sb;
