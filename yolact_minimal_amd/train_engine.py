@@ -316,8 +316,9 @@ def _conv_forward(x, wp, k_pad, cout_pad, kh, kw, stride, pad, shift, act, resid
     return y
 
 
-def _conv_dgrad(dz, weight, cout_pad, x_shape, stride, pad):
-    """dx [B,H,W,Cin] from dz [B,Ho,Wo,cout_pad] (cout_pad % 32 == 0) and the OIHW weight."""
+def _conv_dgrad(dz, weight, cout_pad, x_shape, stride, pad, add=None):
+    """dx [B,H,W,Cin] from dz [B,Ho,Wo,cout_pad] (cout_pad % 32 == 0) and the OIHW weight; `add` [B,H,W,Cin] (another
+    consumer's gradient of the same tensor) is summed in the epilogue."""
     cout, cin, kh, kw = weight.shape
     b, h, w, cin_x = x_shape
     assert cin_x == cin and cout_pad % 32 == 0
@@ -330,6 +331,9 @@ def _conv_dgrad(dz, weight, cout_pad, x_shape, stride, pad):
     d.seg[0].n_begin, d.seg[0].n_end, d.seg[0].out = 0, cin, dx.data_ptr()
     d.seg[0].batch_stride, d.seg[0].pitch, d.seg[0].act = h * w * cin, cin, ACT_NONE
     d.transposed = 1
+    if add is not None:
+        assert tuple(add.shape) == (b, h, w, cin) and add.is_contiguous()
+        d.residual = add.data_ptr()
     _configure_conv(d, f'T_M{b * h * w}_N{cin}_C{cout_pad}_k{kh}_s{stride}')
     d.tile_counters = _tile_counters(dz.device)
     ws = scratch(dz.device, hip.conv_workspace_bytes(d))
@@ -408,11 +412,23 @@ class ConvBias(torch.autograd.Function):
         return dx, dw, dbias, None, None, None, None, (dz if has_res else None)
 
 
+class ResGradLink:
+    """A Bottleneck's input feeds conv1 AND the residual add of conv3 (modules/resnet.py:21,35-37); autograd would sum the two
+    gradients with an extra elementwise pass.  conv3's backward parks its residual gradient here (`give`) and conv1's backward,
+    which necessarily runs later, adds it in the epilogue of its data-gradient conv (`take`)."""
+    __slots__ = ('grad',)
+
+    def __init__(self):
+        self.grad = None
+
+
 class ConvBn(torch.autograd.Function):
     """out = relu?(BN_train(conv(x, W)) + residual?) — one Bottleneck stage (modules/resnet.py:23-38) in train mode."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, residual, stride, pad, relu, momentum, eps):
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, residual, stride, pad, relu, momentum, eps, link=None,
+                role=None):
+        ctx.link, ctx.role = link, role
         cout, cin, kh, kw = weight.shape
         wp, k_pad = _pack_fwd(weight, x.shape[-1], cout)
         stats = _stats_pool.take(2 * cout, x.device)           # zeroed (the fused epilogue accumulates into it)
@@ -456,9 +472,15 @@ class ConvBn(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0]
         if need_dx and cout % 32 != 0:
             raise RuntimeError('ConvBn dgrad needs Cout % 32 == 0')
-        dx = _conv_dgrad(dy, weight, cout, x.shape, stride, pad) if need_dx else None
+        add = None
+        if ctx.link is not None:
+            if ctx.role == 'give' and has_res:
+                ctx.link.grad, dres = dres, None                  # handed to the consumer that shares the tensor
+            elif ctx.role == 'take' and need_dx:
+                add, ctx.link.grad = ctx.link.grad, None
+        dx = _conv_dgrad(dy, weight, cout, x.shape, stride, pad, add) if need_dx else None
         dw = _conv_wgrad(x, dy, weight.shape, stride, pad, weight)
-        return dx, dw, dgamma, dbeta, None, None, dres, None, None, None, None, None
+        return dx, dw, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None
 
 
 class MaxPool(torch.autograd.Function):
@@ -498,9 +520,9 @@ class Bilinear2x(torch.autograd.Function):
         return dx, None
 
 
-def _conv_bn(x, conv, bn, relu=True, residual=None):
+def _conv_bn(x, conv, bn, relu=True, residual=None, link=None, role=None):
     out = ConvBn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, conv.stride[0],
-                       conv.padding[0], relu, float(bn.momentum), float(bn.eps))
+                       conv.padding[0], relu, float(bn.momentum), float(bn.eps), link, role)
     if not getattr(bn, '_ym_nbt_flat', False):               # the trainer bumps all counters with one launch
         bn.num_batches_tracked += 1
     return out
@@ -509,6 +531,9 @@ def _conv_bn(x, conv, bn, relu=True, residual=None):
 def _conv_bias(x, conv, act=ACT_NONE, cout_pad=None, residual=None):
     cout = conv.out_channels
     return ConvBias.apply(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], act, cout_pad or cout, residual)
+
+
+_FUSE_RES_GRAD = os.environ.get('YM_FUSE_RES_GRAD', '1') != '0'
 
 
 def train_features(net, img):
@@ -528,10 +553,12 @@ def train_features(net, img):
         outs = []
         for stage in bb.layers:
             for blk in stage:
-                y = _conv_bn(x, blk.conv1, blk.bn1)
+                # identity blocks: x feeds conv1 and the residual add; their two gradients meet in conv1's dgrad epilogue
+                link = ResGradLink() if (blk.downsample is None and x.requires_grad and _FUSE_RES_GRAD) else None
+                y = _conv_bn(x, blk.conv1, blk.bn1, link=link, role='take')
                 y = _conv_bn(y, blk.conv2, blk.bn2)
                 skip = _conv_bn(x, blk.downsample[0], blk.downsample[1], relu=False) if blk.downsample is not None else x
-                x = _conv_bn(y, blk.conv3, blk.bn3, relu=True, residual=skip)
+                x = _conv_bn(y, blk.conv3, blk.bn3, relu=True, residual=skip, link=link, role='give')
             outs.append(x)
         c3, c4, c5 = outs[1:4]
     fpn = net.fpn
