@@ -61,7 +61,8 @@ def test_conv_bias_fn_grads(cin, cout, k, stride, hw, act, res):
 
 @pytest.mark.parametrize('cin,cout,k,stride,hw,relu,res', [(64, 64, 1, 1, 16, True, False), (64, 64, 3, 1, 14, True, False),
                                                             (128, 256, 1, 2, 12, False, False), (64, 256, 1, 1, 10, True, True),
-                                                            (3, 64, 7, 2, 32, True, False)])
+                                                            (3, 64, 7, 2, 32, True, False), (512, 2048, 1, 1, 6, False, True),
+                                                            (256, 1024, 1, 1, 9, True, False)])
 def test_conv_bn_fn_grads(cin, cout, k, stride, hw, relu, res):
     from yolact_minimal_amd.train_engine import ConvBn
     from yolact_minimal_amd import hip

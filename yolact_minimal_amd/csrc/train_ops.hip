@@ -204,6 +204,52 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ y, c
     }
 }
 
+// k_bn_finalize + k_bn_apply in one launch (the statistics already sit in `sum` / `sumsq`, accumulated by the conv epilogue).
+// The grid stride is a multiple of C/4, so a thread keeps the same four channels for its whole loop: it derives their mean /
+// invstd once, in fp64 like k_bn_finalize (same floats), and the first C/4 threads of the grid also publish them and update the
+// running statistics.  Needs C/4 to divide 256 * gridDim.x.
+__global__ __launch_bounds__(256) void k_bn_finalize_apply(const float* __restrict__ y, const double* __restrict__ sum,
+                                                            const double* __restrict__ sumsq, float eps, float momentum,
+                                                            float* __restrict__ mean, float* __restrict__ invstd,
+                                                            float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ residual, int relu, float* __restrict__ out,
+                                                            long long M, int C) {
+    const int C4 = C >> 2;
+    const size_t gt = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int cq = (int)(gt % C4);
+    f32x4 mu, is;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = cq * 4 + e;
+        const double m = sum[c] / (double)M;
+        double var = sumsq[c] / (double)M - m * m;
+        if (var < 0) var = 0;
+        mu[e] = (float)m;
+        is[e] = (float)(1.0 / sqrt(var + (double)eps));
+        if (gt < (size_t)C4) {
+            mean[c] = mu[e]; invstd[c] = is[e];
+            if (run_mean) {
+                const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+                run_mean[c] = (float)((1.0 - momentum) * (double)run_mean[c] + momentum * m);
+                run_var[c] = (float)((1.0 - momentum) * (double)run_var[c] + momentum * unbiased);
+            }
+        }
+    }
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + cq * 4), b = *reinterpret_cast<const f32x4*>(beta + cq * 4);
+    const size_t total = (size_t)M * C4;
+    for (size_t i = gt; i < total; i += (size_t)gridDim.x * 256) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(y + i * 4);
+        v = (v - mu) * is * g + b;
+        if (residual) v += *reinterpret_cast<const f32x4*>(residual + i * 4);
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];
+        }
+        *reinterpret_cast<f32x4*>(out + i * 4) = v;
+    }
+}
+
 // dy_raw = gamma*invstd * (dz - dbeta/M - xhat * dgamma/M); dres = dz
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ dout, const float* __restrict__ out,
                                                        const float* __restrict__ y, const float* __restrict__ mean,
@@ -452,6 +498,21 @@ extern "C" int ym_bn_train_fwd_stats(const float* y, int64_t M, int C, const flo
     YM_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_train_fwd_stats: C %% 4 != 0");
     hipStream_t st = (hipStream_t)s;
     const double* sum = (const double*)stats;
+    {   // one launch when a grid exists whose stride (256 * grid) is a multiple of C/4 and covers C/4 threads
+        const int C4 = C / 4;
+        const size_t total = (size_t)M * C4;
+        long long grid = (long long)((total + 256 * 8 - 1) / (256 * 8));        // >= 8 float4 per thread: the per-thread fp64
+        if (grid > 2048) grid = 2048;                                             // statistics stay a small share of the work
+        int step = 1;                                                            // smallest g with C4 | 256 * g
+        while ((256ll * step) % C4 != 0 && step <= 64) ++step;
+        if ((256ll * step) % C4 == 0) {
+            grid = (grid + step - 1) / step * step;
+            while (grid * 256 < C4) grid += step;
+            hipLaunchKernelGGL(k_bn_finalize_apply, dim3((unsigned)grid), dim3(256), 0, st, y, sum, sum + C, eps, momentum, save_mean,
+                               save_invstd, running_mean, running_var, gamma, beta, residual, relu, out, (long long)M, C);
+            return ym_check_launch("bn_train_fwd_stats");
+        }
+    }
     hipLaunchKernelGGL(k_bn_finalize, dim3(ym_cdiv(C, 256)), dim3(256), 0, st, sum, sum + C, (long long)M, eps, momentum,
                        save_mean, save_invstd, running_mean, running_var, C);
     hipLaunchKernelGGL(k_bn_apply, dim3(ew_grid((size_t)M * (C / 4))), dim3(256), 0, st, y, save_mean, save_invstd, gamma, beta,
