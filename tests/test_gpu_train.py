@@ -329,11 +329,12 @@ def test_mask_loss_kernel_matches_oracle_autograd():
     ref = R.mask_loss(pos, anchor_gt, cf, pr, [m.double() for m in masks], anchor_box.double())
     ref.backward()
     pg, cg = proto.to(DEV).requires_grad_(), coef.to(DEV).requires_grad_()
+    torch.manual_seed(0)                                     # the visiting order of the positives comes from the device generator
     got = lincomb_mask_loss(cfg, pos.to(DEV), anchor_gt.to(DEV), cg, pg, [m.to(DEV) for m in masks], anchor_box.to(DEV))
     (got * 1.7).backward()
     np.testing.assert_allclose(float(got.detach()), float(ref.detach()), rtol=2e-5)
-    torch.testing.assert_close(pg.grad.cpu().double() / 1.7, pr.grad, rtol=1e-4, atol=1e-7)
-    torch.testing.assert_close(cg.grad.cpu().double() / 1.7, cf.grad, rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(pg.grad.cpu().double() / 1.7, pr.grad, rtol=1e-4, atol=1e-5 * float(pr.grad.abs().max()))
+    torch.testing.assert_close(cg.grad.cpu().double() / 1.7, cf.grad, rtol=1e-4, atol=1e-5 * float(cf.grad.abs().max()))
     assert float(pg.grad[1].abs().max()) == 0.0 and float(cg.grad[1].abs().max()) == 0.0
 
     # single-image entry point (gathered operands) = the same kernel with one item
@@ -351,8 +352,9 @@ def test_mask_loss_kernel_matches_oracle_autograd():
         hip.ptr(anchor_gt[i].to(DEV)[idx].to(torch.int32).contiguous(), torch.int32), hip.ptr(ds), hip.ptr(idx, torch.int64),
         idx.shape[0], hp, hp, 1.0, float(coeff), vp(acc), hip.ptr(dproto), hip.ptr(dcoef), vp(ws), ws.numel(), hip.stream_ptr()),
         'ym_mask_loss_fwd_bwd')
-    torch.testing.assert_close(dproto, pg.grad[i] / 1.7, rtol=1e-4, atol=1e-7)      # the batch form visits the positives in a
-    torch.testing.assert_close(dcoef, cg.grad[i] / 1.7, rtol=1e-4, atol=1e-7)        # random order: summation order differs
+    # the batch form visits the positives in a random order: fp32 summation order differs -> tolerance relative to the tensor
+    for got_t, ref_t in ((dproto, pg.grad[i] / 1.7), (dcoef, cg.grad[i] / 1.7)):
+        torch.testing.assert_close(got_t, ref_t, rtol=1e-4, atol=1e-5 * float(ref_t.abs().max()))
 
 
 def test_mask_loss_subsamples_on_the_device_without_host_sync():
