@@ -235,12 +235,14 @@ int ym_bn_train_fwd_stats(const float* y, int64_t M, int C, const float* gamma, 
                           float* out, float* save_mean, float* save_invstd, const void* stats, ym_stream_t s);
 
 /* Backward of the above: dz = dout * (out > 0 if relu); dres (optional) = dz; dgamma/dbeta [C];
+ * out may be NULL with relu = 1 when the forward had NO residual and `beta` is given: the mask is then re-derived from y with the
+ * forward's exact affine (one pass less over HBM); beta is otherwise unused and may be NULL.
  * dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)).  workspace >= 16*C bytes; with
  * ym_bn_train_bwd_workspace_bytes(M, C) the column sums use per-workgroup partials (larger grid, no atomics, ordered sum). */
 size_t ym_bn_train_bwd_workspace_bytes(int64_t M, int C);
 int ym_bn_train_bwd(const float* dout, const float* out, const float* y, int64_t M, int C, const float* gamma,
-                    const float* save_mean, const float* save_invstd, int relu, float* dy, float* dres, float* dgamma,
-                    float* dbeta, void* workspace, size_t workspace_bytes, ym_stream_t s);
+                    const float* beta, const float* save_mean, const float* save_invstd, int relu, float* dy, float* dres,
+                    float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, ym_stream_t s);
 
 /* Backward of a fused conv epilogue `y = act(conv + bias)`: dz = dy * act'(y) (dz may be NULL or == dy for
  * YM_ACT_NONE), dbias[C] = column sums of dz (optional).  workspace >= 8*C bytes when dbias != NULL. */

@@ -21,15 +21,22 @@ inline int rows_grid(long long M, int C4, int rows_per_block_hint = 64) {
 // ---- column reductions ------------------------------------------------------------------------------------
 // Thread (cq, rl): channel quad cq = tid % CQ, row lane rl = tid / CQ, CQ = min(C/4, 256).  Each block walks rows
 // rl + k*RL of its row range; partials are combined through LDS and then one fp64 atomicAdd per (block, channel).
+// The normalise + affine step of train-mode BN, in ONE fixed operation order (sub, mul, fused multiply-add): the forward pass and
+// the backward kernels that re-derive the ReLU mask from y instead of reading `out` must agree on the sign bit for bit.
+__device__ __forceinline__ float bn_affine(float v, float mu, float is, float g, float b) {
+    return __builtin_fmaf((v - mu) * is, g, b);
+}
+
 // MODE 0: sum x, sum x^2           (bn forward statistics)
-// MODE 1: sum dz, sum dz*xhat      (bn backward; dz = dout masked by relu(out))
+// MODE 1: sum dz, sum dz*xhat      (bn backward; dz = dout masked by relu(out); out == nullptr: the mask is re-derived from y)
 // MODE 2: sum dz                   (bias gradient; dz = dy * act'(y))
 template <int MODE>
 __global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ a, const float* __restrict__ b,
                                                      const float* __restrict__ c, const float* __restrict__ mean,
                                                      const float* __restrict__ invstd, long long M, int C, int relu, int act,
                                                      double* __restrict__ out0, double* __restrict__ out1,
-                                                     double* __restrict__ part = nullptr) {
+                                                     double* __restrict__ part = nullptr, const float* __restrict__ gamma = nullptr,
+                                                     const float* __restrict__ beta = nullptr) {
     // part != nullptr: every workgroup stores its column sums to part[block][2][C] (no atomics: with a large grid the 2*C
     // contended fp64 atomics per workgroup were the bottleneck, which is why the atomic path caps the grid at 512) and
     // k_col_finish adds the blocks in order.
@@ -43,8 +50,10 @@ __global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ a,
         const int cq = cq0 + cq_l;
         f64x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
         if (rl < RL && cq < C4) {
-            f32x4 mu = {0, 0, 0, 0}, is = {1, 1, 1, 1};
+            f32x4 mu = {0, 0, 0, 0}, is = {1, 1, 1, 1}, gm = {1, 1, 1, 1}, bt = {0, 0, 0, 0};
             if (MODE == 1) { mu = *reinterpret_cast<const f32x4*>(mean + cq * 4); is = *reinterpret_cast<const f32x4*>(invstd + cq * 4); }
+            const bool remask = MODE == 1 && relu && b == nullptr;      // no saved `out`: mask = bn_affine(y) > 0
+            if (remask) { gm = *reinterpret_cast<const f32x4*>(gamma + cq * 4); bt = *reinterpret_cast<const f32x4*>(beta + cq * 4); }
             const long long stride = (long long)gridDim.x * RL;
             long long m = (long long)blockIdx.x * RL + rl;
             if (MODE == 0) {
@@ -66,7 +75,10 @@ __global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ a,
                         const size_t off = (size_t)(m + u * stride) * C + cq * 4;
                         d[u] = *reinterpret_cast<const f32x4*>(a + off);
                         y[u] = *reinterpret_cast<const f32x4*>(c + off);
-                        o[u] = relu ? *reinterpret_cast<const f32x4*>(b + off) : f32x4{1.f, 1.f, 1.f, 1.f};
+                        if (remask) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[u][e] = bn_affine(y[u][e], mu[e], is[e], gm[e], bt[e]);
+                        } else o[u] = relu ? *reinterpret_cast<const f32x4*>(b + off) : f32x4{1.f, 1.f, 1.f, 1.f};
                     }
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
@@ -87,12 +99,15 @@ __global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ a,
                 } else if (MODE == 1) {
                     // a = dout, b = out (post-activation, for the relu mask), c = y_raw
                     f32x4 dz = x;
-                    if (relu) {
+                    const f32x4 y = *reinterpret_cast<const f32x4*>(c + off);
+                    if (remask) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dz[e] = bn_affine(y[e], mu[e], is[e], gm[e], bt[e]) > 0.f ? dz[e] : 0.f;
+                    } else if (relu) {
                         const f32x4 o = *reinterpret_cast<const f32x4*>(b + off);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) dz[e] = o[e] > 0.f ? dz[e] : 0.f;
                     }
-                    const f32x4 y = *reinterpret_cast<const f32x4*>(c + off);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { const double d = dz[e]; s0[e] += d; s1[e] += d * (double)((y[e] - mu[e]) * is[e]); }
                 } else {
@@ -194,7 +209,8 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ y, c
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + cq * 4), is = *reinterpret_cast<const f32x4*>(invstd + cq * 4);
         const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + cq * 4), b = *reinterpret_cast<const f32x4*>(beta + cq * 4);
         f32x4 v = *reinterpret_cast<const f32x4*>(y + i * 4);
-        v = (v - mu) * is * g + b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = bn_affine(v[e], mu[e], is[e], g[e], b[e]);
         if (residual) v += *reinterpret_cast<const f32x4*>(residual + i * 4);
         if (relu) {
 #pragma unroll
@@ -240,7 +256,8 @@ __global__ __launch_bounds__(256) void k_bn_finalize_apply(const float* __restri
     const size_t total = (size_t)M * C4;
     for (size_t i = gt; i < total; i += (size_t)gridDim.x * 256) {
         f32x4 v = *reinterpret_cast<const f32x4*>(y + i * 4);
-        v = (v - mu) * is * g + b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = bn_affine(v[e], mu[e], is[e], g[e], b[e]);
         if (residual) v += *reinterpret_cast<const f32x4*>(residual + i * 4);
         if (relu) {
 #pragma unroll
@@ -254,9 +271,10 @@ __global__ __launch_bounds__(256) void k_bn_finalize_apply(const float* __restri
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ dout, const float* __restrict__ out,
                                                        const float* __restrict__ y, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                       const double* __restrict__ dbeta, const double* __restrict__ dgamma,
-                                                       int relu, float* __restrict__ dy, float* __restrict__ dres, long long M,
-                                                       int C, float* __restrict__ dgamma_f, float* __restrict__ dbeta_f) {
+                                                       const float* __restrict__ beta, const double* __restrict__ dbeta,
+                                                       const double* __restrict__ dgamma, int relu, float* __restrict__ dy,
+                                                       float* __restrict__ dres, long long M, int C, float* __restrict__ dgamma_f,
+                                                       float* __restrict__ dbeta_f) {
     const int C4 = C >> 2;
     const size_t total = (size_t)M * C4;
     const float invM = 1.f / (float)M;
@@ -267,13 +285,17 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + cq * 4), is = *reinterpret_cast<const f32x4*>(invstd + cq * 4);
         const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + cq * 4);
         f32x4 dz = *reinterpret_cast<const f32x4*>(dout + i * 4);
-        if (relu) {
+        const f32x4 yy = *reinterpret_cast<const f32x4*>(y + i * 4);
+        if (relu && out) {
             const f32x4 o = *reinterpret_cast<const f32x4*>(out + i * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) dz[e] = o[e] > 0.f ? dz[e] : 0.f;
+        } else if (relu) {                                        // no saved `out`: the same affine as the forward pass
+            const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + cq * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dz[e] = bn_affine(yy[e], mu[e], is[e], g[e], bt[e]) > 0.f ? dz[e] : 0.f;
         }
         if (dres) *reinterpret_cast<f32x4*>(dres + i * 4) = dz;
-        const f32x4 yy = *reinterpret_cast<const f32x4*>(y + i * 4);
         f32x4 r;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -529,10 +551,10 @@ extern "C" size_t ym_bn_train_bwd_workspace_bytes(int64_t M, int C) {
 }
 
 extern "C" int ym_bn_train_bwd(const float* dout, const float* out, const float* y, int64_t M, int C, const float* gamma,
-                               const float* save_mean, const float* save_invstd, int relu, float* dy, float* dres,
-                               float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, ym_stream_t s) {
-    YM_REQUIRE(dout && y && gamma && save_mean && save_invstd && dy && dgamma && dbeta && workspace && (out || !relu),
-               "bn_train_bwd: null pointer");
+                               const float* beta, const float* save_mean, const float* save_invstd, int relu, float* dy,
+                               float* dres, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, ym_stream_t s) {
+    YM_REQUIRE(dout && y && gamma && save_mean && save_invstd && dy && dgamma && dbeta && workspace && (out || !relu || beta),
+               "bn_train_bwd: null pointer (relu needs `out`, or `beta` to re-derive the mask from y)");
     YM_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_train_bwd: C %% 4 != 0");
     if (workspace_bytes < (size_t)C * 16) { ym_set_error("bn_train_bwd: workspace < %d B", C * 16); return YM_ENOSPC; }
     hipStream_t st = (hipStream_t)s;
@@ -545,16 +567,16 @@ extern "C" int ym_bn_train_bwd(const float* dout, const float* out, const float*
     if (workspace_bytes >= (size_t)C * 16 + (size_t)big * 2 * C * 8) {           // two-stage: partials, then an ordered sum
         double* part = dg + C;
         hipLaunchKernelGGL(k_col_reduce<1>, dim3(big), dim3(256), 0, st, dout, out, y, save_mean, save_invstd, (long long)M, C,
-                           relu, 0, db, dg, part);
+                           relu, 0, db, dg, part, gamma, beta);
         hipLaunchKernelGGL(k_col_finish, dim3(ym_cdiv(C, 16)), dim3(256), 0, st, part, big, C, db, dg);
     } else {
         if (grid > 512) grid = 512;
         (void)hipMemsetAsync(db, 0, (size_t)C * 16, st);
         hipLaunchKernelGGL(k_col_reduce<1>, dim3(grid), dim3(256), 0, st, dout, out, y, save_mean, save_invstd, (long long)M, C,
-                           relu, 0, db, dg);
+                           relu, 0, db, dg, (double*)nullptr, gamma, beta);
     }
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid((size_t)M * (C / 4))), dim3(256), 0, st, dout, out, y, save_mean,
-                       save_invstd, gamma, db, dg, relu, dy, dres, (long long)M, C, dgamma, dbeta);
+                       save_invstd, gamma, beta, db, dg, relu, dy, dres, (long long)M, C, dgamma, dbeta);
     return ym_check_launch("bn_train_bwd");
 }
 

@@ -174,7 +174,7 @@ def lib():
         L.ym_bn_train_fwd_stats.argtypes = [vp, i64, i32, vp, vp, f32, f32, vp, vp, vp, i32, vp, vp, vp, vp, vp]
         L.ym_bn_train_bwd_workspace_bytes.argtypes = [i64, i32]
         L.ym_bn_train_bwd_workspace_bytes.restype = sz
-        L.ym_bn_train_bwd.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, sz, vp]
+        L.ym_bn_train_bwd.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, sz, vp]
         L.ym_act_bias_bwd.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp, sz, vp]
         L.ym_maxpool3x3s2_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
         L.ym_bilinear2x_bwd.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]

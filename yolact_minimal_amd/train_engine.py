@@ -448,7 +448,8 @@ class ConvBn(torch.autograd.Function):
                                                 hip.ptr(running_mean), hip.ptr(running_var), res_ptr, int(relu),
                                                 hip.ptr(out), hip.ptr(mean), hip.ptr(invstd), ctypes.c_void_p(stats.data_ptr()),
                                                 stats.numel() * 8, hip.stream_ptr()), 'ym_bn_train_fwd')
-        ctx.save_for_backward(x, weight, gamma, y, out if relu else None, mean, invstd)
+        # `out` is only needed for the ReLU mask when a residual was added; otherwise backward re-derives the mask from y
+        ctx.save_for_backward(x, weight, gamma, y, out if (relu and (residual is not None or beta is None)) else None, mean, invstd)
         ctx.meta = (stride, pad, relu, residual is not None)
         ctx.beta_param = beta
         return out
@@ -465,8 +466,10 @@ class ConvBn(torch.autograd.Function):
         dgamma = _grad_slot(gamma, (cout,))
         dbeta = _grad_slot(ctx.beta_param, (cout,)) if ctx.beta_param is not None else torch.empty(cout, device=y.device)
         ws = scratch(y.device, hip.lib().ym_bn_train_bwd_workspace_bytes(m, cout))
-        hip.check(hip.lib().ym_bn_train_bwd(hip.ptr(dout), hip.ptr(out) if relu else None, hip.ptr(y), m, cout,
-                                            hip.ptr(gamma.detach()), hip.ptr(mean), hip.ptr(invstd), int(relu), hip.ptr(dy),
+        hip.check(hip.lib().ym_bn_train_bwd(hip.ptr(dout), hip.ptr(out) if (relu and out is not None) else None, hip.ptr(y), m, cout,
+                                            hip.ptr(gamma.detach()),
+                                            hip.ptr(ctx.beta_param.detach()) if ctx.beta_param is not None else None, hip.ptr(mean),
+                                            hip.ptr(invstd), int(relu), hip.ptr(dy),
                                             hip.ptr(dres) if has_res else None, hip.ptr(dgamma), hip.ptr(dbeta),
                                             ctypes.c_void_p(ws.data_ptr()), ws.numel(), hip.stream_ptr()), 'ym_bn_train_bwd')
         need_dx = ctx.needs_input_grad[0]
