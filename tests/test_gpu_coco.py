@@ -1,5 +1,6 @@
 """GPU parity of the COCO reader's annotation -> mask step: `ym_poly_to_mask` / `ym_runs_to_mask` behind
 `COCO.annToMask` / `COCODetection`, bit-exact against the oracle's restatement of pycocotools (oracle/coco_ref.py)."""
+import ctypes
 import types
 
 import numpy as np
@@ -112,3 +113,14 @@ def test_dataset_modes_end_to_end(tmp_path):
     det = K.COCODetection(cfg, 'detect', device=DEV)
     img, origin, name = K.detect_collate([det[2]])
     assert tuple(img.shape) == (1, 3, 64, 64) and origin.dtype == np.uint8 and name == '000002.jpg'
+
+
+def test_empty_and_rejected_inputs():
+    from yolact_minimal_amd import hip
+    from yolact_minimal_amd.utils.coco import anns_to_masks
+    assert tuple(anns_to_masks([], 10, 12, DEV).shape) == (0, 10, 12)
+    with pytest.raises(RuntimeError, match='W <= 4096'):
+        anns_to_masks([[[0, 0, 5, 0, 5, 5]]], 4, 5000, DEV)
+    out = torch.empty(1, 8, 8, dtype=torch.uint8, device=DEV)
+    rc = hip.lib().ym_poly_to_mask(None, None, None, 1, 8, 8, ctypes.c_void_p(out.data_ptr()), None, 0, hip.stream_ptr())
+    assert rc != 0 and b'null pointer' in hip.lib().ym_last_error()
