@@ -180,21 +180,32 @@ __device__ int block_topk_sorted(KeyAt key_at, int L, int R, TopkShared<CAP>& sh
         cnt = R;
     }
     __syncthreads();
-    for (int k = 2; k <= CAP; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < CAP; i += nt) {
-                const int x = i ^ j;
-                if (x > i) {
-                    const uint32_t ka = sh.keys[i], kb = sh.keys[x];
-                    const int ia = sh.idx[i], ib = sh.idx[x];
-                    const bool a_first = ka > kb || (ka == kb && ia < ib);
-                    const bool want_a_first = (i & k) == 0;
-                    if (a_first != want_a_first) { sh.keys[i] = kb; sh.keys[x] = ka; sh.idx[i] = ib; sh.idx[x] = ia; }
-                }
-            }
-            __syncthreads();
+    // Sort the CAP slots (key descending, index ascending; empty slots = key 0 last) by counting: NT / CAP threads share one
+    // element, each ranks it against a slice of the list (broadcast LDS reads), the slice counts meet in LDS, one scatter.
+    // Two barriers instead of the 28-36 of a bitonic network (a barrier of a 1024-thread workgroup costs ~1 us).
+    static_assert(NT % CAP == 0, "NT must be a multiple of CAP");
+    constexpr int SL = NT / CAP, SPAN = CAP / SL;
+    const int e = tid % CAP, sl = tid / CAP;
+    const uint32_t ka = sh.keys[e];
+    const int ia = sh.idx[e];
+    int before = 0;
+    if (tid < NT) {
+        for (int x = sl * SPAN; x < (sl + 1) * SPAN; ++x) {
+            const uint32_t kb = sh.keys[x];
+            const int ib = sh.idx[x];
+            before += (kb > ka || (kb == ka && (ib < ia || (ib == ia && x < e)))) ? 1 : 0;
         }
     }
+    if (tid < CAP) sh.hist[tid] = 0u;                           // hist (256 >= CAP entries) is free now: rank accumulators
+    __syncthreads();
+    atomicAdd(&sh.hist[e], (uint32_t)before);
+    __syncthreads();
+    if (sl == 0) {
+        const int r = (int)sh.hist[e];
+        sh.keys[r] = ka;
+        sh.idx[r] = ia;
+    }
+    __syncthreads();
     return cnt;
 }
 
