@@ -36,6 +36,16 @@ if steps:
     for lim in (5, 20, 100, 1000):
         part = sum(g for g in gs if 0 < g <= lim * 1000)
         print(f'  gaps <= {lim:4d} us: {part / steps / 1e6:.3f} ms/step ({sum(1 for g in gs if 0 < g <= lim * 1000) / steps:.0f} per step)')
+if steps and top_n:
+    from collections import Counter
+    cnt, dur = Counter(), Counter()
+    for s0, e0, n0 in rows:
+        k = n0.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][:70]
+        cnt[k] += 1
+        dur[k] += e0 - s0
+    print('  per step (steady state): launches, ms')
+    for k, v in cnt.most_common(top_n):
+        print(f'    {v / steps:7.1f} {dur[k] / steps / 1e6:8.3f}  {k}')
 for q in (0.1, 0.5, 0.9, 0.99):
     print(f'  p{int(q * 100)} gap {gs[int(q * (len(gs) - 1))] / 1e3:.2f} us')
 print(f'  overlapping pairs (negative gap): {sum(1 for g in gs if g < 0)}')
