@@ -347,9 +347,11 @@ def test_mask_loss_kernel_matches_oracle_autograd():
     acc = torch.zeros(1, dtype=torch.float64, device=DEV)
     ws = torch.empty(hip.lib().ym_mask_loss_workspace_bytes(), dtype=torch.uint8, device=DEV)
     vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    # named tensors: a temporary freed right after hip.ptr() could be recycled by the allocator before the launch
+    proto_i, coef_i = proto[i].to(DEV), coef[i].to(DEV)[idx].contiguous()
+    box_i, gt_i = anchor_box[i].to(DEV)[idx].contiguous(), anchor_gt[i].to(DEV)[idx].to(torch.int32).contiguous()
     hip.check(hip.lib().ym_mask_loss_fwd_bwd(
-        hip.ptr(proto[i].to(DEV)), hip.ptr(coef[i].to(DEV)[idx].contiguous()), hip.ptr(anchor_box[i].to(DEV)[idx].contiguous()),
-        hip.ptr(anchor_gt[i].to(DEV)[idx].to(torch.int32).contiguous(), torch.int32), hip.ptr(ds), hip.ptr(idx, torch.int64),
+        hip.ptr(proto_i), hip.ptr(coef_i), hip.ptr(box_i), hip.ptr(gt_i, torch.int32), hip.ptr(ds), hip.ptr(idx, torch.int64),
         idx.shape[0], hp, hp, 1.0, float(coeff), vp(acc), hip.ptr(dproto), hip.ptr(dcoef), vp(ws), ws.numel(), hip.stream_ptr()),
         'ym_mask_loss_fwd_bwd')
     # the batch form visits the positives in a random order: fp32 summation order differs -> tolerance relative to the tensor
