@@ -260,7 +260,14 @@ class _PackCache:
             e['stamp'] = (owner._version, _EPOCH[0])
 
 
-_pack_cache = _PackCache()
+_pack_caches = {}          # one cache (and one device-side table) per device
+
+
+def _pack_cache_for(device):
+    c = _pack_caches.get(device)
+    if c is None:
+        c = _pack_caches[device] = _PackCache()
+    return c
 
 
 def _pack_fwd(weight, cin_pad, cout_pad):
@@ -268,7 +275,7 @@ def _pack_fwd(weight, cin_pad, cout_pad):
     k_pad = _ru(kh * kw * cin_pad, 32)
     if kh == 1 and kw == 1 and cin_pad == cin and cout_pad == cout and cin % 32 == 0 and weight.is_contiguous():
         return weight.detach().view(cout, cin), cin        # OIHW of a 1x1 conv IS the packed [Cout][K] image: no copy
-    cached = _pack_cache.get(weight, 0, cin_pad, k_pad, cout_pad)
+    cached = _pack_cache_for(weight.device).get(weight, 0, cin_pad, k_pad, cout_pad)
     if cached is not None:
         return cached.view(cout_pad, k_pad), k_pad
     if cout_pad == cout:
@@ -281,7 +288,7 @@ def _pack_fwd(weight, cin_pad, cout_pad):
 
 def _pack_dgrad(weight, cout_pad):
     cout, cin, kh, kw = weight.shape
-    cached = _pack_cache.get(weight, 1, cout_pad, 0, 0)
+    cached = _pack_cache_for(weight.device).get(weight, 1, cout_pad, 0, 0)
     if cached is not None:
         return cached
     wd = torch.empty(cin, kh * kw * cout_pad, device=weight.device, dtype=torch.float32)
