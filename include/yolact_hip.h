@@ -318,6 +318,10 @@ int ym_semantic_loss_batch(const float* seg_nhwc, int B, int P, int pitch, int n
                            double* loss_accum, ym_stream_t s);
 
 int ym_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, ym_stream_t s);
+/* The training pair that carries the argmax instead of re-deriving it: fwd_idx also writes idx [B][Ho][Wo][C] uint8 (window
+ * position 3*dy + dx of the winner under ATen's rule, 4-byte aligned), bwd_idx gathers dx from idx + dy alone (x is not read). */
+int ym_maxpool3x3s2_fwd_idx(const float* in, float* out, uint8_t* idx, int B, int H, int W, int C, ym_stream_t s);
+int ym_maxpool3x3s2_bwd_idx(const uint8_t* idx, const float* dy, float* dx, int B, int H, int W, int C, ym_stream_t s);
 int ym_bilinear2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, int align_corners, ym_stream_t s);
 
 /* torch.optim.SGD(momentum, weight_decay) on one flat fp32 buffer (reference train.py:61,130). */

@@ -120,6 +120,13 @@ def test_pool_and_upsample_backward():
     yg.backward(_nhwc(gy).to(DEV))
     assert torch.equal(_nchw(yg).cpu(), y.detach())
     torch.testing.assert_close(_nchw(xg.grad).cpu(), xc.grad, rtol=0, atol=0)
+    # the index-free entry point (re-scans the windows of x) routes the gradient identically
+    from yolact_minimal_amd import hip
+    dx2 = torch.empty_like(xg)
+    dyg = _nhwc(gy).to(DEV)
+    hip.check(hip.lib().ym_maxpool3x3s2_bwd(hip.ptr(xg.detach()), hip.ptr(dyg), hip.ptr(dx2), 2, 13, 14, 8, hip.stream_ptr()),
+              'ym_maxpool3x3s2_bwd')
+    assert torch.equal(dx2, xg.grad)
     for align in (False, True):
         x = torch.randn(2, 8, 9, 7, generator=g)
         xc = x.clone().requires_grad_()

@@ -53,8 +53,10 @@ __global__ void k_fold_bn(const float* gamma, const float* beta, const float* me
     }
 }
 
+// idx (optional, training): per output element the window position 3*dy + dx of the element that won under ATen's rule
+// (a later value replaces the running maximum if it is larger or NaN), which is what max_pool2d's backward routes the gradient to.
 __global__ void k_maxpool3x3s2(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C4,
-                               int Ho, int Wo) {
+                               int Ho, int Wo, uint8_t* __restrict__ idx = nullptr) {
     const size_t total = (size_t)B * Ho * Wo * C4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4);
@@ -63,6 +65,7 @@ __global__ void k_maxpool3x3s2(const float* __restrict__ in, float* __restrict__
         const int oh = (int)(t % Ho);
         const int b = (int)(t / Ho);
         f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        uint32_t arg = 0;                                         // four position bytes
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
             const int ih = oh * 2 - 1 + dy;
@@ -73,10 +76,15 @@ __global__ void k_maxpool3x3s2(const float* __restrict__ in, float* __restrict__
                 if ((unsigned)iw >= (unsigned)W) continue;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(in + (((size_t)b * H + ih) * W + iw) * C4 * 4 + c * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) m[e] = (v[e] > m[e] || v[e] != v[e]) ? v[e] : m[e];
+                for (int e = 0; e < 4; ++e) {
+                    const bool take = v[e] > m[e] || v[e] != v[e];
+                    m[e] = take ? v[e] : m[e];
+                    if (take) arg = (arg & ~(0xFFu << (8 * e))) | ((uint32_t)(dy * 3 + dx) << (8 * e));
+                }
             }
         }
         *reinterpret_cast<f32x4*>(out + i * 4) = m;
+        if (idx) reinterpret_cast<uint32_t*>(idx)[i] = arg;
     }
 }
 
@@ -192,11 +200,21 @@ extern "C" int ym_fold_bn(const float* gamma, const float* beta, const float* me
     return ym_check_launch("fold_bn");
 }
 
+extern "C" int ym_maxpool3x3s2_fwd_idx(const float* in, float* out, uint8_t* idx, int B, int H, int W, int C, ym_stream_t s) {
+    YM_REQUIRE(in && out && idx && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "maxpool: bad args (C %% 4 != 0?)");
+    YM_REQUIRE(((uintptr_t)idx & 3) == 0, "maxpool: idx must be 4-byte aligned");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const size_t total = (size_t)B * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(k_maxpool3x3s2, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, in, out, B, H, W, C / 4, Ho, Wo, idx);
+    return ym_check_launch("maxpool3x3s2");
+}
+
 extern "C" int ym_maxpool3x3s2_fwd(const float* in, float* out, int B, int H, int W, int C, ym_stream_t s) {
     YM_REQUIRE(in && out && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "maxpool: bad args (C %% 4 != 0?)");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const size_t total = (size_t)B * Ho * Wo * (C / 4);
-    hipLaunchKernelGGL(k_maxpool3x3s2, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, in, out, B, H, W, C / 4, Ho, Wo);
+    hipLaunchKernelGGL(k_maxpool3x3s2, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, in, out, B, H, W, C / 4, Ho, Wo,
+                       (uint8_t*)nullptr);
     return ym_check_launch("maxpool3x3s2");
 }
 

@@ -367,6 +367,32 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ x
     }
 }
 
+// The same gather with the argmax positions saved by the forward (ym_maxpool3x3s2_fwd_idx): per input pixel at most 4 index
+// words and 4 gradient vectors instead of re-scanning up to 4 windows of 9 (32 vector loads).
+__global__ __launch_bounds__(256) void k_maxpool_bwd_idx(const uint8_t* __restrict__ idx, const float* __restrict__ dy,
+                                                          float* __restrict__ dx, int B, int H, int W, int C4, int Ho, int Wo) {
+    const size_t total = (size_t)B * H * W * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        size_t t = i / C4;
+        const int iw = (int)(t % W); t /= W;
+        const int ih = (int)(t % H);
+        const int b = (int)(t / H);
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        for (int oh = ih / 2; oh <= (ih + 1) / 2 && oh < Ho; ++oh) {
+            for (int ow = iw / 2; ow <= (iw + 1) / 2 && ow < Wo; ++ow) {
+                const uint32_t me = (uint32_t)((ih - (oh * 2 - 1)) * 3 + (iw - (ow * 2 - 1)));
+                const size_t o = (((size_t)b * Ho + oh) * Wo + ow) * C4 + c;
+                const uint32_t a = reinterpret_cast<const uint32_t*>(idx)[o];
+                const f32x4 d = *reinterpret_cast<const f32x4*>(dy + o * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] += ((a >> (8 * e)) & 0xFFu) == me ? d[e] : 0.f;
+            }
+        }
+        *reinterpret_cast<f32x4*>(dx + i * 4) = g;
+    }
+}
+
 __device__ __forceinline__ void bil_src(int dst, int in_sz, int out_sz, int align, int& i0, int& i1, float& l1) {
     float src;
     if (align) {
@@ -608,6 +634,14 @@ extern "C" int ym_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, i
     hipLaunchKernelGGL(k_maxpool_bwd, dim3(ew_grid((size_t)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)s, x, dy, dx, B, H,
                        W, C / 4, Ho, Wo);
     return ym_check_launch("maxpool_bwd");
+}
+
+extern "C" int ym_maxpool3x3s2_bwd_idx(const uint8_t* idx, const float* dy, float* dx, int B, int H, int W, int C, ym_stream_t s) {
+    YM_REQUIRE(idx && dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "maxpool_bwd_idx: bad args");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(k_maxpool_bwd_idx, dim3(ew_grid((size_t)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)s, idx, dy, dx, B,
+                       H, W, C / 4, Ho, Wo);
+    return ym_check_launch("maxpool_bwd_idx");
 }
 
 extern "C" int ym_bilinear2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, int align_corners, ym_stream_t s) {

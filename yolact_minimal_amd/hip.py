@@ -30,7 +30,7 @@ ABI_SYMBOLS = (
     'ym_swin_window_attention_bwd', 'ym_adamw_step',
     'ym_match_anchors', 'ym_match_anchors_batch', 'ym_loss_workspace_bytes', 'ym_class_box_loss', 'ym_semantic_loss',
     'ym_semantic_loss_batch',
-    'ym_bn_train_bwd_workspace_bytes', 'ym_bn_train_bwd', 'ym_act_bias_bwd', 'ym_conv2d_fuses_bn_stats', 'ym_bn_train_fwd_stats', 'ym_maxpool3x3s2_bwd', 'ym_bilinear2x_bwd', 'ym_sgd_step',
+    'ym_bn_train_bwd_workspace_bytes', 'ym_bn_train_bwd', 'ym_act_bias_bwd', 'ym_conv2d_fuses_bn_stats', 'ym_bn_train_fwd_stats', 'ym_maxpool3x3s2_bwd', 'ym_maxpool3x3s2_fwd_idx', 'ym_maxpool3x3s2_bwd_idx', 'ym_bilinear2x_bwd', 'ym_sgd_step',
 )
 
 
@@ -177,6 +177,8 @@ def lib():
         L.ym_bn_train_bwd.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, sz, vp]
         L.ym_act_bias_bwd.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp, sz, vp]
         L.ym_maxpool3x3s2_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
+        L.ym_maxpool3x3s2_fwd_idx.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
+        L.ym_maxpool3x3s2_bwd_idx.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
         L.ym_bilinear2x_bwd.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
         L.ym_sgd_step.argtypes = [vp, vp, vp, i64, f32, f32, f32, i32, vp]
         for name in ABI_SYMBOLS:

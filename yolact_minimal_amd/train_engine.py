@@ -494,21 +494,28 @@ class ConvBn(torch.autograd.Function):
 
 
 class MaxPool(torch.autograd.Function):
+    """MaxPool2d(3, 2, 1) (modules/resnet.py:91).  The forward keeps the argmax position of every window (one byte per output
+    element) so that backward is a gather from it instead of re-scanning the windows of x."""
+
     @staticmethod
     def forward(ctx, x):
         b, h, w, c = x.shape
-        out = torch.empty(b, (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1, c, device=x.device, dtype=torch.float32)
-        hip.maxpool3x3s2(x, out)
-        ctx.save_for_backward(x)
+        ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+        out = torch.empty(b, ho, wo, c, device=x.device, dtype=torch.float32)
+        idx = torch.empty(b, ho, wo, c, device=x.device, dtype=torch.uint8)
+        hip.check(hip.lib().ym_maxpool3x3s2_fwd_idx(hip.ptr(x.contiguous()), hip.ptr(out), hip.ptr(idx, torch.uint8), b, h, w, c,
+                                                     hip.stream_ptr()), 'ym_maxpool3x3s2_fwd_idx')
+        ctx.save_for_backward(idx)
+        ctx.shape = (b, h, w, c)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
-        b, h, w, c = x.shape
-        dx = torch.empty_like(x)
-        hip.check(hip.lib().ym_maxpool3x3s2_bwd(hip.ptr(x), hip.ptr(dy.contiguous()), hip.ptr(dx), b, h, w, c, hip.stream_ptr()),
-                  'ym_maxpool3x3s2_bwd')
+        (idx,) = ctx.saved_tensors
+        b, h, w, c = ctx.shape
+        dx = torch.empty(b, h, w, c, device=dy.device, dtype=torch.float32)
+        hip.check(hip.lib().ym_maxpool3x3s2_bwd_idx(hip.ptr(idx, torch.uint8), hip.ptr(dy.contiguous()), hip.ptr(dx), b, h, w, c,
+                                                     hip.stream_ptr()), 'ym_maxpool3x3s2_bwd_idx')
         return dx
 
 
