@@ -201,7 +201,8 @@ int ym_pack_conv_weight_dgrad(const float* w_oihw, float* w_packed, int Cout, in
  * stale at once).  items_dev: DEVICE array, one entry per destination image, ordered by first_chunk:
  *   kind 0: ym_pack_conv_weight   into dst [rows][pad_b]          (pad_a = cin_pad, pad_b = k_pad, rows >= cout zero padded)
  *   kind 1: ym_pack_conv_weight_dgrad into dst [cin][kh][kw][pad_a] (pad_a = cout_pad)
- * first_chunk = running sum of ceil(dst elements / 1024) over the preceding items; total_chunks = the sum over all items. */
+ * Chunks of an item: kind 0: ceil(rows * pad_b / 1024); kind 1: ceil(cin*kh*kw / 32) * (pad_a / 32) (32 x 32 transpose tiles).
+ * first_chunk = running sum of the chunks of the preceding items; total_chunks = the sum over all items. */
 typedef struct {
     const float* src;        /* OIHW weight */
     float* dst;

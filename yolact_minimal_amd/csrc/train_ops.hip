@@ -456,8 +456,8 @@ __global__ void k_pack_weight_dgrad(const float* __restrict__ w, float* __restri
 }
 
 // Every layer's weight packing (forward [Cout_pad][k_pad] and dgrad [Cin][KH][KW][cout_pad] images) in ONE launch after an
-// optimizer step: workgroup = one 1024-element chunk of one item's destination; the item is found by bisection over the
-// chunk prefix in the device-side table.
+// optimizer step: workgroup = one chunk of one item's destination (forward image: 1024 consecutive elements; dgrad image: a
+// 32 x 32 tile of the transpose); the item is found by bisection over the chunk prefix in the device-side table.
 __global__ __launch_bounds__(256) void k_pack_weights_batch(const ym_pack_item* __restrict__ items, int n_items) {
     int lo = 0, hi = n_items - 1;
     while (lo < hi) {                                            // last item whose first_chunk <= blockIdx.x
@@ -479,16 +479,24 @@ __global__ __launch_bounds__(256) void k_pack_weights_batch(const ym_pack_item* 
             if (n < it.cout && tap < KHW && c < it.cin) v = it.src[((size_t)n * it.cin + c) * KHW + tap];
             it.dst[i] = v;
         }
-    } else {                                                     // dgrad image: [Cin][KH][KW][cout_pad]
-        const size_t total = (size_t)it.cin * KHW * it.pad_a;
+    } else {                                                     // dgrad image: [Cin][KH][KW][cout_pad] = the transpose of
+        // src viewed as [cout][R], R = cin*KH*KW, zero padded to cout_pad columns: one 32 x 32 tile per workgroup through LDS,
+        // 128-byte rows on both sides (a chunk of this kind is a tile, not 1024 consecutive elements)
+        __shared__ float tile[32][33];
+        const int R = it.cin * KHW, tiles_co = it.pad_a >> 5;
+        const int local = (int)(blockIdx.x - it.first_chunk);
+        const int r0 = (local / tiles_co) << 5, co0 = (local % tiles_co) << 5;
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const size_t i = base + u * 256 + threadIdx.x;
-            if (i >= total) break;
-            const int co = (int)(i % it.pad_a);
-            const size_t t = i / it.pad_a;
-            const int tap = (int)(t % KHW), ci = (int)(t / KHW);
-            it.dst[i] = co < it.cout ? it.src[((size_t)co * it.cin + ci) * KHW + tap] : 0.f;
+        for (int k = 0; k < 4; ++k) {
+            const int co = co0 + ty + 8 * k, r = r0 + tx;
+            tile[ty + 8 * k][tx] = (co < it.cout && r < R) ? it.src[(size_t)co * R + r] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + ty + 8 * k;
+            if (r < R) it.dst[(size_t)r * it.pad_a + co0 + tx] = tile[tx][ty + 8 * k];
         }
     }
 }

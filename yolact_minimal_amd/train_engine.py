@@ -215,7 +215,8 @@ class _PackCache:
         n = rows * pad_b if kind == 0 else cin * kh * kw * pad_a
         e = dict(ref=weakref.ref(owner),
                  dst=torch.empty(n, device=weight.device, dtype=torch.float32), src=weight.data_ptr(), dims=(cout, cin, kh, kw),
-                 kind=kind, pad_a=pad_a, pad_b=pad_b, rows=rows, chunks=(n + 1023) // 1024, stamp=None)
+                 kind=kind, pad_a=pad_a, pad_b=pad_b, rows=rows, stamp=None,
+                 chunks=(n + 1023) // 1024 if kind == 0 else -(-(cin * kh * kw) // 32) * (pad_a // 32))
         self.entries[key] = e
         self.table = None                                   # rebuilt at the next refresh
         L = hip.lib()                                       # a new image is packed on its own
