@@ -246,7 +246,9 @@ int ym_bn_train_bwd(const float* dout, const float* out, const float* y, int64_t
                     float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, ym_stream_t s);
 
 /* Backward of a fused conv epilogue `y = act(conv + bias)`: dz = dy * act'(y) (dz may be NULL or == dy for
- * YM_ACT_NONE), dbias[C] = column sums of dz (optional).  workspace >= 8*C bytes when dbias != NULL. */
+ * YM_ACT_NONE), dbias[C] = column sums of dz (optional).  workspace >= 8*C bytes when dbias != NULL; with
+ * >= 16*C + min(1024, ceil(M/32..)) * 16*C bytes (ym_bn_train_bwd_workspace_bytes(M, C) always suffices) the sums use per-workgroup
+ * partials + an ordered finish instead of fp64 atomics. */
 int ym_act_bias_bwd(const float* dy, const float* y, int64_t M, int C, int act, float* dz, float* dbias, void* workspace,
                     size_t workspace_bytes, ym_stream_t s);
 

@@ -624,13 +624,22 @@ extern "C" int ym_act_bias_bwd(const float* dy, const float* y, int64_t M, int C
         YM_REQUIRE(workspace, "act_bias_bwd: workspace");
         if (workspace_bytes < (size_t)C * 8) { ym_set_error("act_bias_bwd: workspace < %d B", C * 8); return YM_ENOSPC; }
         double* acc = (double*)workspace;
-        (void)hipMemsetAsync(acc, 0, (size_t)C * 8, st);
         const int CQ = (C / 4) < 256 ? (C / 4) : 256, RL = 256 / CQ;
         int grid = (int)((M + (long long)RL * 32 - 1) / ((long long)RL * 32));
-        if (grid > 2048) grid = 2048;
         if (grid < 1) grid = 1;
-        hipLaunchKernelGGL(k_col_reduce<2>, dim3(grid), dim3(256), 0, st, dy, y, nullptr, nullptr, nullptr, (long long)M, C, 0,
-                           act, acc, nullptr);
+        const int big = grid > 1024 ? 1024 : grid;
+        if (workspace_bytes >= (size_t)C * 16 + (size_t)big * 2 * C * 8) {
+            // enough scratch for per-workgroup partials + an ordered finish (as in ym_bn_train_bwd): no contended fp64 atomics
+            double* part = acc + 2 * C;
+            hipLaunchKernelGGL(k_col_reduce<2>, dim3(big), dim3(256), 0, st, dy, y, nullptr, nullptr, nullptr, (long long)M, C, 0,
+                               act, acc, acc + C, part);
+            hipLaunchKernelGGL(k_col_finish, dim3(ym_cdiv(C, 16)), dim3(256), 0, st, part, big, C, acc, acc + C);
+        } else {
+            if (grid > 2048) grid = 2048;
+            (void)hipMemsetAsync(acc, 0, (size_t)C * 8, st);
+            hipLaunchKernelGGL(k_col_reduce<2>, dim3(grid), dim3(256), 0, st, dy, y, nullptr, nullptr, nullptr, (long long)M, C, 0,
+                               act, acc, nullptr);
+        }
         hipLaunchKernelGGL(k_f64_to_f32, dim3(ym_cdiv(C, 256)), dim3(256), 0, st, acc, dbias, C);
     }
     return ym_check_launch("act_bias_bwd");

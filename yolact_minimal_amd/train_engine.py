@@ -409,7 +409,7 @@ class ConvBias(torch.autograd.Function):
         if has_bias:
             dbias = _grad_slot(bias_param, (c,)) if (bias_param is not None and cout_pad == weight.shape[0]) else \
                 torch.empty(c, device=dy.device, dtype=torch.float32)
-        ws = scratch(dy.device, c * 16)
+        ws = scratch(dy.device, hip.lib().ym_bn_train_bwd_workspace_bytes(m, c) if has_bias else c * 16)   # partial-sum path
         hip.check(hip.lib().ym_act_bias_bwd(hip.ptr(dy), hip.ptr(y) if y is not None else None, m, c, act,
                                             hip.ptr(dz) if act != ACT_NONE else None, hip.ptr(dbias), ctypes.c_void_p(ws.data_ptr()),
                                             ws.numel(), hip.stream_ptr()), 'ym_act_bias_bwd')
