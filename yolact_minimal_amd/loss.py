@@ -117,7 +117,10 @@ def lincomb_mask_loss(cfg, pos, anchor_gt, coef_p, proto_p, mask_gt, anchor_box,
     if num_pos is None:
         per = pos.sum(1)
         num_pos = torch.cat([per, per.sum(0, keepdim=True)]).to(torch.int32)
-    cap = min(int(cfg.masks_to_train), MAX_MASKS_PER_IMAGE, n)
+    if int(cfg.masks_to_train) > MAX_MASKS_PER_IMAGE:
+        raise RuntimeError(f'cfg.masks_to_train = {cfg.masks_to_train}: the mask-loss kernel holds at most {MAX_MASKS_PER_IMAGE} '
+                           f'positives per image (the reference default is 100)')
+    cap = min(int(cfg.masks_to_train), n)
     keys = torch.rand(b, n, device=dev).masked_fill_(~pos, -1.0)
     idx = keys.topk(cap, dim=1).indices.contiguous()          # the positives (random order) come first; the rest is never read
     ds_masks = []
