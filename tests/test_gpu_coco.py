@@ -124,3 +124,15 @@ def test_empty_and_rejected_inputs():
     out = torch.empty(1, 8, 8, dtype=torch.uint8, device=DEV)
     rc = hip.lib().ym_poly_to_mask(None, None, None, 1, 8, 8, ctypes.c_void_p(out.data_ptr()), None, 0, hip.stream_ptr())
     assert rc != 0 and b'null pointer' in hip.lib().ym_last_error()
+
+
+def test_frozen_vectors(golden_dir):
+    import json
+    import os
+    from yolact_minimal_amd.utils.coco import anns_to_masks
+    gold = json.load(open(os.path.join(golden_dir, 'coco_polys.json')))
+    for case in gold['cases']:
+        h, w = case['h'], case['w']
+        got = anns_to_masks(case['segmentations'], h, w, DEV).cpu().numpy()
+        for m, counts in zip(got, case['counts']):
+            np.testing.assert_array_equal(m, R.rle_decode(counts, h, w))

@@ -153,3 +153,12 @@ def test_batch_loader_shards_like_distributed_sampler(n, world):
             assert got == list(ref) and len(bl) == -(-len(got) // 2)
             seen += got
         assert set(seen) == set(range(n))
+
+
+def test_oracle_matches_its_frozen_vectors(golden_dir):
+    import json
+    import os
+    gold = json.load(open(os.path.join(golden_dir, 'coco_polys.json')))
+    for case in gold['cases']:
+        for seg, counts in zip(case['segmentations'], case['counts']):
+            assert R.rle_counts(C.segm_to_mask(seg, case['h'], case['w'])) == counts
