@@ -34,8 +34,8 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--cfg', default='res101_coco')
     ap.add_argument('--batch', type=int, default=1, help='images per GPU per step')
     ap.add_argument('--img_size', type=int, default=544)
@@ -47,8 +47,6 @@ def parse():
     ap.add_argument('--train-batch', type=int, default=8, help='images per GPU per training step')
     ap.add_argument('--train-steps', type=int, default=6)
     ap.add_argument('--no-train', action='store_true', help='skip the DDP training measurement')
-    ap.add_argument('--pipeline', action='store_true', help='bs=1: serving order (post-processing of image i overlaps the forward of '
-                    'image i+1 on a second stream); measured 304 vs 311 img/s sequential on MI355X, so it is not the default')
     ap.add_argument('--local_rank', type=int, default=None)
     return ap.parse_args()
 
@@ -66,7 +64,7 @@ class Workload:
     """forward(batch) + per-image post-processing, everything resident on the device."""
 
     def __init__(self, net, cfg, batch, img_size, device, with_post=True, seed=0):
-        from oracle.yolact_ref import synth_head_outputs   # only its *input generator* is used here
+        from yolact_minimal_amd.utils.synthetic import synth_head_outputs
         self.net, self.cfg, self.batch, self.device = net, cfg, batch, device
         g = torch.Generator().manual_seed(seed)
         self.img = torch.randn(batch, 3, img_size, img_size, generator=g).to(device)
@@ -87,23 +85,6 @@ class Workload:
                 r = nms(cls, box, coef, proto, self.anchors, self.cfg)
                 after_nms(r[0], r[1], r[2], r[3], r[4], 480, 640, self.cfg)
 
-
-class PipelinedWorkload(Workload):
-    """bs=1 serving order (`yolact_minimal_amd.serving.ServingPipeline`): the forward of image i+1 is in flight on one stream
-    while nms + after_nms of image i run on another.  One step = one forward submitted + one image post-processed, so K steps
-    are K complete forward + nms + after_nms passes (the trailing forward also finishes inside the timed region)."""
-
-    def __init__(self, net, cfg, batch, img_size, device, **kw):
-        super().__init__(net, cfg, batch, img_size, device, **kw)
-        from yolact_minimal_amd.serving import ServingPipeline
-        assert batch == 1
-        self.pipe = ServingPipeline(net, cfg, img_size, device)
-
-    def step(self):
-        p = self.pipe
-        p.submit(self.img)
-        if p.submitted - p.collected == 2:
-            p.collect(480, 640, post_inputs=self.head)
 
 
 def timed(workload, steps, warmup, barrier):
@@ -160,11 +141,11 @@ def conv_roofline(engine, img, iters=5):
 def eval_metrics_bench(device, n=100, g=15, h=480, w=640, iters=20, cpu=True):
     """Next-row f2: `prep_metrics` (mask IoU 100 x 15 masks at 480x640 + box IoU + matching over 10 thresholds) per image.
     HBM roofline of the mask-IoU kernel: every mask is read once = (n + g) * h * w * 4 bytes."""
-    from oracle import metrics_ref as M                  # synthetic-input generator + the CPU baseline leg
+    from yolact_minimal_amd.utils.synthetic import synth_eval_case
     from yolact_minimal_amd.utils import common_utils as C
     from yolact_minimal_amd.utils.box_utils import mask_iou
     thres = [x / 100 for x in range(50, 100, 5)]
-    ids, scores, boxes, masks, gt, gt_masks, h, w = M.synth_eval_case(1, n, g, h, w, 10)
+    ids, scores, boxes, masks, gt, gt_masks, h, w = synth_eval_case(1, n, g, h, w, 10)
     d = [boxes.to(device), masks.to(device), gt.to(device), gt_masks.to(device)]
     a, b = d[1].reshape(n, -1), d[3].reshape(g, -1)
     for _ in range(3):
@@ -197,7 +178,7 @@ def eval_metrics_bench(device, n=100, g=15, h=480, w=640, iters=20, cpu=True):
     out.update(rle_encode_ms=round(t_rle * 1e3, 3), rle_gbs=round(2 * n * h * w * 4 / t_rle / 1e9, 1),
                rle_bytes_per_image=sum(len(r['counts']) for r in rles), dense_mask_bytes_per_image=n * h * w * 4)
     if cpu:
-        from oracle import rle_ref as R
+        from oracle import metrics_ref as M, rle_ref as R       # cpu_baseline leg only
         t0 = time.perf_counter()
         for _ in range(3):
             ref = M.new_ap_data(10, len(thres))
@@ -215,7 +196,7 @@ def train_aug_bench(device, iters=30, cpu=True):
     """Next-row f4: `train_aug` of one COCO-like sample (480x640 uint8 image, 6 instance masks) to the 544 train size.
     HBM view: the image + masks are read about once and [3 + k, 544, 544] floats are written."""
     import random
-    from oracle.make_golden_augment import synth_sample        # synthetic-input generator
+    from yolact_minimal_amd.utils.synthetic import synth_sample
     from yolact_minimal_amd.utils.augmentations import train_aug
     img, masks, boxes, labels = synth_sample(12, 480, 640, 6)
     g_img, g_masks = torch.from_numpy(img).to(device), torch.from_numpy(masks).to(device)
@@ -249,7 +230,7 @@ def train_aug_bench(device, iters=30, cpu=True):
 def ann_to_mask_bench(device, iters=30, cpu=True):
     """Next-row f4 (reader): the polygon annotations of one COCO-like image (480x640, 7 instances of 1-3 polygons) -> dense uint8
     masks (`COCO.annToMask` per annotation in the reference).  HBM view: n*H*W bytes written once; the bitmaps live in LDS."""
-    from oracle.coco_ref import synth_polygons, segm_to_mask    # synthetic-input generator + cpu leg
+    from yolact_minimal_amd.utils.synthetic import synth_polygons
     from yolact_minimal_amd.utils.coco import anns_to_masks
     h, w = 480, 640
     segs = synth_polygons(21, h, w, n=7)
@@ -264,9 +245,10 @@ def ann_to_mask_bench(device, iters=30, cpu=True):
     out = dict(workload='7 annotations (1-3 polygons each, 3-40 vertices) -> [7, 480, 640] uint8 masks, incl. the H2D of the vertices',
                ms_per_image=round(t * 1e3, 3), images_per_s=round(1.0 / t, 1))
     if cpu:
+        from oracle.coco_ref import segm_to_mask as _segm_to_mask      # cpu_baseline leg only
         t0 = time.perf_counter()
         for s in segs:
-            segm_to_mask(s, h, w)
+            _segm_to_mask(s, h, w)
         out['cpu_oracle_ms_per_image'] = round((time.perf_counter() - t0) * 1e3, 2)
     return out
 
@@ -274,7 +256,7 @@ def ann_to_mask_bench(device, iters=30, cpu=True):
 def train_bench(cfg_name, img_size, batch, steps, warmup, world, local_rank, device, barrier):
     """DDP training: one step = forward + loss + backward (+ RCCL gradient all-reduce overlapped by DDP hooks) +
     SGD step on `batch` synthetic images per GPU (targets: 4 boxes + rectangular masks per image)."""
-    from oracle.yolact_ref import synth_targets          # input generator only
+    from yolact_minimal_amd.utils.synthetic import synth_targets
     from yolact_minimal_amd.config import build_cfg
     from yolact_minimal_amd.modules.yolact import Yolact
     from yolact_minimal_amd.trainer import Trainer, reduce_max
@@ -308,35 +290,43 @@ def train_bench(cfg_name, img_size, batch, steps, warmup, world, local_rank, dev
                 last_losses=[round(float(l.detach()), 4) for l in losses], finite=all(bool(torch.isfinite(l)) for l in losses))
 
 
-def cpu_baseline(cfg_name, img_size):
-    """The CPU oracle (plain PyTorch-CPU restatement of the reference) timed on this host's cores, bounded sample."""
+def cpu_baseline(cfg_name, img_size, threads=None, budget_s=12.0, max_img=10):
+    """The CPU oracle (plain PyTorch-CPU restatement of the reference) timed on this host's cores, bounded sample.
+    `threads`: torch intra-op threads for the sample (None = torch's default = all host cores)."""
     from oracle import yolact_ref as R
     from yolact_minimal_amd.config import build_cfg
     from yolact_minimal_amd.modules.yolact import Yolact
-    cfg = build_cfg(cfg_name, 'val', img_size)
-    torch.manual_seed(0)
-    sd = Yolact(cfg).eval().state_dict()
-    img = torch.randn(1, 3, img_size, img_size, generator=torch.Generator().manual_seed(0))
-    n_anchors = sum(((img_size + s - 1) // s) ** 2 * 3 for s in (8, 16, 32, 64, 128))
-    cls, box, coef, proto = R.synth_head_outputs(n_anchors, proto_hw=img_size // 4, seed=1)
-    anchors = R.anchors_for(img_size, cfg.scales)
-    n_img, t_fwd, t_nms, t_after, best = 0, 0.0, 0.0, 0.0, 1e30
-    t_start = time.perf_counter()
-    with torch.no_grad():
-        R.forward_eval(img, sd)                       # warm-up
-        while n_img < 3 or (time.perf_counter() - t_start < 12 and n_img < 10):
-            t0 = time.perf_counter(); R.forward_eval(img, sd); t1 = time.perf_counter()
-            r = R.nms(cls, box, coef, proto, anchors); t2 = time.perf_counter()
-            R.after_nms(r[0], r[1], r[2], r[3], r[4], 480, 640); t3 = time.perf_counter()
-            t_fwd += t1 - t0; t_nms += t2 - t1; t_after += t3 - t2
-            best = min(best, t3 - t0)
-            n_img += 1
+    prev = torch.get_num_threads()
+    if threads:
+        torch.set_num_threads(threads)
+    try:
+        cfg = build_cfg(cfg_name, 'val', img_size)
+        torch.manual_seed(0)
+        sd = Yolact(cfg).eval().state_dict()
+        img = torch.randn(1, 3, img_size, img_size, generator=torch.Generator().manual_seed(0))
+        n_anchors = sum(((img_size + s - 1) // s) ** 2 * 3 for s in (8, 16, 32, 64, 128))
+        cls, box, coef, proto = R.synth_head_outputs(n_anchors, proto_hw=img_size // 4, seed=1)
+        anchors = R.anchors_for(img_size, cfg.scales)
+        n_img, t_fwd, t_nms, t_after, best = 0, 0.0, 0.0, 0.0, 1e30
+        t_start = time.perf_counter()
+        with torch.no_grad():
+            R.forward_eval_any(img, sd)                   # warm-up
+            while n_img < 3 or (time.perf_counter() - t_start < budget_s and n_img < max_img):
+                t0 = time.perf_counter(); R.forward_eval_any(img, sd); t1 = time.perf_counter()
+                r = R.nms(cls, box, coef, proto, anchors); t2 = time.perf_counter()
+                R.after_nms(r[0], r[1], r[2], r[3], r[4], 480, 640); t3 = time.perf_counter()
+                t_fwd += t1 - t0; t_nms += t2 - t1; t_after += t3 - t2
+                best = min(best, t3 - t0)
+                n_img += 1
+        nthr = torch.get_num_threads()
+    finally:
+        torch.set_num_threads(prev)
     # the host of a GPU box is shared and noisy (3x swings between runs were observed): the fastest image of the sample is the
     # baseline, the means are kept in the sample text
-    return dict(value=round(1.0 / best, 3), unit='img/s', cores=torch.get_num_threads(), kind='port',
+    return dict(value=round(1.0 / best, 3), unit='img/s', cores=nthr, kind='port',
                 sample=f'best of {n_img} images bs=1 {cfg_name}@{img_size} ({best * 1e3:.0f} ms); means: oracle forward {t_fwd / n_img * 1e3:.0f} ms + nms '
                        f'{t_nms / n_img * 1e3:.0f} ms + after_nms(480x640) {t_after / n_img * 1e3:.0f} ms on '
-                       f'{os.cpu_count()} host cpus ({torch.get_num_threads()} torch threads)')
+                       f'{os.cpu_count()} host cpus ({nthr} torch threads)')
 
 
 def main():
@@ -360,8 +350,7 @@ def main():
             dist.barrier()
 
     net, cfg = build_net(args.cfg, args.img_size, device)
-    pipelined = args.batch == 1 and not args.no_post and args.pipeline
-    wl = (PipelinedWorkload if pipelined else Workload)(net, cfg, args.batch, args.img_size, device, with_post=not args.no_post)
+    wl = Workload(net, cfg, args.batch, args.img_size, device, with_post=not args.no_post)
     elapsed = timed(wl, args.steps, args.warmup, barrier)
     if dist is not None:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -395,11 +384,7 @@ def main():
                         kernel='conv_igemm_f32 (all instantiations)', launches_per_step=launches,
                         flops_per_launch=round(flops / launches), avg_launch_us=round(conv_secs / launches * 1e6, 2),
                         conv_ms_per_step=round(conv_secs * 1e3, 3))
-        seq = None
-        if pipelined:                                 # the reference's strictly sequential per-image order, for comparison
-            sq = Workload(net, cfg, args.batch, args.img_size, device, with_post=True)
-            seq = args.batch * args.steps / timed(sq, args.steps, 2, lambda: None)
-        extra = dict(sequential_img_s=round(seq, 2) if seq else None, forward_only_ms=round(t_fwd * 1e3, 3),
+        extra = dict(forward_only_ms=round(t_fwd * 1e3, 3),
                      forward_only_img_s=round(args.batch / t_fwd, 1),
                      forward_tflops=round(flops / t_fwd / 1e12, 2),
                      gflop_per_img=round(flops / args.batch / 1e9, 1))
@@ -430,6 +415,11 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.cfg, args.img_size)
+            # the same sample on 8 threads (comparable with the survey's 8-vCPU probes) and BASELINE.json config 1
+            # (res50_coco bs=1 on the CPU path); bounded to a few seconds each
+            cpu['threads8'] = cpu_baseline(args.cfg, args.img_size, threads=8, budget_s=5.0, max_img=4)
+            cpu['res50_coco'] = cpu_baseline('res50_coco', args.img_size, budget_s=5.0, max_img=4)
+            cpu['res50_coco_threads8'] = cpu_baseline('res50_coco', args.img_size, threads=8, budget_s=5.0, max_img=4)
         extra['train'] = train
         primary_train = args.mode == 'train' and train is not None
         out = {
@@ -442,8 +432,7 @@ def main():
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'{args.cfg} 544x544 (the reference\'s "550-class" size) bs={args.batch} inference: '
                                    f'forward + nms + after_nms(480x640) per image'
-                                   + (', serving order: post-processing of image i overlaps the forward of image i+1 (2 streams)'
-                                      if pipelined else '') if not args.no_post else
+                                   if not args.no_post else
                                    f'{args.cfg} 544x544 bs={args.batch} forward only',
                        'global_batch': args.batch * world, 'parallelism': f'replicas x{world} (inference does not shard)',
                        'weights': 'seeded random init', 'post_inputs': 'synthetic dense head outputs (17.8k candidates)'},

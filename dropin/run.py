@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Launcher: run one of the reference's scripts, unmodified, on the MI355X path.
+
+    cd /path/to/Yolact_minimal
+    python /path/to/repo/dropin/run.py eval.py --weight weights/best_30.5_res101_coco_392000.pth
+    python -m torch.distributed.run --nproc-per-node 8 /path/to/repo/dropin/run.py train.py --train_bs 64
+
+Python puts the SCRIPT's directory first on the module path, so a checkout's own `modules/`, `utils/`, `config.py` would win
+over PYTHONPATH.  This launcher orders the path as [dropin, repo, checkout, ...] and then executes the script as `__main__`
+(with `sys.argv` shifted), so `from modules.yolact import Yolact`, `from utils.output_utils import nms, after_nms`,
+`from config import get_config` resolve to yolact_minimal_amd while everything else still comes from the checkout."""
+import os
+import runpy
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+
+
+def main():
+    if len(sys.argv) < 2:
+        raise SystemExit(__doc__)
+    script = os.path.abspath(sys.argv[1])
+    checkout = os.path.dirname(script)
+    rest = [p for p in sys.path if os.path.abspath(p or os.getcwd()) not in (HERE, REPO, checkout)]
+    sys.path[:] = [HERE, REPO, checkout] + rest
+    sys.argv = [script] + sys.argv[2:]
+    runpy.run_path(script, run_name='__main__')
+
+
+if __name__ == '__main__':
+    main()

@@ -400,6 +400,11 @@ int ym_detect_greedy_nms(const float* class_pred, const float* box_pred, const f
                          float* out_scores, float* out_boxes, float* out_coefs, void* workspace,
                          size_t workspace_bytes, ym_stream_t s);
 
+/* y[i] = exp(x[i]) rounded to nearest float — the exp of the box decode (utils/output_utils.py:150, `torch.exp`), exposed so
+ * that the parity suite can compare it with oracle/expf_cr.c on arbitrary inputs (bit-identical by construction: same IEEE
+ * double operation sequence).  The reference's own torch.exp is MKL VML (1 ulp off this value in 1.1 % of inputs). */
+int ym_expf_cr(const float* x, float* y, int64_t n, ym_stream_t s);
+
 /* Drop-in for `cython_nms.nms(dets, thresh)` (cython_nms.pyx:24) on device data: dets [n][5]
  * (x1,y1,x2,y2,score), "+1" areas, suppress ovr >= thresh; keep_mask uint8[n] (1 = kept), in original
  * index order like np.where(suppressed == 0).  workspace >= ym_greedy_nms_workspace_bytes(n). */

@@ -105,26 +105,7 @@ def segm_to_mask(segm, h, w):
     return rle_decode(list(counts), h, w).astype(np.uint8)
 
 
-def synth_polygons(seed, h, w, n=6):
-    """Random annotations for the tests / bench: per annotation 1-3 polygons (star-shaped, 3-40 vertices, fractional
-    coordinates, some reaching outside the image), like COCO's 'segmentation' lists."""
-    rng = np.random.default_rng(seed)
-    anns = []
-    for _ in range(n):
-        polys = []
-        for _ in range(int(rng.integers(1, 4))):
-            k = int(rng.integers(3, 41))
-            cx, cy = rng.uniform(0, w), rng.uniform(0, h)
-            rad = rng.uniform(0.5, max(2.0, 0.45 * min(h, w)))
-            ang = np.sort(rng.uniform(0, 2 * np.pi, k))
-            r = rad * rng.uniform(0.4, 1.0, k)
-            xs = np.round(cx + r * np.cos(ang), 2)
-            ys = np.round(cy + r * np.sin(ang), 2)
-            if rng.random() < 0.7:                      # COCO polygons are clipped to the image; keep some that are not
-                xs, ys = np.clip(xs, 0, w), np.clip(ys, 0, h)
-            polys.append(np.stack([xs, ys], 1).reshape(-1).tolist())
-        anns.append(polys)
-    return anns
+from yolact_minimal_amd.utils.synthetic import synth_polygons  # noqa: E402,F401  (input generator)
 
 
 def write_synth_dataset(root, n_images=6, seed=0, sizes=((48, 64), (60, 44), (37, 53))):

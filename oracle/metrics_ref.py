@@ -93,28 +93,4 @@ def calc_map(ap_data, iou_thres, num_classes):
     return out
 
 
-def synth_eval_case(seed, n=40, g=7, h=48, w=64, num_classes=6):
-    """Synthetic detections vs ground truth: rectangular gt masks, predictions = jittered copies (some duplicates, some
-    wrong-class, some empty masks) so that every branch of the matching is exercised.  Returns the prep_metrics arguments."""
-    rng = torch.Generator().manual_seed(seed)
-    gt_box = torch.zeros(g, 5)
-    gt_masks = torch.zeros(g, h, w)
-    for j in range(g):
-        x1, y1 = torch.rand(2, generator=rng).mul(0.55).tolist()
-        bw, bh = (torch.rand(2, generator=rng) * 0.3 + 0.12).tolist()
-        gt_box[j] = torch.tensor([x1, y1, x1 + bw, y1 + bh, float(torch.randint(0, num_classes, (1,), generator=rng))])
-        gt_masks[j, int(y1 * h):int((y1 + bh) * h) + 1, int(x1 * w):int((x1 + bw) * w) + 1] = 1.0
-    ids, scores, boxes, masks = [], [], torch.zeros(n, 4, dtype=torch.int32), torch.zeros(n, h, w)
-    for i in range(n):
-        j = int(torch.randint(0, g, (1,), generator=rng))
-        jit = (torch.rand(4, generator=rng) - 0.5) * (0.02 + 0.3 * float(torch.rand(1, generator=rng)))
-        b = (gt_box[j, :4] + jit).clamp(0, 1)
-        x1, y1, x2, y2 = int(b[0] * w), int(b[1] * h), int(b[2] * w), int(b[3] * h)
-        boxes[i] = torch.tensor([x1, y1, x2, y2], dtype=torch.int32)
-        if i % 11 != 10:                                             # every 11th prediction has an empty mask
-            masks[i, y1:y2 + 1, x1:x2 + 1] = 1.0
-        cls = int(gt_box[j, 4]) if i % 5 else int(torch.randint(0, num_classes, (1,), generator=rng))
-        ids.append(cls)
-        scores.append(float(torch.rand(1, generator=rng)))
-    order = sorted(range(n), key=lambda k: -scores[k])             # after_nms returns detections by descending score
-    return ([ids[k] for k in order], [scores[k] for k in order], boxes[order], masks[order], gt_box, gt_masks, h, w)
+from yolact_minimal_amd.utils.synthetic import synth_eval_case  # noqa: E402,F401  (input generator)

@@ -153,10 +153,31 @@ def pairwise_iou(a, b):
     return inter / (area_a + area_b - inter)
 
 
-def decode(box_p, anchors):
-    """utils/output_utils.py:148-153 — centre-size decode to corners, clipped to [0,1]."""
+_expf_lib = None
+
+
+def expf_cr(x):
+    """exp(x) rounded to nearest float32 (oracle/expf_cr.c: IEEE double, fixed operation sequence, no libm)."""
+    global _expf_lib
+    if _expf_lib is None:
+        path = os.path.join(_HERE, 'libexpf_cr.so')
+        if not os.path.exists(path):
+            raise RuntimeError(f'{path} missing: run `make -C oracle`')
+        _expf_lib = ctypes.CDLL(path)
+        _expf_lib.oracle_expf_cr_array.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
+    x = x.detach().float().contiguous()
+    y = torch.empty_like(x)
+    _expf_lib.oracle_expf_cr_array(x.data_ptr(), y.data_ptr(), x.numel())
+    return y
+
+
+def decode(box_p, anchors, exp='torch'):
+    """utils/output_utils.py:148-153 — centre-size decode to corners, clipped to [0,1].
+    exp='torch': the reference's own call (MKL VML on this torch build: host-ISA dependent, 1 ulp off the correctly rounded
+    value in ~1.1 % of inputs).  exp='cr': the correctly rounded exp of oracle/expf_cr.c — the host-independent anchor the
+    HIP kernel is held to bit for bit."""
     cxcy = anchors[:, :2] + box_p[:, :2] * 0.1 * anchors[:, 2:]
-    wh = anchors[:, 2:] * torch.exp(box_p[:, 2:] * 0.2)
+    wh = anchors[:, 2:] * (expf_cr(box_p[:, 2:] * 0.2) if exp == 'cr' else torch.exp(box_p[:, 2:] * 0.2))
     x1y1 = cxcy - wh / 2
     x2y2 = wh + x1y1
     return torch.clip(torch.cat((x1y1, x2y2), 1), min=0., max=1.)
@@ -233,13 +254,13 @@ def traditional_nms(boxes, coefs, scores, img_size, score_thre=0.05, iou_thre=0.
 
 
 def nms(class_pred, box_pred, coef_pred, proto_out, anchors, score_thre=0.05, iou_thre=0.5, top_k=200,
-        max_det=100, traditional=False, img_size=544, stable=False):
+        max_det=100, traditional=False, img_size=544, stable=False, exp='torch'):
     """utils/output_utils.py:126-163 (batch of one). Returns (ids, scores, boxes, coefs, proto) or 5x None."""
     cls = class_pred.squeeze(0).transpose(1, 0).contiguous()[1:]       # [C-1, N], background dropped
     box_p, coef_p, proto = box_pred.squeeze(0), coef_pred.squeeze(0), proto_out.squeeze(0)
     keep = cls.max(dim=0)[0] > score_thre
     cls_k = cls[:, keep]
-    boxes = decode(box_p[keep], anchors[keep])
+    boxes = decode(box_p[keep], anchors[keep], exp)
     coefs = coef_p[keep]
     if cls_k.shape[1] == 0:
         return None, None, None, None, None
@@ -303,16 +324,7 @@ def after_nms(ids, scores, boxes, coefs, proto, img_h, img_w, visual_thre=0.0, d
 # ------------------------------------------------------------------------------------------------
 # synthetic inputs shared by goldens, tests and bench
 # ------------------------------------------------------------------------------------------------
-def synth_head_outputs(n_anchors, num_classes=81, proto_hw=136, seed=1, bg_bias=4.0, spread=2.5):
-    """softmax(randn*spread + bg_bias*e_bg), randn*0.5 boxes, tanh(randn) coefs, relu(randn) protos."""
-    g = torch.Generator().manual_seed(seed)
-    logits = torch.randn(1, n_anchors, num_classes, generator=g) * spread
-    logits[..., 0] += bg_bias
-    cls = F.softmax(logits, -1)
-    box = torch.randn(1, n_anchors, 4, generator=g) * 0.5
-    coef = torch.tanh(torch.randn(1, n_anchors, 32, generator=g))
-    proto = F.relu(torch.randn(1, proto_hw, proto_hw, 32, generator=g))
-    return cls, box, coef, proto
+from yolact_minimal_amd.utils.synthetic import synth_head_outputs, synth_targets  # noqa: E402,F401  (input generators)
 
 
 def randomize_bn_(sd, seed=7):
@@ -328,6 +340,18 @@ def randomize_bn_(sd, seed=7):
                 sd[k].copy_(torch.rand(sd[k].shape, generator=g) * 0.2 + 0.4)
             elif k.endswith('.bias'):
                 sd[k].copy_(torch.randn(sd[k].shape, generator=g) * 0.05)
+    return sd
+
+
+def damp_residual_branches_(sd, seed=13, scale=0.05):
+    """Every Bottleneck's last BatchNorm gets gamma in [scale/2, 3*scale/2] ("zero-init-residual" style): the blocks are close to
+    the identity, which makes a random-init net well enough conditioned in backward for a meaningful gradient comparison
+    (with gamma = 1 the reference's OWN CPU gradients differ by 2e-2 of max|g| between fp32 and fp64, and by 7e-3 between an
+    8-thread and a 1-thread fp32 run — DESIGN.md "Oracle and parity")."""
+    g = torch.Generator().manual_seed(seed)
+    for k in sorted(sd):
+        if k.endswith('bn3.weight'):
+            sd[k].copy_(torch.rand(sd[k].shape, generator=g) * scale + scale / 2)
     return sd
 
 
@@ -482,24 +506,6 @@ def compute_loss(class_p, box_p, coef_p, proto_p, seg_p, box_class, mask_gt, anc
     pos = conf > 0
     return (ohem_class_loss(class_p, conf, pos, stable=stable), box_reg_loss(box_p, offs, pos),
             mask_loss(pos, aidx, coef_p, proto_p, mask_gt, abox), semantic_loss(seg_p, mask_gt, cls_gt))
-
-
-def synth_targets(batch, img_size, n_gt=4, num_classes=80, seed=0):
-    """SURVEY.md §8d training inputs: n_gt boxes uniform in [0.1,0.9] with min side 0.1, rectangular float masks."""
-    boxes, masks = [], []
-    for i in range(batch):
-        g = torch.Generator().manual_seed(seed + i)
-        xy = torch.rand(n_gt, 2, generator=g) * 0.6 + 0.1
-        wh = torch.rand(n_gt, 2, generator=g) * 0.25 + 0.1
-        x2y2 = torch.clamp(xy + wh, max=0.9)
-        cls = torch.randint(0, num_classes, (n_gt, 1), generator=g).float()
-        boxes.append(torch.cat([xy, x2y2, cls], 1))
-        m = torch.zeros(n_gt, img_size, img_size)
-        for j in range(n_gt):
-            x1, y1, x2, y2 = (torch.cat([xy[j], x2y2[j]]) * img_size).round().long().tolist()
-            m[j, y1:y2, x1:x2] = 1.0
-        masks.append(m)
-    return boxes, masks
 
 
 # ------------------------------------------------------------------------------------------------

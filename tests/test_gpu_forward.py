@@ -68,6 +68,45 @@ def test_forward_544_digest(golden_dir, name):
         np.testing.assert_allclose(got, g[key], rtol=2e-4)
 
 
+def check_bs8_digest(g, out, tuned_hits):
+    """Shared by the ResNet and Swin bs=8 tests: per-image samples within 1e-4, per-image digests, images distinct."""
+    cls, box, coef, proto = out
+    assert cls.shape == (8, 18525, 81) and proto.shape == (8, 136, 136, 32)
+    _close(cls[:, ::97], g['class_sample'], 'class sample')
+    _close(box[:, ::97], g['box_sample'], 'box sample')
+    _close(coef[:, ::97], g['coef_sample'], 'coef sample')
+    _close(proto[:, ::9, ::9], g['proto_sample'], 'proto sample')
+    for t, key in ((cls, 'class_digest'), (box, 'box_digest'), (coef, 'coef_digest'), (proto, 'proto_digest')):
+        d = t.double().reshape(8, -1)
+        got = torch.stack([d.sum(1), d.abs().sum(1), (d * d).sum(1)], 1).cpu().numpy()
+        np.testing.assert_allclose(got[:, 1:], g[key][:, 1:], rtol=2e-4, err_msg=key)          # |sum| and sum of squares
+        np.testing.assert_allclose(got[:, 0], g[key][:, 0], rtol=2e-4, atol=1e-5 * float(g[key][:, 1].max()), err_msg=key)   # signed sum: cancels
+    assert tuned_hits > 0, 'the bs=8 plan did not pick anything from tuned_gfx950.json: this test must exercise the tuned kernels'
+
+
+@pytest.mark.parametrize('graph', ['0', '1'])
+@pytest.mark.parametrize('name', ['res50_coco', 'res101_coco'])
+def test_forward_544_bs8_digest_under_the_tuned_plan(golden_dir, name, graph, monkeypatch):
+    """BASELINE.json config 2 (res50 bs=8) and config 3's per-GPU forward shape (res101 bs=8) at 544 px, against the REAL
+    reference's outputs (oracle/make_golden_fullsize.py).  Runs the plan bench.py times: tuned_gfx950.json tiles / split-K /
+    tail splits / direct-to-LDS variants, per-level head launches, with and without hipGraph replay."""
+    monkeypatch.setenv('YM_GRAPH', graph)
+    g = np.load(os.path.join(golden_dir, f'forward_{name}_544_b8_digest.npz'))
+    seed = int(g['seed'])
+    net, cfg = make_net(name, 544, seed)
+    img = torch.randn(8, 3, 544, 544, generator=torch.Generator().manual_seed(seed + 300))
+    net = net.to(DEV)
+    with torch.no_grad():
+        out = net(img.to(DEV))
+        out2 = net(img.to(DEV))
+    for a, b in zip(out, out2):
+        assert torch.equal(a, b)
+    eng = net._engine(img.to(DEV))
+    from yolact_minimal_amd.engine import tuned_table
+    hits = sum(1 for c in eng.convs if c.sig in tuned_table())
+    check_bs8_digest(g, out, hits)
+
+
 def test_batch_equals_per_image():
     """bs=8-style batching: image i of a batch equals the bs=1 result."""
     net, cfg = make_net('res50_coco', 64, 77)
@@ -124,7 +163,7 @@ def test_other_class_counts_forward_post_and_loss(name):
     # post-processing on synthetic head outputs with this class count
     cls, box, coef, proto = R.synth_head_outputs(len(net.anchors) // 4, num_classes=nc, proto_hw=size // 4, seed=2, bg_bias=3.0)
     anchors = torch.tensor(net.anchors).reshape(-1, 4)
-    r = R.nms(cls, box, coef, proto, anchors, stable=True)
+    r = R.nms(cls, box, coef, proto, anchors, stable=True, exp='cr')
     g = nms(cls.to(DEV), box.to(DEV), coef.to(DEV), proto.to(DEV), net.anchors, cfg)
     assert torch.equal(g[0].cpu(), r[0]) and torch.equal(g[1].cpu(), r[1])
     ra = R.after_nms(r[0], r[1], r[2], r[3], r[4], 70, 90)

@@ -44,7 +44,7 @@ def test_eval_loop_end_to_end():
     # 2. post-processing on synthetic head outputs of the same shapes (random-init nets give degenerate detections)
     cls, box, coef, proto = R.synth_head_outputs(len(net.anchors) // 4, proto_hw=size // 4, seed=3, bg_bias=5.0)
     anchors = torch.tensor(net.anchors).reshape(-1, 4)
-    r_ids, r_sc, r_box, r_coef, r_proto = R.nms(cls, box, coef, proto, anchors, stable=True)
+    r_ids, r_sc, r_box, r_coef, r_proto = R.nms(cls, box, coef, proto, anchors, stable=True, exp='cr')
     ids, sc, bx, cf, pr = nms(cls.to(DEV), box.to(DEV), coef.to(DEV), proto.to(DEV), net.anchors, cfg)
     assert torch.equal(ids.cpu(), r_ids) and torch.equal(sc.cpu(), r_sc)
     r_ids2, r_sc2, r_boxes, r_masks = R.after_nms(r_ids, r_sc, r_box, r_coef, r_proto, img_h, img_w)

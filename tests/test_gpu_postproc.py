@@ -1,7 +1,13 @@
 """GPU parity of nms / fast-NMS / greedy NMS / mask assembly / after_nms against the CPU oracle and the
-reference's golden vectors.  Bar: ids, scores, coefs bit-exact; boxes bit-exact except for the libm
-dependent exp() in the decode (<= 1 ulp of the box size, atol 2e-7); binary masks may differ only where the
-interpolated value is within 1e-4 of the 0.5 threshold."""
+reference's golden vectors.  Bar: ids, scores, coefs, BOXES and pixel boxes bit-exact against the oracle; binary masks may
+differ only where the interpolated value is within 1e-4 of the 0.5 threshold.
+
+The one transcendental of the path, the decode's exp (utils/output_utils.py:150), is MKL VML inside the reference's torch
+build: closed source, host-ISA dependent, 1 ulp off the correctly rounded value in 1.1 % of inputs
+(oracle/make_golden_exp.py, tests/test_oracle_expf.py).  The oracle is therefore run with exp='cr' (exp rounded to nearest,
+oracle/expf_cr.c), which the kernel matches on every bit; against the reference's frozen outputs the boxes may differ by
+that one ulp of exp in a few coordinates (asserted: >= 99 % of coordinates equal, the rest within 1 ulp of the box size), while ids,
+scores, coefs, pixel boxes and masks of the goldens are reproduced exactly, end to end, from the kernel's own boxes."""
 import ctypes
 import os
 
@@ -28,18 +34,34 @@ def _gpu_nms(cls, box, coef, proto, anchors, cfg):
     return nms(cls.to(DEV), box.to(DEV), coef.to(DEV), proto.to(DEV), anchors.to(DEV), cfg)
 
 
-def _check_nms(g, r, exact_boxes=False):
+def _check_nms(g, r):
+    """Everything nms returns, bit for bit, against the oracle run with the correctly rounded exp."""
     assert (g[0] is None) == (r[0] is None)
     if r[0] is None:
         return
     assert g[0].dtype == torch.int64
     np.testing.assert_array_equal(g[0].cpu().numpy(), r[0].numpy())
     np.testing.assert_array_equal(g[1].cpu().numpy(), r[1].numpy())
-    if exact_boxes:
-        np.testing.assert_array_equal(g[2].cpu().numpy(), r[2].numpy())
-    else:
-        np.testing.assert_allclose(g[2].cpu().numpy(), r[2].numpy(), rtol=0, atol=2e-7)
+    np.testing.assert_array_equal(g[2].cpu().numpy(), r[2].numpy())
     np.testing.assert_array_equal(g[3].cpu().numpy(), r[3].numpy())
+
+
+def _check_boxes_vs_reference_exp(boxes, golden_boxes):
+    """Against the reference's frozen boxes (decode through MKL's exp): equal except for its 1-ulp deviations."""
+    b = boxes.cpu().numpy()
+    assert float((b == golden_boxes).mean()) >= 0.99
+    np.testing.assert_allclose(b, golden_boxes, rtol=0, atol=1.2e-7)     # 1 ulp of w or h (< 1), halved, re-added
+
+
+def test_expf_cr_kernel_is_bit_identical_to_the_oracle():
+    from yolact_minimal_amd import hip
+    g = torch.Generator().manual_seed(11)
+    x = torch.cat([torch.randn(2_000_000, generator=g) * 0.5, (torch.rand(2_000_000, generator=g) * 2 - 1) * 110.0,
+                   torch.tensor([float('nan'), float('inf'), -float('inf'), 0.0, -0.0, 88.72, 88.73, 89.0, 89.5, -87.4, -103.0,
+                                 -103.98, -104.0, -104.5, -1e30, 1e30, 1e-40, -1e-40])])
+    got = hip.expf_cr(x.to(DEV)).cpu()
+    want = R.expf_cr(x)
+    np.testing.assert_array_equal(got.numpy().view(np.int32), want.numpy().view(np.int32))
 
 
 def _check_after(ga, r, h, w):
@@ -71,22 +93,21 @@ def test_nms_small_goldens(golden_dir, tag):
     # against the reference's own outputs
     np.testing.assert_array_equal(out[0].cpu().numpy(), g['ids'])
     np.testing.assert_array_equal(out[1].cpu().numpy(), g['scores'])
-    np.testing.assert_allclose(out[2].cpu().numpy(), g['boxes'], rtol=0, atol=2e-7)
+    _check_boxes_vs_reference_exp(out[2], g['boxes'])
     np.testing.assert_array_equal(out[3].cpu().numpy(), g['coefs'])
-    r = R.nms(cls, box, coef, proto, anchors)
+    r = R.nms(cls, box, coef, proto, anchors, exp='cr')
     _check_nms(out, r)
     for key in g.files:
         if key.startswith('px_boxes_'):
             h, w = (int(v) for v in key[len('px_boxes_'):].split('x'))
-            boxes_in = torch.from_numpy(g['boxes']).to(DEV)     # identical inputs -> pixel boxes bit-exact
+            boxes_in = out[2].clone()                            # the kernel's OWN boxes, end to end
             ga = after_nms(out[0], out[1], boxes_in, out[3], out[4], h, w, cfg)
-            np.testing.assert_array_equal(ga[2].cpu().numpy(), g[key])
-            np.testing.assert_array_equal(boxes_in.cpu().numpy(), g['boxes'] * max(h, w))   # in-place scaling
+            np.testing.assert_array_equal(ga[2].cpu().numpy(), g[key])                           # the reference's pixel boxes
+            np.testing.assert_array_equal(boxes_in.cpu().numpy(), r[2].numpy() * max(h, w))      # in-place scaling
             packed = np.packbits(ga[3].cpu().numpy().astype(np.uint8).reshape(-1))
             mism = int(np.unpackbits(packed ^ g[f'masks_{h}x{w}_packed']).sum())
             assert mism <= max(2, int(1e-5 * ga[3].numel())), f'{mism} mask pixels differ from the reference'
-            r2 = (r[0], r[1], torch.from_numpy(g['boxes']), r[3], r[4])
-            _check_after(ga, r2, h, w)
+            _check_after(ga, (r[0], r[1], r[2].clone(), r[3], r[4]), h, w)
 
 
 def test_nms_ties_against_stable_oracle(golden_dir):
@@ -97,7 +118,7 @@ def test_nms_ties_against_stable_oracle(golden_dir):
     anchors = torch.from_numpy(g['in_anchors'])
     out = _gpu_nms(cls, box, coef, proto, anchors, _cfg(img_size=128))
     np.testing.assert_array_equal(out[1].cpu().numpy(), g['scores'])
-    r = R.nms(cls, box, coef, proto, anchors, stable=True)
+    r = R.nms(cls, box, coef, proto, anchors, stable=True, exp='cr')
     _check_nms(out, r)
 
 
@@ -117,13 +138,14 @@ def test_nms_full_size(golden_dir, seed, bg, tag):
     np.testing.assert_allclose(out[1].cpu().numpy(), g['scores'], rtol=0, atol=1e-7)
     np.testing.assert_allclose(out[2].cpu().numpy(), g['boxes'], rtol=0, atol=2e-7)
     np.testing.assert_allclose(out[3].cpu().numpy(), g['coefs'], rtol=0, atol=1.2e-7)
-    r = R.nms(cls, box, coef, proto, anchors)
+    r = R.nms(cls, box, coef, proto, anchors, exp='cr')
     _check_nms(out, r)
     for key in g.files:
         if key.startswith('px_boxes_'):
             h, w = (int(v) for v in key[len('px_boxes_'):].split('x'))
-            ga = after_nms(out[0], out[1], torch.from_numpy(g['boxes']).to(DEV), out[3], out[4], h, w, cfg)
+            ga = after_nms(out[0], out[1], out[2].clone(), out[3], out[4], h, w, cfg)     # the kernel's own boxes
             np.testing.assert_array_equal(ga[2].cpu().numpy(), g[key])
+            _check_after(ga, (r[0], r[1], r[2].clone(), r[3], r[4]), h, w)
             np.testing.assert_allclose(ga[3].sum(dim=(1, 2)).cpu().numpy(), g[f'masks_{h}x{w}_area'], rtol=0, atol=3)
             packed = np.packbits(ga[3].cpu().numpy().astype(np.uint8).reshape(-1))
             mism = int(np.unpackbits(packed ^ g[f'masks_{h}x{w}_packed']).sum())
@@ -154,14 +176,14 @@ def test_traditional_nms_matches_oracle():
     a128 = R.anchors_for(128, [int(128 / 544 * s) for s in (24, 48, 96, 192, 384)])
     cfg = _cfg(img_size=128, traditional_nms=True)
     out = _gpu_nms(cls, box, coef, proto, a128, cfg)
-    r = R.nms(cls, box, coef, proto, a128, traditional=True, img_size=128, stable=True)
+    r = R.nms(cls, box, coef, proto, a128, traditional=True, img_size=128, stable=True, exp='cr')
     _check_nms(out, r)
     # full size, sparse (greedy is O(n^2) per class)
     cls, box, coef, proto = R.synth_head_outputs(18525, seed=2, bg_bias=9.0)
     anchors = R.anchors_for(544, [24, 48, 96, 192, 384])
     cfg = _cfg(traditional_nms=True)
     out = _gpu_nms(cls, box, coef, proto, anchors, cfg)
-    r = R.nms(cls, box, coef, proto, anchors, traditional=True, img_size=544, stable=True)
+    r = R.nms(cls, box, coef, proto, anchors, traditional=True, img_size=544, stable=True, exp='cr')
     _check_nms(out, r)
 
 

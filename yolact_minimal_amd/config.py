@@ -42,6 +42,19 @@ COCO_LABEL_MAP = {cid: k + 1 for k, cid in
                   enumerate(c for c in range(1, 91) if c not in _COCO_ID_HOLES)}
 
 # BGR mean / std used by the reference pre-processing (config.py:66-67).
+def _palette(n=81):
+    """Drawing colours for `draw_img` (host-side visualisation, outside the hot path): index 0 = background black, then n-1 well
+    separated BGR colours from a golden-angle walk round the hue circle.  Own palette — the values do not influence any result."""
+    import colorsys
+    cols = [[0, 0, 0]]
+    for k in range(n - 1):
+        r, g, b = colorsys.hsv_to_rgb((k * 0.61803398875) % 1.0, 0.65 + 0.3 * ((k % 3) / 2), 0.95 - 0.25 * ((k % 4) / 3))
+        cols.append([int(b * 255), int(g * 255), int(r * 255)])
+    return np.array(cols)
+
+
+COLORS = _palette()
+
 norm_mean = np.array([103.94, 116.78, 123.68], dtype=np.float32)
 norm_std = np.array([57.38, 57.12, 58.40], dtype=np.float32)
 

@@ -308,6 +308,40 @@ __global__ __launch_bounds__(NT) void k_compact(const uint8_t* __restrict__ flag
     if (tid == 0) counters[0] = total_before;
 }
 
+// exp() of the box decode (utils/output_utils.py:150).  The reference's torch.exp is Intel MKL VML here (closed source, host-ISA
+// dependent, 1 ulp off the correctly rounded value in 1.1 % of inputs), so the anchor for this primitive is exp(x) ROUNDED TO
+// NEAREST float: evaluated in IEEE double with a fixed operation sequence (v_rndne_f64, v_fma_f64, v_mul_f64, one
+// v_cvt_f32_f64) that oracle/expf_cr.c states independently -> bit-identical to the oracle on every input.
+__device__ __forceinline__ float expf_cr(float xf) {
+    if (xf != xf) return xf;
+    const double x = (double)xf;
+    if (x > 89.0) return __builtin_inff();
+    if (x < -104.0) return 0.f;
+    const double k = __builtin_rint(x * 1.44269504088896338700e+00);
+    double r = __builtin_fma(k, -6.93147180369123816490e-01, x);
+    r = __builtin_fma(k, -1.90821492927058770002e-10, r);
+    double p = 1.0 / 6227020800.0;
+    p = __builtin_fma(p, r, 1.0 / 479001600.0);
+    p = __builtin_fma(p, r, 1.0 / 39916800.0);
+    p = __builtin_fma(p, r, 1.0 / 3628800.0);
+    p = __builtin_fma(p, r, 1.0 / 362880.0);
+    p = __builtin_fma(p, r, 1.0 / 40320.0);
+    p = __builtin_fma(p, r, 1.0 / 5040.0);
+    p = __builtin_fma(p, r, 1.0 / 720.0);
+    p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const long long bits = ((long long)k + 1023) << 52;
+    return (float)(p * __builtin_bit_cast(double, bits));
+}
+
+__global__ __launch_bounds__(256) void k_expf_cr(const float* __restrict__ x, float* __restrict__ y, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = expf_cr(x[i]);
+}
+
 __global__ __launch_bounds__(256) void k_decode_transpose(const float* __restrict__ cls, const float* __restrict__ box,
                                                            const float* __restrict__ anchors, int N, int C,
                                                            const int* __restrict__ keep_idx, const int* __restrict__ counters,
@@ -323,8 +357,8 @@ __global__ __launch_bounds__(256) void k_decode_transpose(const float* __restric
         const f32x4 b = *reinterpret_cast<const f32x4*>(box + (size_t)a * 4);
         const float cx = an[0] + (b[0] * 0.1f) * an[2];
         const float cy = an[1] + (b[1] * 0.1f) * an[3];
-        const float w = an[2] * (float)exp((double)(b[2] * 0.2f));
-        const float h = an[3] * (float)exp((double)(b[3] * 0.2f));
+        const float w = an[2] * expf_cr(b[2] * 0.2f);
+        const float h = an[3] * expf_cr(b[3] * 0.2f);
         float x1 = cx - w / 2.f, y1 = cy - h / 2.f;
         float x2 = w + x1, y2 = h + y1;
         auto clip01 = [](float v) { return v != v ? v : fminf(fmaxf(v, 0.f), 1.f); };
@@ -670,6 +704,15 @@ extern "C" int ym_detect_greedy_nms(const float* class_pred, const float* box_pr
     hipLaunchKernelGGL(k_greedy_final, dim3(1), dim3(NT), 0, st, w, g, N, C - 1, cfg->max_det, cfg->img_size, coef_pred,
                        cfg->coef_dim, out_count, out_ids, out_scores, out_boxes, out_coefs);
     return ym_check_launch("greedy_nms");
+}
+
+extern "C" int ym_expf_cr(const float* x, float* y, int64_t n, ym_stream_t s) {
+    YM_REQUIRE(n >= 0 && (n == 0 || (x && y)), "expf_cr: bad arguments");
+    if (n == 0) return YM_OK;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_expf_cr, dim3(grid), dim3(256), 0, (hipStream_t)s, x, y, (long long)n);
+    return ym_check_launch("expf_cr");
 }
 
 extern "C" size_t ym_greedy_nms_workspace_bytes(int n) {

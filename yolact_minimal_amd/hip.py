@@ -21,7 +21,7 @@ ABI_SYMBOLS = (
     'ym_sizeof_conv_desc', 'ym_conv2d_workspace_bytes', 'ym_conv2d_tile_counters', 'ym_conv2d_fwd', 'ym_maxpool3x3s2_fwd', 'ym_bilinear2x_fwd',
     'ym_softmax_rows', 'ym_nms_workspace_bytes', 'ym_detect_fast_nms', 'ym_detect_greedy_nms',
     'ym_greedy_nms_workspace_bytes', 'ym_greedy_nms', 'ym_mask_assemble', 'ym_mask_resize_binarize',
-    'ym_boxes_to_pixels',
+    'ym_boxes_to_pixels', 'ym_expf_cr',
     'ym_pack_conv_weight_dgrad', 'ym_pack_conv_weights_batch', 'ym_conv2d_wgrad_workspace_bytes', 'ym_conv2d_wgrad', 'ym_bn_train_fwd',
     'ym_val_preprocess', 'ym_layernorm', 'ym_patch_merge_layernorm', 'ym_swin_window_attention',
     'ym_mask_loss_workspace_bytes', 'ym_mask_loss_fwd_bwd', 'ym_mask_loss_batch_workspace_bytes', 'ym_mask_loss_batch',
@@ -127,6 +127,7 @@ def lib():
         L.ym_mask_assemble.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
         L.ym_mask_resize_binarize.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
         L.ym_boxes_to_pixels.argtypes = [vp, vp, i32, f32, vp]
+        L.ym_expf_cr.argtypes = [vp, vp, i64, vp]
         L.ym_pack_conv_weight_dgrad.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
         L.ym_pack_conv_weights_batch.argtypes = [vp, i32, i32, vp]
         L.ym_conv2d_wgrad_workspace_bytes.argtypes = [ctypes.POINTER(WgradDesc)]
@@ -298,6 +299,13 @@ def mask_resize_binarize(masks, img_h, img_w, out):
     n, hp, wp = masks.shape
     check(lib().ym_mask_resize_binarize(ptr(masks), n, hp, wp, img_h, img_w, ptr(out), stream_ptr()),
           'ym_mask_resize_binarize')
+
+
+def expf_cr(x):
+    """exp(x) rounded to nearest float (the decode's exp; see include/yolact_hip.h)."""
+    y = torch.empty_like(x)
+    check(lib().ym_expf_cr(ptr(x), ptr(y), x.numel(), stream_ptr()), 'ym_expf_cr')
+    return y
 
 
 def boxes_to_pixels(boxes_f, boxes_px, size):

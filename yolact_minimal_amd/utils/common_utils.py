@@ -189,3 +189,44 @@ class MakeJson:
         for data, path in ((self.bbox_data, bbox_path), (self.mask_data, mask_path)):
             with open(path, 'w') as f:
                 json.dump(data, f)
+
+
+# ---- harness helpers the reference scripts import from this module (host only) -----------------------------------------
+class ProgressBar:
+    """`ProgressBar(length, max_val).get_bar(i)` -> a `length`-character bar (reference common_utils.py:15-38; eval.py:32,81)."""
+
+    def __init__(self, length, max_val):
+        self.length, self.max_val = int(length), max_val
+        self.string = self.get_bar(0)
+
+    def get_bar(self, new_val):
+        filled = int(self.length * (min(new_val, self.max_val) / self.max_val)) if self.max_val else self.length
+        self.string = '█' * filled + '░' * (self.length - filled)
+        return self.string
+
+
+def _replace_checkpoint(prefix, cfg_name, new_name, net):
+    import glob
+    import os
+    old = [p for p in glob.glob(f'weights/{prefix}*') if cfg_name in p]
+    assert len(old) <= 1, f'Error, multiple {prefix} weight found.'
+    for p in old:
+        os.remove(p)
+    print(f"\nSaving the {prefix} model as '{new_name}'.\n")
+    torch.save(net.state_dict(), f'weights/{new_name}')
+
+
+def save_best(net, mask_map, cfg_name, step):
+    """Keep `weights/best_<mask mAP>_<cfg>_<step>.pth` if `mask_map` is at least the stored best (reference common_utils.py:41-53,
+    train.py:174; the file-name convention is what eval.py / train.py --resume parse)."""
+    import glob
+    old = [p for p in glob.glob('weights/best*') if cfg_name in p]
+    assert len(old) <= 1, 'Error, multiple best weight found.'
+    best = float(old[0].split('/')[-1].split('_')[1]) if old else 0.
+    if mask_map >= best:
+        _replace_checkpoint('best', cfg_name, f'best_{mask_map}_{cfg_name}_{step}.pth', net)
+
+
+def save_latest(net, cfg_name, step):
+    """`weights/latest_<cfg>_<step>.pth`, replacing the previous one (reference common_utils.py:56-63, train.py:184,196)."""
+    _replace_checkpoint('latest', cfg_name, f'latest_{cfg_name}_{step}.pth', net)
