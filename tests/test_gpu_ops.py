@@ -363,3 +363,45 @@ def test_val_aug_preprocess(h, w, dtype):
     want = R.val_aug(img, 544)
     assert got.shape == (3, 544, 544)
     torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('tile,ksplit,stages,tail', [((64, 64), 1, 22, (50, 2)), ((64, 64), 4, 22, (0, 0)), ((64, 64), 3, 0, (0, 0)),
+                                                     ((128, 64), 1, 23, (37, 3))])
+def test_conv_splitk_exchange_is_race_free(tile, ksplit, stages, tail):
+    """The K-slice exchange between workgroups of one launch (fused split-K finish / tail split): 400 back-to-back launches of a
+    chip-filling shape must all be bit-identical to the un-split launch of the same tile (slices are summed in slice order).
+    Regression test for the missing store drain before the arrival counter (a slice still in flight when the last workgroup
+    summed it: a few wrong elements in ~1 % of the launches; M9248_N1152_C384 is the Swin-T bs=8 qkv shape that showed it)."""
+    from yolact_minimal_amd import hip
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    b, h, w, cin, cout = 8, 34, 34, 384, 1152
+    x = torch.randn(b, h, w, cin, generator=g).to(dev)
+    wt = (torch.randn(cout, cin, 1, 1, generator=g) * 0.05).to(dev)
+    wp = hip.pack_conv_weight(wt, cin, cin)
+    out = torch.empty(b, h, w, cout, device=dev)
+    counters = torch.zeros(hip.TILE_COUNTERS, device=dev, dtype=torch.int32)
+    d = hip.ConvDesc()
+    d.inp, d.weight = x.data_ptr(), wp.data_ptr()
+    d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW = b, h, w, cin, cout, 1, 1
+    d.stride, d.pad, d.Ho, d.Wo, d.k_pad, d.nseg = 1, 0, h, w, cin, 1
+    d.seg[0].n_begin, d.seg[0].n_end, d.seg[0].out = 0, cout, out.data_ptr()
+    d.seg[0].batch_stride, d.seg[0].pitch, d.seg[0].act = h * w * cout, cout, 0
+    d.tile_counters = counters.data_ptr()
+    d.tile_m, d.tile_n, d.ksplit, d.stages = tile[0], tile[1], 1, 0
+    ws = torch.empty(1 << 27, dtype=torch.uint8, device=dev)
+    hip.conv2d_fwd(d, ws)
+    want = out.clone()
+    d.ksplit, d.stages = ksplit, stages
+    d.tail_tiles, d.tail_ksplit = tail
+    assert hip.conv_workspace_bytes(d) <= ws.numel()
+    hip.conv2d_fwd(d, ws)
+    first = out.clone()
+    bad_t = torch.zeros((), device=dev, dtype=torch.int64)
+    for it in range(400):                      # (ksplit > 1 changes the association of the K sum: launches are compared with each other)
+        hip.conv2d_fwd(d, ws)
+        bad_t += (out != first).any()
+    bad = int(bad_t)
+    assert bad == 0, f'{bad} launches differed from the first one'
+    assert int(counters.abs().sum()) == 0                                     # arrival counters left at zero
+    torch.testing.assert_close(first, want, rtol=1e-5, atol=1e-5)

@@ -88,44 +88,6 @@ def test_eval_loop_end_to_end():
     assert len(mj.mask_data) == n and mj.mask_data[0]['segmentation']['size'] == [img_h, img_w]
 
 
-def test_serving_pipeline_equals_sequential_calls():
-    """Forward of image i+1 overlapped with nms + after_nms of image i (two streams, two staging slots): same results as the
-    reference-style sequential loop, for more images than slots."""
-    from yolact_minimal_amd.serving import ServingPipeline
-    from yolact_minimal_amd.utils.output_utils import nms, after_nms
-    size = 128
-    cfg = build_cfg('res101_coco', 'val', size)
-    torch.manual_seed(1)
-    net = Yolact(cfg).eval()
-    sd = net.state_dict()
-    R.randomize_bn_(sd, 1)
-    R.randomize_bias_(sd, 2)
-    sd['prediction_layers.conf_layer.bias'] += torch.randn(sd['prediction_layers.conf_layer.bias'].shape,
-                                                            generator=torch.Generator().manual_seed(3)) * 2.0   # some confident classes
-    net.load_state_dict(sd)
-    net = net.to(DEV)
-    g = torch.Generator().manual_seed(9)
-    imgs = [torch.randn(1, 3, size, size, generator=g).to(DEV) * (1 + 0.5 * i) for i in range(5)]
-    sizes = [(96, 120), (128, 128), (50, 70), (96, 120), (128, 100)]
-    want = []
-    with torch.no_grad():
-        for im, (h, w) in zip(imgs, sizes):
-            out = net(im)
-            r = nms(*out, net.anchors, cfg)
-            want.append(after_nms(r[0], r[1], r[2], r[3], r[4], h, w, cfg))
-    pipe = ServingPipeline(net, cfg, size, torch.device(DEV))
-    got = list(pipe.run(imgs, sizes))
-    assert len(got) == len(want)
-    n_det = 0
-    for a, b in zip(got, want):
-        for x, y in zip(a, b):
-            assert (x is None) == (y is None)
-            if x is not None:
-                assert torch.equal(x.cpu(), y.cpu())
-                n_det += x.shape[0]
-    assert n_det > 0
-
-
 @pytest.mark.parametrize('seed,h,w,n,size', [(0, 96, 128, 2, 160), (3, 120, 110, 4, 160), (7, 128, 96, 3, 544), (12, 480, 640, 6, 544),
                                                (21, 427, 640, 5, 544), (33, 100, 100, 1, 160)])
 def test_train_aug_matches_oracle_chain(seed, h, w, n, size):

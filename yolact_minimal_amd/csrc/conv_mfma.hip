@@ -490,7 +490,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
             if (!fused) return;                    // the host launches conv_splitk_reduce
             // the last workgroup to arrive at this output tile owns the reduction + epilogue
             __shared__ int s_last;
-            __syncthreads();                       // s_waitcnt vmcnt(0): every lane's slice stores are acknowledged
+            // EVERY writing wave drains its own slice stores before the barrier: __syncthreads() is a workgroup-scope fence and
+            // on gfx950 that is `s_waitcnt lgkmcnt(0); s_barrier` only — it does NOT wait for outstanding global stores (vmcnt),
+            // so without this line the arrival count below could overtake a slice that is still in flight and the last
+            // workgroup would sum a stale slice (seen as run-to-run differences of a few elements in ~1 % of the launches:
+            // tools/determinism_check.py; cdna guide §6 G16 "every writing wave drains").
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
             if (tid == 0) {
                 int* cnt = p.counters + tile_m * p.tiles_n + tile_n;
                 const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
