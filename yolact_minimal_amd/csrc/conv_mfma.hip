@@ -323,7 +323,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
     if constexpr (DL && PF) {
         static_assert(NS >= 3, "fragment prefetch needs a ring of 3+");
         constexpr int D = NS - 1;
-        constexpr int WAIT = 0xF70 | ((AR + BR) * (D - 2));   // tiles <= t+1 landed at the barrier that ends tile t-1
+        static_assert((AR + BR) * (D - 2) < 16, "vmcnt field");
+        constexpr int WAIT = 0x070 | ((AR + BR) * (D - 2));   // tiles <= t+1 landed at the barrier that ends tile t-1; lgkmcnt(0): see RING_WAIT
         const int nt = kt_end - kt_beg;
         auto read_frag = [&](int buf, int g, f32x4 (&fa)[TM], f32x4 (&fb)[TN]) {
             const float* a = As + buf * BM * RP + a_frag_off + goff[g];
@@ -383,7 +384,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
         __builtin_amdgcn_s_barrier();
     } else if constexpr (DL) {
         constexpr int D = NS - 1;                          // prefetch distance in K tiles
-        constexpr int WAIT = 0xF70 | ((AR + BR) * (D - 1));   // s_waitcnt vmcnt((AR+BR)*(D-1)): everything but the newest D-1 tiles
+        // s_waitcnt vmcnt((AR+BR)*(D-1)) lgkmcnt(0).  vmcnt: everything but the newest D-1 tiles has landed.  lgkmcnt(0) (RING_WAIT):
+        // the DMA issued right after this barrier re-stages the buffer that was read during THIS iteration, and hipcc sinks the
+        // last K group's MFMAs (with their lgkmcnt wait) below the raw s_barrier — so a wave could sit at the barrier with
+        // ds_reads of that buffer still queued while a faster wave's DMA overwrote it (WAR; cdna guide "restage a buffer 1 phase
+        // after its last ds_read only when an lgkmcnt before the barrier retired those reads").  Seen with the ring of 2 as one
+        // wrong 16-byte operand chunk (32 wrong outputs) in ~1 % of the launches of a 2610-tile conv: tools/race_probe.py.
+        static_assert((AR + BR) * (D - 1) < 16, "vmcnt field");
+        constexpr int WAIT = 0x070 | ((AR + BR) * (D - 1));
         const int nt = kt_end - kt_beg;
 #pragma unroll
         for (int d = 0; d < D; ++d) dma_tile(kt_beg + d, d);
