@@ -393,6 +393,16 @@ int ym_detect_fast_nms(const float* class_pred, const float* box_pred, const flo
                        float* out_scores, float* out_boxes, float* out_coefs, void* workspace,
                        size_t workspace_bytes, ym_stream_t s);
 
+/* The same for a batch of B images in ONE launch set (grid row = image; SURVEY.md §0.3: the reference's nms() is batch-1 only,
+ * eval.py loops over images): class_pred [B][N][C], box_pred [B][N][4], coef_pred [B][N][coef_dim]; outputs out_count int32[B],
+ * out_ids [B][max_det], out_scores [B][max_det], out_boxes [B][max_det][4], out_coefs [B][max_det][coef_dim] (rows past an
+ * image's count are unspecified).  Per image the result equals ym_detect_fast_nms on that image.
+ * workspace >= ym_nms_batch_workspace_bytes(cfg, B). */
+size_t ym_nms_batch_workspace_bytes(const ym_nms_cfg* cfg, int B);
+int ym_detect_fast_nms_batch(const float* class_pred, const float* box_pred, const float* coef_pred, const float* anchors,
+                             const ym_nms_cfg* cfg, int B, int32_t* out_count, int64_t* out_ids, float* out_scores,
+                             float* out_boxes, float* out_coefs, void* workspace, size_t workspace_bytes, ym_stream_t s);
+
 /* Same contract, greedy per-class NMS: replaces traditional_nms (utils/output_utils.py:84-123) and the
  * Cython kernel it calls (cython_nms.pyx:24-74) without the 80 D2H/H2D round trips. */
 int ym_detect_greedy_nms(const float* class_pred, const float* box_pred, const float* coef_pred,
@@ -425,6 +435,17 @@ int ym_mask_resize_binarize(const float* masks, int n, int Hp, int Wp, int img_h
 
 /* box_p *= S; box_p.int()  (utils/output_utils.py:230-231): boxes_f is scaled IN PLACE like the reference. */
 int ym_boxes_to_pixels(float* boxes_f, int32_t* boxes_px, int n, float S, ym_stream_t s);
+
+/* after_nms (utils/output_utils.py:200-233) for a batch of B images in one launch set: prototype x coefficient product, sigmoid,
+ * crop, bilinear resize to S = max(img_h, img_w), > 0.5, slice — fused, the [n][Hp][Wp] soft masks never reach HBM — plus the
+ * in-place box scaling + truncation.  proto [B][Hp][Wp][32]; coefs [B][max_det][32], boxes [B][max_det][4] (scaled IN PLACE),
+ * counts int32[B] on the DEVICE (NULL = every image has max_det detections; B = 1 with max_det = n is the single-image call);
+ * masks [B][max_det][img_h][img_w] (only slots < count are written), boxes_px int32 [B][max_det][4].
+ * workspace >= ym_after_nms_batch_workspace_bytes(...) (0 unless the image is much smaller than the prototype map). */
+size_t ym_after_nms_batch_workspace_bytes(int max_det, int Hp, int Wp, int img_h, int img_w);
+int ym_after_nms_batch(const float* proto, const float* coefs, float* boxes, const int32_t* counts, int B, int max_det, int Hp,
+                       int Wp, int K, int img_h, int img_w, int do_crop, float* masks, int32_t* boxes_px, void* workspace,
+                       size_t workspace_bytes, ym_stream_t s);
 
 #ifdef __cplusplus
 }

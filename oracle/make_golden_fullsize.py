@@ -95,31 +95,32 @@ def gen_train(ref_config, ref_yolact, name, size, batch, seed, damp=False):
         if 'running' in k:
             assert torch.equal(sd1[k], params[k].detach()), k
     keys = list(grads.keys())
+    # how far is this fp32 run from an fp64 evaluation of the same step?  (per tensor, relative to max|g|: the tests' yardstick)
+    t0 = time.time()
+    p64 = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+    for k in keys:
+        p64[k].requires_grad_(True)
+    o64 = R.TrainNet(p64).forward(img.double())
+    torch.set_default_dtype(torch.float64)
+    try:
+        l64 = R.compute_loss(*o64, [b.double() for b in boxes], [m.double() for m in masks], anchors.double())
+    finally:
+        torch.set_default_dtype(torch.float32)
+    sum(l64).backward()
+    e = np.array([((grads[k].double() - p64[k].grad).abs().max() / (p64[k].grad.abs().max() + 1e-30)).item() for k in keys])
+    print(f'fp64 step {time.time() - t0:.1f}s; fp32-vs-fp64 gradient error / max|g|: median {np.median(e):.2e} '
+          f'p90 {np.quantile(e, 0.9):.2e} max {e.max():.2e} ({keys[int(e.argmax())]}); '
+          f'loss rel err {max(abs(float(a) - float(b)) / abs(float(b)) for a, b in zip(losses, l64)):.2e}', flush=True)
     np.savez_compressed(
         os.path.join(OUT, f'train_{name}_{size}_b{batch}.npz'), seed=np.array(seed),
-        losses=np.array([float(l) for l in losses], dtype=np.float64),
+        losses=np.array([float(l.detach()) for l in losses], dtype=np.float64),
+        losses_fp64=np.array([float(l.detach()) for l in l64], dtype=np.float64),
         grad_keys=np.array(keys), grad_digest=np.stack([tensor_digest(grads[k]) for k in keys]),
         grad_sample=np.stack([np.pad(grad_sample(grads[k]).numpy(), (0, 64 - min(64, grad_sample(grads[k]).numel()))) for k in keys]),
-        grad_absmax=np.array([float(grads[k].abs().max()) for k in keys]),
+        grad_sample_fp64=np.stack([np.pad(grad_sample(p64[k].grad).numpy(), (0, 64 - min(64, grad_sample(p64[k].grad).numel()))) for k in keys]),
+        grad_absmax=np.array([float(p64[k].grad.abs().max()) for k in keys]), grad_err_vs_fp64=e,
         run_mean_stem=sd1['backbone.bn1.running_mean'].numpy(), run_var_stem=sd1['backbone.bn1.running_var'].numpy())
     print(name, size, batch, 'losses', [round(float(l), 5) for l in losses], 'restatement bit-equal: ok', flush=True)
-
-    if os.environ.get('YM_GOLDEN_CONDITIONING', '1') == '1':          # how far is fp32-CPU from fp64? (sets the test's bound)
-        t0 = time.time()
-        p64 = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
-        for k in keys:
-            p64[k].requires_grad_(True)
-        o64 = R.TrainNet(p64).forward(img.double())
-        torch.set_default_dtype(torch.float64)
-        try:
-            l64 = R.compute_loss(*o64, [b.double() for b in boxes], [m.double() for m in masks], anchors.double())
-        finally:
-            torch.set_default_dtype(torch.float32)
-        sum(l64).backward()
-        e = np.array([((grads[k].double() - p64[k].grad).abs().max() / (p64[k].grad.abs().max() + 1e-30)).item() for k in keys])
-        print(f'fp64 step {time.time() - t0:.1f}s; fp32-vs-fp64 gradient error / max|g|: median {np.median(e):.2e} '
-              f'p90 {np.quantile(e, 0.9):.2e} max {e.max():.2e} ({keys[int(e.argmax())]}); '
-              f'loss rel err {max(abs(float(a) - float(b)) / abs(float(b)) for a, b in zip(losses, l64)):.2e}', flush=True)
 
 
 def main():

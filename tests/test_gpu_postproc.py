@@ -248,3 +248,69 @@ def test_after_nms_visual_thre_and_none():
     assert ga[0].numel() == int((out[1] >= cfg.visual_thre).sum())
     cfg.visual_thre = 2.0
     assert after_nms(out[0], out[1], out[2].clone(), out[3], out[4], 50, 70, cfg) == (None, None, None, None)
+
+
+@pytest.mark.parametrize('hw', [(480, 640), (544, 544), (300, 200)])
+def test_batched_postprocessing_equals_per_image(hw):
+    """`nms_batch` + `after_nms_batch` (one launch set for the batch, ONE host read) against the batch-1 calls image by image:
+    everything bit-identical — including an image without detections and one with fewer candidates than top_k.
+    (300, 200) takes the two-kernel fallback of ym_after_nms_batch (image much smaller than 2.7x the prototype map)."""
+    from yolact_minimal_amd.utils.output_utils import nms, after_nms, nms_batch, after_nms_batch
+    h, w = hw
+    cfg = _cfg()
+    anchors = R.anchors_for(544, [24, 48, 96, 192, 384])
+    parts = [R.synth_head_outputs(18525, seed=1), R.synth_head_outputs(18525, seed=2, bg_bias=9.0),
+             R.synth_head_outputs(18525, seed=4, bg_bias=30.0), R.synth_head_outputs(18525, seed=5, bg_bias=7.5),
+             R.synth_head_outputs(18525, seed=7, bg_bias=5.0)]
+    cls, box, coef, proto = (torch.cat([p[i] for p in parts], 0).to(DEV) for i in range(4))
+    per_image = []
+    for b in range(len(parts)):
+        r = nms(cls[b:b + 1], box[b:b + 1], coef[b:b + 1], proto[b:b + 1], anchors.to(DEV), cfg)
+        a = after_nms(r[0], r[1], r[2].clone() if r[2] is not None else None, r[3], r[4], h, w, cfg)
+        per_image.append((r, a))
+    dets = nms_batch(cls, box, coef, proto, anchors.to(DEV), cfg)
+    split = dets.split()
+    assert [s[0] is None for s in split] == [False, False, True, False, False]
+    for (r, _), s in zip(per_image, split):
+        assert (r[0] is None) == (s[0] is None)
+        if r[0] is not None:
+            for x, y in zip(r[:4], s[:4]):
+                assert torch.equal(x, y)
+    got = after_nms_batch(dets, h, w, cfg)
+    for (_, a), g_ in zip(per_image, got):
+        assert (a[0] is None) == (g_[0] is None)
+        if a[0] is not None:
+            assert g_[2].dtype == torch.int32 and g_[3].shape == a[3].shape
+            for x, y in zip(a, g_):
+                assert torch.equal(x, y)
+
+
+def test_fused_after_nms_matches_the_two_kernel_path():
+    """ym_after_nms_batch's fused kernel (soft masks only in LDS, zero-filled tiles outside the crop window) against
+    ym_mask_assemble + ym_mask_resize_binarize: identical except where the interpolated value sits within 1e-6 of the threshold
+    (the fused dot product sums in k order, the MFMA in its own order)."""
+    from yolact_minimal_amd import hip
+    from yolact_minimal_amd.utils.output_utils import after_nms
+    g = torch.Generator().manual_seed(8)
+    for (hp, n, h, w, crop) in ((136, 100, 480, 640, True), (136, 37, 544, 544, True), (136, 9, 427, 640, False), (32, 20, 96, 128, True),
+                                (34, 5, 333, 517, True)):
+        proto = torch.relu(torch.randn(hp, hp, 32, generator=g)).to(DEV)
+        coef = torch.tanh(torch.randn(n, 32, generator=g)).to(DEV)
+        xy = torch.rand(n, 2, generator=g) * 0.7
+        boxes = torch.cat([xy, xy + torch.rand(n, 2, generator=g) * 0.3], 1)
+        boxes[0] = torch.tensor([0.9, 0.2, 0.1, 0.8])
+        boxes[-1] = torch.tensor([0.0, 0.0, 1.0, 1.0])
+        boxes = boxes.to(DEV)
+        soft = torch.empty(n, hp, hp, device=DEV)
+        hip.mask_assemble(proto, coef, boxes, soft, crop)
+        want = torch.empty(n, h, w, device=DEV)
+        hip.mask_resize_binarize(soft, h, w, want)
+        cfg = _cfg(no_crop=not crop)
+        ids = torch.zeros(n, dtype=torch.int64, device=DEV)
+        sc = torch.ones(n, device=DEV)
+        got = after_nms(ids, sc, boxes.clone(), coef, proto, h, w, cfg)[3]
+        diff = got != want
+        if bool(diff.any()):
+            up = torch.nn.functional.interpolate(soft[None], (max(h, w), max(h, w)), mode='bilinear', align_corners=False)[0][:, :h, :w]
+            assert float((up[diff] - 0.5).abs().max()) < 1e-5
+        assert float(diff.float().mean()) < 1e-5

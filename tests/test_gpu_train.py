@@ -243,13 +243,14 @@ def _grad_sample(g):
 def test_train_step_256_well_conditioned_golden(golden_dir):
     """The tight end-to-end gradient check: res50_coco, 256 px, batch 4 (layer4's BatchNorms see 256 samples), residual
     branches damped (`R.damp_residual_branches_`) so that backward is as well conditioned as a random-init net gets.
-    Golden: the REAL reference's losses + gradient digests / samples (oracle/make_golden_fullsize.py train256).
+    Golden: the REAL reference's losses + gradient digests / samples (oracle/make_golden_fullsize.py train256), together with the
+    distance of that fp32 reference run from an fp64 evaluation of the same step, tensor by tensor (`grad_err_vs_fp64`).
 
-    How tight can "tight" be?  Measured in the build container on this very case: the reference's own fp32 CPU gradients differ
-    from an fp64 evaluation by 4.7e-4 of max|g| (median over tensors; isolated tensors with a nearly dead BatchNorm channel reach
-    8e-2), and an 8-thread run differs from a 1-thread run of the SAME fp32 code by as much.  No fp32 implementation can sit
-    closer to fp64 than that, so every tensor is held to 3x the fp32-CPU oracle's own distance from fp64 (floor 1e-4 of max|g|),
-    the losses to 1e-5, and the golden's samples to the same per-tensor bound."""
+    How tight can "tight" be?  Measured on this very case: the reference's own fp32 CPU gradients differ from fp64 by 4.7e-4 of
+    max|g| (median over tensors; isolated tensors with a nearly dead BatchNorm channel reach 8e-2), and an 8-thread run differs
+    from a 1-thread run of the SAME fp32 code by as much.  No fp32 implementation can sit closer to fp64 than that, so every
+    tensor is held to 3x the fp32 CPU reference's own distance from fp64 (the larger of the frozen build-container run and the
+    oracle run live on this host; floor 1e-4 of max|g|), the median over tensors to 1e-3, and the losses to 1e-5."""
     g = np.load(os.path.join(golden_dir, 'train_res50_coco_256_b4.npz'))
     seed, size, batch = int(g['seed']), 256, 4
     cfg = build_cfg('res50_coco', 'train', size)
@@ -271,19 +272,20 @@ def test_train_step_256_well_conditioned_golden(golden_dir):
     np.testing.assert_allclose(got, g['losses'], rtol=1e-5)              # the reference's own numbers
     keys = [str(k) for k in g['grad_keys']]
     assert keys == [k for k, _ in net.named_parameters()]
-    worst = []
+    rows = []
     for i, (k, p) in enumerate(net.named_parameters()):
         gg = p.grad.detach().cpu().double()
-        e_gpu, e_cpu = _rel_err(gg, g64[k]), _rel_err(g32[k], g64[k])
-        bound = max(3.0 * e_cpu, 1e-4)
-        worst.append((e_gpu / bound, k, e_gpu, e_cpu))
-        # the reference's frozen samples of this tensor (fp32 CPU in the build container): same bound, relative to max|g|
+        e_gpu, e_cpu = _rel_err(gg, g64[k]), max(_rel_err(g32[k], g64[k]), float(g['grad_err_vs_fp64'][i]))
+        # the frozen fp64 samples of this tensor (same positions): the live fp64 oracle and the build container's agree
         n = min(64, _grad_sample(gg).numel())
-        d = np.abs(_grad_sample(gg).numpy()[:n] - g['grad_sample'][i][:n]).max() / (float(g['grad_absmax'][i]) + 1e-30)
-        assert d <= 2 * bound + 1e-4, (k, d, bound)
-    worst.sort(reverse=True)
-    assert worst[0][0] <= 1.0, worst[:5]
-    e_all = np.array([w[2] for w in worst])
+        d64 = np.abs(_grad_sample(g64[k]).numpy()[:n] - g['grad_sample_fp64'][i][:n]).max() / (float(g['grad_absmax'][i]) + 1e-30)
+        assert d64 < 1e-9, (k, d64)
+        rows.append((e_gpu / max(3.0 * e_cpu, 1e-4), k, e_gpu, e_cpu))
+    rows.sort(reverse=True)
+    e_all = np.array([r[2] for r in rows])
+    print(f'256 px bs=4: gradient error vs fp64 / max|g|: GPU median {np.median(e_all):.2e} max {e_all.max():.2e}; '
+          f'fp32 CPU reference median {np.median([r[3] for r in rows]):.2e}; worst ratio to the bound {rows[0][0]:.2f} ({rows[0][1]})')
+    assert rows[0][0] <= 1.0, rows[:5]
     assert np.median(e_all) <= 1e-3, np.median(e_all)
     np.testing.assert_allclose(net.backbone.bn1.running_mean.cpu().numpy(), g['run_mean_stem'], rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(net.backbone.bn1.running_var.cpu().numpy(), g['run_var_stem'], rtol=1e-5, atol=1e-7)
@@ -291,16 +293,15 @@ def test_train_step_256_well_conditioned_golden(golden_dir):
 
 def test_train_step_res101_544_bs8_golden(golden_dir):
     """BASELINE.json config 3's per-GPU training step at FULL size (res101_coco, 544 px, batch 8) — the shape bench.py times, under
-    the tuned training plan — against the REAL reference's losses and per-tensor gradient digests / samples
-    (oracle/make_golden_fullsize.py train544, which also pins the oracle's restatement bit for bit at this size).
+    the tuned training plan — against the REAL reference's losses and gradients (oracle/make_golden_fullsize.py train544, which
+    also pins the oracle's restatement bit for bit at this size and evaluates the same step in fp64).
 
-    Conditioning, measured when the golden was made: the reference's own fp32 CPU gradients differ from an fp64 evaluation of the
-    same step by 5.5e-2 of max|g| (median over the 419 tensors; 2.2e-1 worst, in layer4) and its losses by 6.7e-5 — a
-    random-init res101 with batch-statistics BatchNorm amplifies rounding that much in backward.  The frozen values are that fp32
-    run, so the comparison is fp32 vs fp32: losses within 5e-4; for every tensor sum|g| within 10 %, sum g^2 within 20 %, strided
-    samples within 0.5 max|g| (measured on MI355X: median 0.12, worst 0.32 — two fp32 runs ~2x the fp32-vs-fp64 distance apart);
-    the tensors AFTER the backbone (FPN, ProtoNet, heads, semantic conv — no BatchNorm between them and the loss) within 6 % of
-    max|g| (measured: median 1.5e-3, worst 3.9e-2).  The tight per-tensor check lives in the 256 px test above."""
+    Conditioning, measured when the golden was made: the reference's own fp32 CPU gradients differ from the fp64 evaluation by
+    5.5e-2 of max|g| (median over the 419 tensors; 2.2e-1 worst, in layer4) and its losses by 6.7e-5 — a random-init res101 with
+    batch-statistics BatchNorm amplifies rounding that much in backward.  The fp64 oracle is too slow to run live here, so the
+    golden carries strided fp64 samples of every gradient and the reference run's own error per tensor: the HIP step is held,
+    tensor by tensor, to 3x the fp32 reference's distance from fp64 (floor 1e-3 of max|g|), its robust norms (sum|g|, sum g^2) to
+    10 % / 20 % of the reference's, and its losses to 3e-4 of the fp64 values."""
     g = np.load(os.path.join(golden_dir, 'train_res101_coco_544_b8.npz'))
     seed, size, batch = int(g['seed']), 544, 8
     cfg = build_cfg('res101_coco', 'train', size)
@@ -310,23 +311,25 @@ def test_train_step_res101_544_bs8_golden(golden_dir):
     boxes, masks = R.synth_targets(batch, size, seed=seed)
     losses = net(img.to(DEV), [b.to(DEV) for b in boxes], [m.to(DEV) for m in masks])
     sum(losses).backward()
-    np.testing.assert_allclose(np.array([float(l.detach()) for l in losses]), g['losses'], rtol=5e-4)
+    got = np.array([float(l.detach()) for l in losses])
+    print('544 px bs=8 losses', got, 'reference fp32', g['losses'], 'fp64', g['losses_fp64'])
+    np.testing.assert_allclose(got, g['losses_fp64'], rtol=3e-4)
     keys = [str(k) for k in g['grad_keys']]
     assert keys == [k for k, _ in net.named_parameters()]
-    bad, tail_err, body_err = [], [], []
+    bad, ratios, errs = [], [], []
     for i, (k, p) in enumerate(net.named_parameters()):
         gg = p.grad.detach().double()
         dig = np.array([gg.abs().sum().item(), (gg * gg).sum().item()])
         ref = g['grad_digest'][i][1:]
         n = min(64, _grad_sample(gg).numel())
-        d = np.abs(_grad_sample(gg).cpu().numpy()[:n] - g['grad_sample'][i][:n]).max() / (float(g['grad_absmax'][i]) + 1e-30)
-        after_backbone = not k.startswith('backbone.')
-        (tail_err if after_backbone else body_err).append(d)
-        if (abs(dig[0] - ref[0]) > 0.10 * ref[0] + 1e-12 or abs(dig[1] - ref[1]) > 0.20 * ref[1] + 1e-20
-                or d > (0.06 if after_backbone else 0.5)):
-            bad.append((k, dig.tolist(), ref.tolist(), d))
-    print(f'544 px bs=8 gradient samples vs the reference: backbone median {np.median(body_err):.2e} max {np.max(body_err):.2e}; '
-          f'after the backbone median {np.median(tail_err):.2e} max {np.max(tail_err):.2e}')
+        d = np.abs(_grad_sample(gg).cpu().numpy()[:n] - g['grad_sample_fp64'][i][:n]).max() / (float(g['grad_absmax'][i]) + 1e-30)
+        bound = max(3.0 * float(g['grad_err_vs_fp64'][i]), 1e-3)
+        ratios.append(d / bound)
+        errs.append(d)
+        if abs(dig[0] - ref[0]) > 0.10 * ref[0] + 1e-12 or abs(dig[1] - ref[1]) > 0.20 * ref[1] + 1e-20 or d > bound:
+            bad.append((k, d, bound, dig.tolist(), ref.tolist()))
+    print(f'544 px bs=8 gradient samples vs fp64 / max|g|: GPU median {np.median(errs):.2e} max {np.max(errs):.2e}; fp32 CPU reference median '
+          f'{np.median(g["grad_err_vs_fp64"]):.2e} max {np.max(g["grad_err_vs_fp64"]):.2e}; worst ratio to the bound {np.max(ratios):.2f}')
     assert not bad, (len(bad), bad[:5])
 
 

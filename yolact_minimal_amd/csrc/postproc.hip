@@ -227,6 +227,22 @@ struct NmsWs {
 
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// Batched launches (ym_detect_fast_nms_batch): blockIdx.y = image; image b owns the workspace carved at base + b * stride.
+__device__ __forceinline__ NmsWs image_ws(const NmsWs& w, size_t stride, int b) {
+    NmsWs o = w;
+    const size_t sh = stride * (size_t)b;
+    o.counters = (int*)((char*)w.counters + sh);
+    o.flag = w.flag + sh;
+    o.keep_idx = (int*)((char*)w.keep_idx + sh);
+    o.boxes_k = (float*)((char*)w.boxes_k + sh);
+    o.scores_t = (float*)((char*)w.scores_t + sh);
+    o.top_idx = (int*)((char*)w.top_idx + sh);
+    o.top_score = (float*)((char*)w.top_score + sh);
+    o.top_cnt = (int*)((char*)w.top_cnt + sh);
+    o.col_keep = w.col_keep + sh;
+    return o;
+}
+
 NmsWs carve(void* base, int N, int C) {
     NmsWs w;
     size_t off = 0;
@@ -248,7 +264,9 @@ NmsWs carve(void* base, int N, int C) {
 // stage A: score filter, ordered compaction, decode + transpose  (utils/output_utils.py:135-153)
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_score_flag(const float* __restrict__ cls, int N, int C, float thre,
-                                                     uint8_t* __restrict__ flag) {
+                                                     uint8_t* __restrict__ flag, size_t ws_stride) {
+    cls += (size_t)blockIdx.y * N * C;
+    flag += ws_stride * blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
     for (int a = wave0; a < N; a += nw) {
@@ -263,7 +281,10 @@ __global__ __launch_bounds__(256) void k_score_flag(const float* __restrict__ cl
 
 // Ordered compaction in ONE pass: every thread owns a contiguous run of flags (<= 32), one block-wide exclusive scan.
 __global__ __launch_bounds__(NT) void k_compact(const uint8_t* __restrict__ flag, int N, int* __restrict__ keep_idx,
-                                                int* __restrict__ counters) {
+                                                int* __restrict__ counters, size_t ws_stride) {
+    flag += ws_stride * blockIdx.y;
+    keep_idx = (int*)((char*)keep_idx + ws_stride * blockIdx.y);
+    counters = (int*)((char*)counters + ws_stride * blockIdx.y);
     __shared__ int wave_tot[NT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int total_before = 0;
@@ -345,7 +366,16 @@ __global__ __launch_bounds__(256) void k_expf_cr(const float* __restrict__ x, fl
 __global__ __launch_bounds__(256) void k_decode_transpose(const float* __restrict__ cls, const float* __restrict__ box,
                                                            const float* __restrict__ anchors, int N, int C,
                                                            const int* __restrict__ keep_idx, const int* __restrict__ counters,
-                                                           float* __restrict__ boxes_k, float* __restrict__ scores_t) {
+                                                           float* __restrict__ boxes_k, float* __restrict__ scores_t, size_t ws_stride) {
+    {
+        const size_t sh = ws_stride * blockIdx.y;
+        cls += (size_t)blockIdx.y * N * C;
+        box += (size_t)blockIdx.y * N * 4;
+        keep_idx = (const int*)((const char*)keep_idx + sh);
+        counters = (const int*)((const char*)counters + sh);
+        boxes_k = (float*)((char*)boxes_k + sh);
+        scores_t = (float*)((char*)scores_t + sh);
+    }
     extern __shared__ float tile[];  // [64][C]
     const int K = counters[0];
     const int k0 = blockIdx.x * 64;
@@ -379,7 +409,8 @@ __global__ __launch_bounds__(256) void k_decode_transpose(const float* __restric
 // ---------------------------------------------------------------------------------------------------
 // stage B: per-class top-k + IoU column test  (utils/output_utils.py:12-26)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_class_topk_iou(const NmsWs w, int N, int top_k, float iou_thre) {
+__global__ __launch_bounds__(NT) void k_class_topk_iou(const NmsWs w0, int N, int top_k, float iou_thre, size_t ws_stride) {
+    const NmsWs w = image_ws(w0, ws_stride, blockIdx.y);
     __shared__ TopkShared<TOPK_CAP> sh;
     __shared__ __attribute__((aligned(16))) float sbox[TOPK_CAP * 4];
     const int K = w.counters[0];
@@ -414,10 +445,21 @@ __global__ __launch_bounds__(NT) void k_class_topk_iou(const NmsWs w, int N, int
 // ---------------------------------------------------------------------------------------------------
 // stage C: global top max_det over the kept (class, rank) pairs + gather  (utils/output_utils.py:31-43)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_final_topk(const NmsWs w, int ncls, int max_det, const float* __restrict__ coef,
+__global__ __launch_bounds__(NT) void k_final_topk(const NmsWs w0, int ncls, int max_det, const float* __restrict__ coef,
                                                    int coef_dim, int32_t* __restrict__ out_count,
                                                    int64_t* __restrict__ out_ids, float* __restrict__ out_scores,
-                                                   float* __restrict__ out_boxes, float* __restrict__ out_coefs) {
+                                                   float* __restrict__ out_boxes, float* __restrict__ out_coefs, size_t ws_stride,
+                                                   int N) {
+    const NmsWs w = image_ws(w0, ws_stride, blockIdx.y);
+    {
+        const size_t b = blockIdx.y;                       // image b's outputs: [B][max_det] rows
+        coef += b * (size_t)N * coef_dim;
+        out_count += b;
+        out_ids += b * max_det;
+        out_scores += b * max_det;
+        out_boxes += b * (size_t)max_det * 4;
+        out_coefs += b * (size_t)max_det * coef_dim;
+    }
     __shared__ TopkShared<DET_CAP> sh;
     __shared__ int n_valid;
     const int tid = threadIdx.x;
@@ -644,14 +686,14 @@ int check_cfg(const ym_nms_cfg* cfg) {
 }
 
 int run_stage_a(const float* cls, const float* box, const float* anchors, const ym_nms_cfg* cfg, const NmsWs& w,
-                hipStream_t st) {
+                hipStream_t st, int B = 1, size_t ws_stride = 0) {
     const int N = cfg->num_anchors, C = cfg->num_classes;
     int g1 = ym_cdiv(N, 4);
     if (g1 > 2048) g1 = 2048;
-    hipLaunchKernelGGL(k_score_flag, dim3(g1), dim3(256), 0, st, cls, N, C, cfg->score_thre, w.flag);
-    hipLaunchKernelGGL(k_compact, dim3(1), dim3(NT), 0, st, w.flag, N, w.keep_idx, w.counters);
-    hipLaunchKernelGGL(k_decode_transpose, dim3(ym_cdiv(N, 64)), dim3(256), (size_t)64 * C * sizeof(float), st, cls, box,
-                       anchors, N, C, w.keep_idx, w.counters, w.boxes_k, w.scores_t);
+    hipLaunchKernelGGL(k_score_flag, dim3(g1, B), dim3(256), 0, st, cls, N, C, cfg->score_thre, w.flag, ws_stride);
+    hipLaunchKernelGGL(k_compact, dim3(1, B), dim3(NT), 0, st, w.flag, N, w.keep_idx, w.counters, ws_stride);
+    hipLaunchKernelGGL(k_decode_transpose, dim3(ym_cdiv(N, 64), B), dim3(256), (size_t)64 * C * sizeof(float), st, cls, box,
+                       anchors, N, C, w.keep_idx, w.counters, w.boxes_k, w.scores_t, ws_stride);
     return ym_check_launch("nms stage A");
 }
 
@@ -663,24 +705,42 @@ extern "C" size_t ym_nms_workspace_bytes(const ym_nms_cfg* cfg) {
     return w.bytes + greedy_extra_bytes(cfg->num_anchors, cfg->num_classes);
 }
 
+extern "C" size_t ym_nms_batch_workspace_bytes(const ym_nms_cfg* cfg, int B) {
+    if (check_cfg(cfg) != YM_OK || B < 1) return 0;
+    return align_up(carve(nullptr, cfg->num_anchors, cfg->num_classes).bytes) * (size_t)B;
+}
+
+extern "C" int ym_detect_fast_nms_batch(const float* class_pred, const float* box_pred, const float* coef_pred,
+                                        const float* anchors, const ym_nms_cfg* cfg, int B, int32_t* out_count, int64_t* out_ids,
+                                        float* out_scores, float* out_boxes, float* out_coefs, void* workspace,
+                                        size_t workspace_bytes, ym_stream_t s) {
+    int rc = check_cfg(cfg);
+    if (rc != YM_OK) return rc;
+    YM_REQUIRE(B >= 1 && B <= 65535, "fast_nms: batch must be 1..65535");
+    YM_REQUIRE(class_pred && box_pred && coef_pred && anchors && out_count && out_ids && out_scores && out_boxes &&
+                   out_coefs && workspace, "fast_nms: null pointer");
+    NmsWs w = carve(workspace, cfg->num_anchors, cfg->num_classes);
+    const size_t stride = align_up(w.bytes);
+    if (stride * (size_t)B > workspace_bytes && !(B == 1 && w.bytes <= workspace_bytes)) {
+        ym_set_error("fast_nms: workspace %zu < %zu", workspace_bytes, stride * (size_t)B);
+        return YM_ENOSPC;
+    }
+    hipStream_t st = (hipStream_t)s;
+    rc = run_stage_a(class_pred, box_pred, anchors, cfg, w, st, B, stride);
+    if (rc != YM_OK) return rc;
+    const int ncls = cfg->num_classes - 1;
+    hipLaunchKernelGGL(k_class_topk_iou, dim3(ncls, B), dim3(NT), 0, st, w, cfg->num_anchors, cfg->top_k, cfg->iou_thre, stride);
+    hipLaunchKernelGGL(k_final_topk, dim3(1, B), dim3(NT), 0, st, w, ncls, cfg->max_det, coef_pred, cfg->coef_dim, out_count,
+                       out_ids, out_scores, out_boxes, out_coefs, stride, cfg->num_anchors);
+    return ym_check_launch("fast_nms");
+}
+
 extern "C" int ym_detect_fast_nms(const float* class_pred, const float* box_pred, const float* coef_pred,
                                   const float* anchors, const ym_nms_cfg* cfg, int32_t* out_count, int64_t* out_ids,
                                   float* out_scores, float* out_boxes, float* out_coefs, void* workspace,
                                   size_t workspace_bytes, ym_stream_t s) {
-    int rc = check_cfg(cfg);
-    if (rc != YM_OK) return rc;
-    YM_REQUIRE(class_pred && box_pred && coef_pred && anchors && out_count && out_ids && out_scores && out_boxes &&
-                   out_coefs && workspace, "fast_nms: null pointer");
-    NmsWs w = carve(workspace, cfg->num_anchors, cfg->num_classes);
-    if (w.bytes > workspace_bytes) { ym_set_error("fast_nms: workspace %zu < %zu", workspace_bytes, w.bytes); return YM_ENOSPC; }
-    hipStream_t st = (hipStream_t)s;
-    rc = run_stage_a(class_pred, box_pred, anchors, cfg, w, st);
-    if (rc != YM_OK) return rc;
-    const int ncls = cfg->num_classes - 1;
-    hipLaunchKernelGGL(k_class_topk_iou, dim3(ncls), dim3(NT), 0, st, w, cfg->num_anchors, cfg->top_k, cfg->iou_thre);
-    hipLaunchKernelGGL(k_final_topk, dim3(1), dim3(NT), 0, st, w, ncls, cfg->max_det, coef_pred, cfg->coef_dim, out_count,
-                       out_ids, out_scores, out_boxes, out_coefs);
-    return ym_check_launch("fast_nms");
+    return ym_detect_fast_nms_batch(class_pred, box_pred, coef_pred, anchors, cfg, 1, out_count, out_ids, out_scores, out_boxes,
+                                    out_coefs, workspace, workspace_bytes, s);
 }
 
 extern "C" int ym_detect_greedy_nms(const float* class_pred, const float* box_pred, const float* coef_pred,

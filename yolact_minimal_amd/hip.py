@@ -21,7 +21,8 @@ ABI_SYMBOLS = (
     'ym_sizeof_conv_desc', 'ym_conv2d_workspace_bytes', 'ym_conv2d_tile_counters', 'ym_conv2d_fwd', 'ym_maxpool3x3s2_fwd', 'ym_bilinear2x_fwd',
     'ym_softmax_rows', 'ym_nms_workspace_bytes', 'ym_detect_fast_nms', 'ym_detect_greedy_nms',
     'ym_greedy_nms_workspace_bytes', 'ym_greedy_nms', 'ym_mask_assemble', 'ym_mask_resize_binarize',
-    'ym_boxes_to_pixels', 'ym_expf_cr',
+    'ym_boxes_to_pixels', 'ym_expf_cr', 'ym_nms_batch_workspace_bytes', 'ym_detect_fast_nms_batch', 'ym_after_nms_batch_workspace_bytes',
+    'ym_after_nms_batch',
     'ym_pack_conv_weight_dgrad', 'ym_pack_conv_weights_batch', 'ym_conv2d_wgrad_workspace_bytes', 'ym_conv2d_wgrad', 'ym_bn_train_fwd',
     'ym_val_preprocess', 'ym_layernorm', 'ym_patch_merge_layernorm', 'ym_swin_window_attention',
     'ym_mask_loss_workspace_bytes', 'ym_mask_loss_fwd_bwd', 'ym_mask_loss_batch_workspace_bytes', 'ym_mask_loss_batch',
@@ -128,6 +129,12 @@ def lib():
         L.ym_mask_resize_binarize.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
         L.ym_boxes_to_pixels.argtypes = [vp, vp, i32, f32, vp]
         L.ym_expf_cr.argtypes = [vp, vp, i64, vp]
+        L.ym_nms_batch_workspace_bytes.argtypes = [ctypes.POINTER(NmsCfg), i32]
+        L.ym_nms_batch_workspace_bytes.restype = sz
+        L.ym_detect_fast_nms_batch.argtypes = [vp, vp, vp, vp, ctypes.POINTER(NmsCfg), i32, vp, vp, vp, vp, vp, vp, sz, vp]
+        L.ym_after_nms_batch_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
+        L.ym_after_nms_batch_workspace_bytes.restype = sz
+        L.ym_after_nms_batch.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp]
         L.ym_pack_conv_weight_dgrad.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
         L.ym_pack_conv_weights_batch.argtypes = [vp, i32, i32, vp]
         L.ym_conv2d_wgrad_workspace_bytes.argtypes = [ctypes.POINTER(WgradDesc)]
