@@ -73,18 +73,21 @@ class Workload:
         cls, box, coef, proto = synth_head_outputs(n_anchors, num_classes=cfg.num_classes, proto_hw=img_size // 4,
                                                    seed=1)
         self.head = [t.to(device) for t in (cls, box, coef, proto)]
+        # batch > 1: the batched launch set (one image per grid row, one host read per batch) on B copies of the dense case
+        self.head_b = [t.expand(batch, *t.shape[1:]).contiguous() for t in self.head] if batch > 1 else None
         self.anchors = torch.tensor(net.anchors, dtype=torch.float32).reshape(-1, 4).to(device)
         self.engine = net._engine(self.img)
 
     def step(self):
-        from yolact_minimal_amd.utils.output_utils import nms, after_nms
+        from yolact_minimal_amd.utils.output_utils import nms, after_nms, nms_batch, after_nms_batch
         self.engine.run(self.img)
         if self.with_post:
-            cls, box, coef, proto = self.head
-            for _ in range(self.batch):
+            if self.batch > 1:
+                after_nms_batch(nms_batch(*self.head_b, self.anchors, self.cfg), 480, 640, self.cfg)
+            else:
+                cls, box, coef, proto = self.head
                 r = nms(cls, box, coef, proto, self.anchors, self.cfg)
                 after_nms(r[0], r[1], r[2], r[3], r[4], 480, 640, self.cfg)
-
 
 
 def timed(workload, steps, warmup, barrier):
@@ -136,6 +139,37 @@ def conv_roofline(engine, img, iters=5):
     flops = sum(c.flops for c in convs)
     layers = [dict(name=c.name, ms=per_layer[i] / iters, gflop=c.flops / 1e9) for i, c in enumerate(convs)]
     return flops, secs, len(convs), layers
+
+
+def post_bench(net, cfg, device, img_size, iters=30):
+    """nms and after_nms on the dense synthetic head outputs (17.8 k candidates -> 100 detections), timed with HIP events on the
+    launch stream.  after_nms is HBM-bound on its output: n * img_h * img_w * 4 bytes written once (123 MB at 100 x 480 x 640)."""
+    from yolact_minimal_amd.utils.output_utils import nms, after_nms, nms_batch, after_nms_batch
+    from yolact_minimal_amd.utils.synthetic import synth_head_outputs
+    n_anchors = len(net.anchors) // 4
+    head = [t.to(device) for t in synth_head_outputs(n_anchors, num_classes=cfg.num_classes, proto_hw=img_size // 4, seed=1)]
+    anchors = torch.tensor(net.anchors, dtype=torch.float32).reshape(-1, 4).to(device)
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    out = {}
+    for b in (1, 8):
+        hb = [t.expand(b, *t.shape[1:]).contiguous() for t in head]
+        t_nms = t_after = 0.0
+        for it in range(iters + 3):
+            e[0].record()
+            dets = nms_batch(*hb, anchors, cfg)
+            e[1].record()
+            r = after_nms_batch(dets, 480, 640, cfg, sync=False)
+            e[2].record()
+            torch.cuda.synchronize()
+            if it >= 3:
+                t_nms += e[0].elapsed_time(e[1])
+                t_after += e[1].elapsed_time(e[2])
+        n_det = int(r[4].sum())
+        nbytes = n_det * 480 * 640 * 4
+        t_nms, t_after = t_nms / iters * 1e-3, t_after / iters * 1e-3
+        out[f'bs{b}'] = dict(detections=n_det, nms_us=round(t_nms * 1e6, 1), after_nms_us=round(t_after * 1e6, 1),
+                             after_nms_gbs=round(nbytes / t_after / 1e9, 1), after_nms_frac_hbm_peak=round(nbytes / t_after / 1e9 / HBM_PEAK_GBS, 4))
+    return out
 
 
 def eval_metrics_bench(device, n=100, g=15, h=480, w=640, iters=20, cpu=True):
@@ -404,6 +438,7 @@ def main():
                                               forward_tflops=round(fl2 / tf2 / 1e12, 2),
                                               frac_f32_mfma_peak=round(fl2 / tf2 / 1e12 / F32_MFMA_PEAK_TFLOPS, 4))
         if not args.no_extra and world == 1:
+            extra['post'] = post_bench(net, cfg, device, args.img_size)
             extra['eval_metrics'] = eval_metrics_bench(device, cpu=not args.no_cpu_baseline)
             extra['train_aug'] = train_aug_bench(device, cpu=not args.no_cpu_baseline)
             extra['ann_to_mask'] = ann_to_mask_bench(device, cpu=not args.no_cpu_baseline)
@@ -414,12 +449,15 @@ def main():
                                                             local_rank, device, lambda: None)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args.cfg, args.img_size)
-            # the same sample on 8 threads (comparable with the survey's 8-vCPU probes) and BASELINE.json config 1
-            # (res50_coco bs=1 on the CPU path); bounded to a few seconds each
-            cpu['threads8'] = cpu_baseline(args.cfg, args.img_size, threads=8, budget_s=5.0, max_img=4)
-            cpu['res50_coco'] = cpu_baseline('res50_coco', args.img_size, budget_s=5.0, max_img=4)
-            cpu['res50_coco_threads8'] = cpu_baseline('res50_coco', args.img_size, threads=8, budget_s=5.0, max_img=4)
+            # the oracle's throughput depends on the thread count (128 threads on a 256-cpu shared host are SLOWER than 8: the
+            # layers are too small to split that far), so the sample is taken at 8 / 32 / all threads and the best one is `value`;
+            # 8 threads is also SURVEY §8d's comparison point with the 8-vCPU survey probes.  BASELINE.json config 1
+            # (res50_coco bs=1 on the CPU path) is measured the same way.
+            runs = {t: cpu_baseline(args.cfg, args.img_size, threads=t, budget_s=4.0, max_img=4) for t in (8, 32, None)}
+            cpu = dict(max(runs.values(), key=lambda r: r['value']))
+            cpu['by_threads'] = {str(r['cores']): r['value'] for r in runs.values()}
+            r50 = [cpu_baseline('res50_coco', args.img_size, threads=t, budget_s=4.0, max_img=4) for t in (8, 32)]
+            cpu['res50_coco'] = max(r50, key=lambda r: r['value'])
         extra['train'] = train
         primary_train = args.mode == 'train' and train is not None
         out = {
