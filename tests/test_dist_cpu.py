@@ -112,8 +112,20 @@ def test_lr_schedule_matches_reference_formula():
     from yolact_minimal_amd.trainer import lr_at
     cfg = build_cfg('res101_coco', 'train', 544, train_bs=16, bs_per_gpu=8)
     assert cfg.lr == pytest.approx(0.002) and cfg.lr_steps[1] == 140000
-    assert lr_at(cfg, 0) == pytest.approx(cfg.warmup_init)
+    assert lr_at(cfg, 0) == pytest.approx(cfg.lr)                   # 0 is in lr_steps: the reference trains step 0 at the full rate
+    assert lr_at(cfg, 1) == pytest.approx((cfg.lr - cfg.warmup_init) / 500 + cfg.warmup_init)
     assert lr_at(cfg, 250) == pytest.approx((cfg.lr - cfg.warmup_init) * 0.5 + cfg.warmup_init)
     assert lr_at(cfg, 501) == pytest.approx(cfg.lr)
     assert lr_at(cfg, 140000) == pytest.approx(cfg.lr * 0.1)
     assert lr_at(cfg, 280001) == pytest.approx(cfg.lr * 0.01)
+
+    # against a literal simulation of the reference loop's stateful updates (train.py:103-109), incl. an lr_step inside the warm-up
+    class C:
+        lr, warmup_init, warmup_until, lr_steps = 0.01, 0.001, 50, (0, 20, 80, 120)
+    lr = C.lr
+    for step in range(200):
+        if C.warmup_until > 0 and step <= C.warmup_until:
+            lr = (C.lr - C.warmup_init) * (step / C.warmup_until) + C.warmup_init
+        if step in C.lr_steps:
+            lr = C.lr * 0.1 ** C.lr_steps.index(step)
+        assert lr_at(C, step) == pytest.approx(lr), step

@@ -689,6 +689,32 @@ def test_two_rank_training_keeps_replicas_identical(cfg_name):
     assert ' OK ' in line and 'world 2' in line, line
 
 
+def test_gradient_buckets_are_reduced_while_backward_is_still_running():
+    """res101_coco at 256 px under torch.distributed.run with backend nccl (= RCCL; one rank, the only RCCL configuration a 1-GPU
+    box allows): the 200 MB of gradients form >= 3 buckets, and every bucket but the last is handed to `all_reduce(async_op=True)`
+    from a gradient hook DURING backward — the first one before half of the parameters have produced their gradient — i.e. the
+    collective stream gets its work while dgrad / wgrad kernels are still being enqueued.  (What a 1-GPU box cannot show: the
+    RCCL kernels themselves.  With one rank RCCL has nothing to exchange and launches none, so there is no second-stream kernel
+    to see in a trace; the 2/4/8-GPU overlap stays unmeasured until the driver's multi-GPU run.)"""
+    import json
+    import subprocess
+    import sys
+    from tests.conftest import REPO
+    env = dict(os.environ, YM_FORCE_DIST='1', YM_CHECK_CFG='res101_coco', YM_CHECK_SIZE='256', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('YM_DIST_BACKEND', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', '29547', os.path.join(REPO, 'tools', 'ddp_check.py')]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith('DDP_LAUNCH_LOG')][-1].split(' ', 1)[1])
+    assert rec['backend'] == 'nccl' and rec['buckets'] >= 3, rec
+    log = rec['log']
+    assert [b for b, _, _ in log] == list(range(rec['buckets']))            # bucket order = the order every rank uses
+    in_backward = [e for e in log if not e[2]]
+    assert len(in_backward) >= rec['buckets'] - 1, log                        # at most the last bucket waits for finish()
+    assert log[0][1] < 0.5 * rec['params'], log                               # first message leaves with most of backward ahead
+
+
 def test_bench_two_ranks_control_flow():
     """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one JSON line from rank 0, barrier + MAX over
     ranks, whole-job img/s), with gloo so that both ranks can share this box's GPU: inference replicas + the 2-rank training leg."""

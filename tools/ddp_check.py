@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle.yolact_ref import synth_targets  # noqa: E402  (input generator)
+from yolact_minimal_amd.utils.synthetic import synth_targets  # noqa: E402
 from yolact_minimal_amd.config import build_cfg  # noqa: E402
 from yolact_minimal_amd.modules.yolact import Yolact  # noqa: E402
 from yolact_minimal_amd.trainer import Trainer, init_distributed  # noqa: E402
@@ -21,13 +21,14 @@ def main():
     dev = torch.device('cuda', local_rank % ndev)
     torch.cuda.set_device(dev)
     name = os.environ.get('YM_CHECK_CFG', 'res50_coco')
-    cfg = build_cfg(name, 'train', 128, train_bs=2 * world, bs_per_gpu=2)
+    size = int(os.environ.get('YM_CHECK_SIZE', '128'))
+    cfg = build_cfg(name, 'train', size, train_bs=2 * world, bs_per_gpu=2)
     torch.manual_seed(100 + rank)                       # DIFFERENT initial weights per rank: the trainer must broadcast rank 0's
     tr = Trainer(Yolact(cfg), cfg, dev, world, local_rank % ndev)
     for blk in (b for l in getattr(tr.net.backbone, 'layers', []) for b in getattr(l, 'blocks', [])):
         blk.drop_prob = 0.0                             # (Swin) DropPath masks are per-rank random numbers
-    img = torch.randn(2, 3, 128, 128, generator=torch.Generator().manual_seed(7 + rank)).to(dev)
-    boxes, masks = synth_targets(2, 128, seed=50 + 10 * rank)
+    img = torch.randn(2, 3, size, size, generator=torch.Generator().manual_seed(7 + rank)).to(dev)
+    boxes, masks = synth_targets(2, size, seed=50 + 10 * rank)
     boxes, masks = [b.to(dev) for b in boxes], [m.to(dev) for m in masks]
     losses = None
     for _ in range(3):
@@ -44,6 +45,10 @@ def main():
     if rank == 0:
         print('DDP_CHECK', 'OK' if ok else 'MISMATCH', 'world', world, 'launches', tr.reducer.launches if tr.reducer else None,
               'buckets', len(tr.reducer.buckets) if tr.reducer else None, [g.tolist() for g in gathered])
+        if tr.reducer:
+            import json
+            print('DDP_LAUNCH_LOG', json.dumps(dict(params=len(tr.opt.params), buckets=len(tr.reducer.buckets), backend=dist.get_backend(),
+                                                    log=tr.reducer.last_launch_log)))
     dist.barrier()
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)

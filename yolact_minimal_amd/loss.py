@@ -105,6 +105,22 @@ class _MaskLossFn(torch.autograd.Function):
 
 MAX_MASKS_PER_IMAGE = 128        # positives per image the mask-loss kernel holds (cfg.masks_to_train = 100)
 
+_mask_generators = {}
+
+
+def mask_generator(device):
+    """The mask-loss sub-sampling has its OWN device generator (seeded from torch's seed at first use, part of the trainer's
+    checkpoint): the reference draws its `randperm` from the CPU generator and only for images over the cap, so a sub-sampling
+    draw must not advance the stream Swin's DropPath uses (`torch.rand` on the default device generator)."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    g = _mask_generators.get(key)
+    if g is None:
+        g = _mask_generators[key] = torch.Generator(device=device)
+        g.manual_seed((torch.initial_seed() + 0x5EED) % (2 ** 63))
+    return g
+
+
 
 def lincomb_mask_loss(cfg, pos, anchor_gt, coef_p, proto_p, mask_gt, anchor_box, num_pos=None):
     """`num_pos`: int32 device tensor [n_0..n_{B-1}, total] of positive counts (`ym_class_box_loss` produces it); computed here
@@ -121,7 +137,7 @@ def lincomb_mask_loss(cfg, pos, anchor_gt, coef_p, proto_p, mask_gt, anchor_box,
         raise RuntimeError(f'cfg.masks_to_train = {cfg.masks_to_train}: the mask-loss kernel holds at most {MAX_MASKS_PER_IMAGE} '
                            f'positives per image (the reference default is 100)')
     cap = min(int(cfg.masks_to_train), n)
-    keys = torch.rand(b, n, device=dev).masked_fill_(~pos, -1.0)
+    keys = torch.rand(b, n, device=dev, generator=mask_generator(dev)).masked_fill_(~pos, -1.0)
     idx = keys.topk(cap, dim=1).indices.contiguous()          # the positives (random order) come first; the rest is never read
     ds_masks = []
     for i in range(b):

@@ -34,14 +34,22 @@ def init_distributed(backend=None):
 
 
 def lr_at(cfg, step):
-    """LR schedule of the reference loop (train.py:103-109): linear warm-up to `warmup_until`, x0.1 at each lr_step."""
-    lr = cfg.lr
-    if cfg.warmup_until > 0 and step <= cfg.warmup_until:
+    """Learning rate the reference loop has in force at `step` (train.py:103-109), stateless.  The reference keeps the rate in the
+    optimizer and overwrites it on two events: every step <= warmup_until sets the linear warm-up value, and then — in the same
+    iteration, so it wins — a step listed in cfg.lr_steps sets cfg.lr * 0.1**index.  Consequences kept here: step 0 trains at the
+    FULL cfg.lr (0 is in lr_steps), an lr_step inside the warm-up window applies for that one step, and after the warm-up the
+    rate is whatever the most recent event left."""
+    steps = list(cfg.lr_steps)
+    if step in steps:
+        return cfg.lr * 0.1 ** steps.index(step)
+    warm = cfg.warmup_until > 0
+    if warm and step <= cfg.warmup_until:
         return (cfg.lr - cfg.warmup_init) * (step / cfg.warmup_until) + cfg.warmup_init
-    for i, s in enumerate(cfg.lr_steps):
-        if step >= s:
-            lr = cfg.lr * 0.1 ** i
-    return lr
+    past = [s for s in steps if s <= step]
+    last = max(past) if past else None
+    if warm and (last is None or last < cfg.warmup_until):
+        return (cfg.lr - cfg.warmup_init) * 1.0 + cfg.warmup_init          # the value the last warm-up step (warmup_until) set
+    return cfg.lr * 0.1 ** steps.index(last) if last is not None else cfg.lr
 
 
 def shard_batch(global_batch, rank, world):
@@ -107,7 +115,20 @@ class FlatSGD:
             p._ym_grad_slot.copy_(g)
         p._ym_in_slot = True
 
+    def check_storage(self):
+        """The parameters must still BE the flat buffer: `net.to(device)`, `.half()`, `.double()` after the trainer was built
+        re-allocate parameter storage (Module._apply), after which this optimizer would step an orphaned buffer and the wgrad
+        kernels would write stale slots — fail loudly instead."""
+        base = self.flat.data_ptr()
+        for p, (a, _) in zip(self.params, self.offsets):
+            if p.data_ptr() != base + 4 * a:
+                raise RuntimeError('a parameter no longer aliases the optimizer\'s flat buffer (was the module moved / cast after the '
+                                   'Trainer was created?): build the Trainer after .to(device) and do not re-allocate parameters')
+
     def step(self):
+        """(Deviation from torch.optim.SGD, irrelevant for YOLACT where every parameter receives a gradient each step: a parameter
+        whose grad is None is treated as a zero gradient — it still gets weight decay and momentum — where torch skips it.)"""
+        self.check_storage()
         for p in self.params:
             self.gather(p)
         hip.check(hip.lib().ym_sgd_step(hip.ptr(self.flat), hip.ptr(self.grad), hip.ptr(self.buf), self.flat.numel(),
@@ -129,6 +150,7 @@ class FlatAdamW(FlatSGD):
         self.exp_avg_sq = torch.zeros_like(self.flat)          # `buf` is exp_avg
 
     def step(self):
+        self.check_storage()
         for p in self.params:
             self.gather(p)
         self.steps += 1
@@ -176,6 +198,9 @@ class FlatGradReducer:
         self.pending = [len(idx) for _, _, idx in self.buckets]
         self.next_bucket = 0
         self.works = []
+        self.grads_seen = 0
+        self.in_finish = False
+        self.launch_log = []        # per step: (bucket, gradients produced when it was launched, launched by finish()?)
 
     def _make_hook(self, i):
         def hook(p):
@@ -184,6 +209,7 @@ class FlatGradReducer:
                 p.grad = p._ym_grad_slot.view_as(p._ym_grad_slot)     # the reduced value is what the caller must see
             b = self.bucket_of[i]
             self.pending[b] -= 1
+            self.grads_seen += 1
             self._launch_ready()
         return hook
 
@@ -192,12 +218,14 @@ class FlatGradReducer:
             a, e, _ = self.buckets[self.next_bucket]
             op = dist.ReduceOp.AVG if self.avg_op else dist.ReduceOp.SUM
             self.works.append(dist.all_reduce(self.opt.grad[a:e], op=op, group=self.group, async_op=True))
+            self.launch_log.append((self.next_bucket, self.grads_seen, self.in_finish))
             self.launches += 1
             self.next_bucket += 1
 
     def finish(self):
         """After backward: reduce what is left (parameters that received no gradient count as zeros), wait for every
         bucket, and leave the AVERAGED gradients in the flat buffer."""
+        self.in_finish = True
         for b in range(self.next_bucket, len(self.buckets)):
             for i in self.buckets[b][2]:
                 p = self.opt.params[i]
@@ -209,6 +237,7 @@ class FlatGradReducer:
             w.wait()
         if not self.avg_op and self.world > 1:
             self.opt.grad.mul_(1.0 / self.world)
+        self.last_launch_log = self.launch_log
         self.reset()
 
 
@@ -279,7 +308,12 @@ class Trainer:
                 'exp_avg_sq': self.opt.exp_avg_sq.detach().clone() if hasattr(self.opt, 'exp_avg_sq') else None,
                 'param_numel': [p.numel() for p in self.opt.params],
                 # generator states: DropPath and the mask-loss sub-sampling draw from the device generator
-                'cuda_rng': torch.cuda.get_rng_state(self.device), 'cpu_rng': torch.get_rng_state()}
+                'cuda_rng': torch.cuda.get_rng_state(self.device), 'cpu_rng': torch.get_rng_state(),
+                # the augmentation decisions (`train_aug`) draw from python's `random`; the saving rank is recorded so that the
+                # other ranks can derive their own streams on resume (a shared state would give every rank identical DropPath
+                # masks and mask-loss sub-samples)
+                'py_random': __import__('random').getstate(), 'rank': dist.get_rank() if dist.is_initialized() else 0,
+                'mask_rng': __import__('yolact_minimal_amd.loss', fromlist=['x']).mask_generator(self.device).get_state()}
 
     def load_state_dict(self, state):
         if state['param_numel'] != [p.numel() for p in self.opt.params]:
@@ -298,6 +332,21 @@ class Trainer:
         if state.get('cuda_rng') is not None:
             torch.cuda.set_rng_state(state['cuda_rng'].cpu(), self.device)
             torch.set_rng_state(state['cpu_rng'].cpu())
+            import random
+            if state.get('py_random') is not None:
+                random.setstate(state['py_random'])
+            rank = dist.get_rank() if dist.is_initialized() else 0
+            if state.get('mask_rng') is not None:
+                from .loss import mask_generator
+                mask_generator(self.device).set_state(state['mask_rng'].cpu())
+            if rank != int(state.get('rank', 0)):
+                # a different rank than the one that saved: same checkpoint, its OWN random streams (deterministic in step and rank)
+                seed = (int(state['step_idx']) * 1000003 + 7919 * rank + 12345) % (2 ** 31)
+                torch.cuda.manual_seed(seed)
+                torch.manual_seed(seed)
+                random.seed(seed)
+                from .loss import mask_generator
+                mask_generator(self.device).manual_seed(seed + 1)
         self.net.mark_weights_changed()
         weights_changed()
 

@@ -288,7 +288,7 @@ class BatchLoader:
     ahead on `threads` host threads, `dataset.finish` (HIP launches, `random` draws) in sample order on the caller's thread,
     collated by `collate_fn`."""
 
-    def __init__(self, dataset, batch_size, collate_fn, shuffle=False, rank=0, world_size=1, seed=0, threads=4, drop_last=True):
+    def __init__(self, dataset, batch_size, collate_fn, shuffle=False, rank=0, world_size=1, seed=0, threads=4, drop_last=False):
         self.dataset, self.batch_size, self.collate_fn = dataset, batch_size, collate_fn
         self.shuffle, self.rank, self.world_size, self.seed, self.threads, self.drop_last = shuffle, rank, world_size, seed, threads, drop_last
         self.epoch = 0
