@@ -101,6 +101,11 @@ typedef struct {
     int32_t tail_tiles;      /* workgroup-quantisation fix (needs tile_counters, ksplit <= 1, plain NHWC output): the   */
     int32_t tail_ksplit;     /* LAST tail_tiles output tiles are each split into tail_ksplit K slices, so that e.g. 580  */
                              /* tiles on 256 CUs become 512 whole tiles + 68x4 quarter tiles instead of 2-or-3 per CU.   */
+    int32_t mma;             /* matrix pipe of the workgroup kernel.  0 = f32 MFMA (v_mfma_f32_32x32x2_f32: exact fp32 products, the    */
+                             /* parity mode).  3 / 6 = "split bf16": every fp32 operand is split on its way into LDS into two / three  */
+                             /* bf16 terms and the 3 / 6 most significant cross products run on v_mfma_f32_32x32x16_bf16 with fp32     */
+                             /* accumulation (relative error per product ~2^-17 / ~2^-23; tensors in HBM stay fp32).  Needs Cin % 32   */
+                             /* == 0, kwaves == 0, no pyramid input; stages is ignored (register-staged double buffer).               */
 } ym_conv_desc;
 
 /* y = act(conv(x, w) * scale + shift + residual), one launch (plus a reduce launch if K is split).

@@ -366,7 +366,8 @@ def test_val_aug_preprocess(h, w, dtype):
 
 
 @pytest.mark.parametrize('tile,ksplit,stages,tail', [((64, 64), 1, 22, (50, 2)), ((64, 64), 1, 22, (0, 0)), ((64, 64), 4, 22, (0, 0)),
-                                                     ((64, 64), 3, 0, (0, 0)), ((128, 64), 1, 23, (37, 3)), ((64, 64), 1, 34, (0, 0))])
+                                                     ((64, 64), 3, 0, (0, 0)), ((128, 64), 1, 23, (37, 3)), ((64, 64), 1, 34, (0, 0)),
+                                                     ((128, 128), 1, 103, (0, 0)), ((64, 64), 2, 103, (50, 2)), ((128, 64), 1, 106, (0, 0))])
 def test_conv_launches_are_race_free(tile, ksplit, stages, tail):
     """400 back-to-back launches of a chip-filling shape (2610 tiles: the Swin-T bs=8 qkv conv, M9248_N1152_C384) must all be
     bit-identical, and equal to the plain launch of the same tile up to the association of the K sum.  Regression test for two
@@ -394,7 +395,9 @@ def test_conv_launches_are_race_free(tile, ksplit, stages, tail):
     ws = torch.empty(1 << 28, dtype=torch.uint8, device=dev)
     hip.conv2d_fwd(d, ws)
     want = out.clone()
-    d.ksplit, d.stages = ksplit, stages
+    d.ksplit, d.stages = ksplit, stages % 100
+    if stages >= 100:                               # 103 / 106: split-bf16 x3 / x6 (register staging)
+        d.mma, d.stages = stages - 100, 0
     d.tail_tiles, d.tail_ksplit = tail
     assert hip.conv_workspace_bytes(d) <= ws.numel()
     hip.conv2d_fwd(d, ws)
@@ -406,4 +409,4 @@ def test_conv_launches_are_race_free(tile, ksplit, stages, tail):
     bad = int(bad_t)
     assert bad == 0, f'{bad} launches differed from the first one'
     assert int(counters.abs().sum()) == 0                                     # arrival counters left at zero
-    torch.testing.assert_close(first, want, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(first, want, rtol=1e-5, atol=1e-5 if d.mma != 3 else 1e-4)

@@ -129,6 +129,19 @@ def test_swin_forward_544_bs8_digest_under_the_tuned_plan(golden_dir, graph, mon
     check_bs8_digest(g, out, sum(1 for c in eng.convs if c.sig in tuned_table()))
 
 
+def test_swin_forward_544_bs8_split_bf16x3_holds_the_1e4_bar(golden_dir, monkeypatch):
+    from tests.test_gpu_forward import check_bs8_digest
+    monkeypatch.setenv('YM_CONV_MMA', '3')
+    g = np.load(os.path.join(golden_dir, 'forward_swin_tiny_coco_544_b8_digest.npz'))
+    seed = int(g['seed'])
+    net, cfg = _make_swin(544, seed)
+    img = torch.randn(8, 3, 544, 544, generator=torch.Generator().manual_seed(seed + 300))
+    net = net.to(DEV)
+    with torch.no_grad():
+        out = net(img.to(DEV))
+    check_bs8_digest(g, out, 1)
+
+
 # ---- training (backward kernels, AdamW) ---------------------------------------------------------------------------------
 def test_layernorm_gelu_merge_backward():
     from yolact_minimal_amd.swin_train import LayerNormFn, PatchMergeLNFn, GeluFn

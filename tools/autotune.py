@@ -19,6 +19,7 @@ def main():
     ap.add_argument('--cfgs', default='res101_coco,res50_coco,swin_tiny_coco')
     ap.add_argument('--batches', default='1,8')
     ap.add_argument('--iters', type=int, default=10)
+    ap.add_argument('--mma', type=int, default=0, help='0: f32 MFMA; 3 / 6: split-bf16 (entries get the suffix _mma3 / _mma6)')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     table, detail = {}, {}
@@ -27,7 +28,7 @@ def main():
         for b in (int(x) for x in args.batches.split(',')):
             img = torch.randn(b, 3, 544, 544, device=dev)
             eng = net._engine(img)
-            res = eng.autotune(args.iters, verbose=True)
+            res = eng.autotune(args.iters, verbose=True, mma=args.mma)
             for k, v in res.items():
                 if k not in table:
                     table[k] = v[:7]

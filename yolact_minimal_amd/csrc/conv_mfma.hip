@@ -67,14 +67,23 @@ __device__ __forceinline__ void buf_st16_sc1(__amdgpu_buffer_rsrc_t r, unsigned 
 // early: ring of NS >= 3 with NS-2 tiles still in flight), so the dependent MFMA chain of a wave never waits on LDS or on the
 // barrier round trip: measured 1500 -> ~1100 cycles per K tile for a workgroup that has its CU to itself (the bs=1 regime).
 // RG: pyramid input (ym_conv_desc.nlevels): every staging row carries its own map size.
-template <int BM, int BN, int MODE, int NS, bool DL = false, bool PF = false, bool RG = false>
+// SPL ("split bf16", ym_conv_desc.mma = 3 / 6): the products run on the bf16 MFMA (v_mfma_f32_32x32x16_bf16, 16x the f32 pipe's
+// rate) with every fp32 operand split, while it is staged into LDS, into SPL bf16 planes x = p0 + p1 (+ p2)
+// (p0 = bf16(x), p1 = bf16(x - p0), ...: 16 resp. 24 significant bits) and the cross terms of significance >= 2^-16 resp. 2^-24
+// summed in the fp32 accumulator: SPL = 2 -> 3 MFMAs per product ("bf16x3", relative error ~2^-17 per product), SPL = 3 -> 6 MFMAs
+// ("bf16x6", fp32-grade).  Tensors in HBM stay fp32; only the register-staged double buffer exists in this mode.
+template <int BM, int BN, int MODE, int NS, bool DL = false, bool PF = false, bool RG = false, int SPL = 0>
 __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
+    static_assert(SPL == 0 || (SPL <= 3 && !DL && !PF && (NS == 2 || NS == 3) && MODE != 1), "split-bf16: register staging, Cin % 32 == 0");
+    constexpr int LB = SPL ? 2 : NS;            // LDS buffers (split mode: always two; NS = 3 there means two REGISTER sets)
     constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave (wave tile = BM/2 x BN/2)
     constexpr int AR = BM / 32, BR = BN / 32;   // staging rows per thread
-    constexpr int RP = DL ? 32 : PITCH;         // LDS row pitch in floats
+    constexpr int BP = 40;                      // split mode: LDS row pitch of one bf16 plane, in bf16 (80 B: 16 rows of a
+                                                // ds_read_b128 phase fall into 16 distinct 16-byte bank groups)
+    constexpr int RP = SPL ? (SPL * BP) / 2 : (DL ? 32 : PITCH);   // LDS floats per tile row (split: SPL planes of BP bf16, stored plane-major)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                         // [NS][BM][RP]
-    float* Bs = smem + NS * BM * RP;          // [NS][BN][RP]
+    float* Bs = smem + LB * BM * RP;          // [LB][BN][RP]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -228,10 +237,37 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
         gather_tile(kt, [&](int i, unsigned off) { rA[SET][DL ? 0 : i] = buf_ld16(rs_in, off); },
                     [&](int i, unsigned off) { rB[SET][DL ? 0 : i] = buf_ld16(rs_w, off); });
     };
+    // split mode: 4 floats -> SPL x 4 bf16 (round to nearest even; the residual of each step is exact in fp32)
+    auto split_store = [&](unsigned short* row, const f32x4 v, int plane_stride) {
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        f32x4 r = v;
+#pragma unroll
+        for (int pl = 0; pl < (SPL ? SPL : 1); ++pl) {
+            const unsigned p01 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{r[0], r[1]}, bf16x2_t));
+            const unsigned p23 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{r[2], r[3]}, bf16x2_t));
+            *reinterpret_cast<uint2*>(row + pl * plane_stride) = uint2{p01, p23};
+            if (pl + 1 < SPL) {
+                r[0] -= __uint_as_float(p01 << 16);
+                r[1] -= __uint_as_float(p01 & 0xFFFF0000u);
+                r[2] -= __uint_as_float(p23 << 16);
+                r[3] -= __uint_as_float(p23 & 0xFFFF0000u);
+            }
+        }
+    };
     auto store_tile = [&](int buf, auto set_c) {
         constexpr int SET = decltype(set_c)::value;
         float* a = As + buf * BM * RP;
         float* b = Bs + buf * BN * RP;
+        if constexpr (SPL > 0) {
+#pragma unroll
+            for (int i = 0; i < AR; ++i)
+                split_store(reinterpret_cast<unsigned short*>(a) + (rbase + 32 * i) * BP + c4 * 4, rA[SET][i], BM * BP);
+#pragma unroll
+            for (int i = 0; i < BR; ++i)
+                split_store(reinterpret_cast<unsigned short*>(b) + (rbase + 32 * i) * BP + c4 * 4, rB[SET][i], BN * BP);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < AR; ++i)
             *reinterpret_cast<f32x4*>(a + (rbase + 32 * i) * RP + c4 * 4) = rA[SET][DL ? 0 : i];
@@ -259,7 +295,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
     // other through the accumulator: measured ~88 cycles per dependent v_mfma_f32_32x32x2 (64 of work + a forwarding bubble),
     // i.e. 1400 instead of 1024 cycles per K tile when the wave has its SIMD to itself (the bs=1 regime).  Two accumulators that
     // take alternate K steps make consecutive MFMAs independent; they are summed once after the K loop.
-    constexpr bool DUAL = TM * TN == 1;
+    constexpr bool DUAL = TM * TN == 1 && SPL == 0;
     f32x16 acc_odd;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc_odd[r] = 0.f;
@@ -272,6 +308,38 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
     for (int g = 0; g < 4; ++g) goff[g] = DL ? (((2 * g + khalf) ^ ((frag_row >> 1) & 7)) * 4) : (g * 8 + khalf * 4);
 
     auto compute = [&](int buf) {
+        if constexpr (SPL > 0) {
+            // bf16 32x32x16: lane l supplies A[i = l & 31][k = 8 * (l >> 5) .. + 7] of a 16-deep block: one ds_read_b128 per plane
+            typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+            // LDS image (plane-major): [plane][row][BP] bf16, row pitch 80 B
+            const unsigned short* a = reinterpret_cast<const unsigned short*>(As + buf * BM * RP) + (wm * (BM / 2) + frag_row) * BP + khalf * 8;
+            const unsigned short* b = reinterpret_cast<const unsigned short*>(Bs + buf * BN * RP) + (wn * (BN / 2) + frag_row) * BP + khalf * 8;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                bf16x8_t fa[TM][SPL], fb[TN][SPL];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < SPL; ++pl)
+                        fa[i][pl] = *reinterpret_cast<const bf16x8_t*>(a + i * 32 * BP + pl * BM * BP + kb * 16);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < SPL; ++pl)
+                        fb[j][pl] = *reinterpret_cast<const bf16x8_t*>(b + j * 32 * BP + pl * BN * BP + kb * 16);
+                // cross terms by rising significance (pa + pb = SPL-1 ... 0): the small ones enter the accumulator first
+#pragma unroll
+                for (int sig = SPL - 1; sig >= 0; --sig)
+#pragma unroll
+                    for (int pa = 0; pa <= sig; ++pa)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa], fb[j][sig - pa], acc[i][j], 0, 0, 0);
+            }
+            return;
+        }
         const float* a = As + buf * BM * RP + a_frag_off;
         const float* b = Bs + buf * BN * RP + b_frag_off;
 #pragma unroll
@@ -418,18 +486,33 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
         __syncthreads();
         YM_STAMP(1);
         int buf = 0;
+        // split mode: the conversion VALU of store_tile (its operands arrived an iteration ago) is interleaved with compute's
+        // MFMAs — a bf16 MFMA occupies the matrix pipe for 32 cycles and ~5 other instructions issue for free in that shadow
+        auto interleave = [&]() {
+            if constexpr (SPL > 0) {
+                constexpr int NMFMA = TM * TN * 2 * (SPL == 2 ? 3 : 6);
+                constexpr int VPER = (SPL == 2 ? 12 : 24) * (AR + BR) / NMFMA + 1;     // conversion VALU per MFMA
+#pragma unroll
+                for (int g = 0; g < NMFMA; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, VPER, 0);   // a few VALU
+                }
+            }
+        };
         for (int t = 0; t < nt; t += 2) {
             load_tile(kt_beg + t + 2, I0{});
             compute(buf);
-            int nb = buf == 2 ? 0 : buf + 1;
+            int nb = buf == LB - 1 ? 0 : buf + 1;
             store_tile(nb, I1{});            // past-the-end tiles are zeros: harmless, keeps the body branch-free
+            interleave();
             __syncthreads();
             buf = nb;
             if (t + 1 >= nt) break;
             load_tile(kt_beg + t + 3, I1{});
             compute(buf);
-            nb = buf == 2 ? 0 : buf + 1;
+            nb = buf == LB - 1 ? 0 : buf + 1;
             store_tile(nb, I0{});
+            interleave();
             __syncthreads();
             buf = nb;
         }
@@ -497,7 +580,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
             }
             if (!fused) return;                    // the host launches conv_splitk_reduce
             // the last workgroup to arrive at this output tile owns the reduction + epilogue
-            __shared__ int s_last;
+            // the "I am last" flag lives in the (now dead) staging area instead of a second __shared__ object: 16 static bytes on
+            // top of 2 x 80 KB of dynamic LDS would cost the split-bf16 128x128 kernel its second workgroup per CU
+            int& s_last = *reinterpret_cast<int*>(smem);          // (C was consumed before the barrier below; nobody reads it again here)
             // EVERY writing wave drains its own slice stores before the barrier: __syncthreads() is a workgroup-scope fence and
             // on gfx950 that is `s_waitcnt lgkmcnt(0); s_barrier` only — it does NOT wait for outstanding global stores (vmcnt),
             // so without this line the arrival count below could overtake a slice that is still in flight and the last
@@ -767,18 +852,32 @@ int make_plan(const ym_conv_desc* d, Plan* pl) {
     return YM_OK;
 }
 
-template <int BM, int BN, int MODE, int NS = 2, bool DL = false, bool PF = false, bool RG = false>
+template <int BM, int BN, int MODE, int NS = 2, bool DL = false, bool PF = false, bool RG = false, int SPL = 0>
 void launch(const ConvP& p, int grid, hipStream_t st) {
-    size_t lds = (size_t)NS * (BM + BN) * (DL ? 32 : PITCH) * sizeof(float);
+    size_t lds = SPL ? (size_t)2 * (BM + BN) * SPL * 80 : (size_t)NS * (BM + BN) * (DL ? 32 : PITCH) * sizeof(float);
     const size_t epi = (size_t)BM * (BN + 4) * sizeof(float);          // accumulator staging of the vector epilogue
     if (lds < epi) lds = epi;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_f32<BM, BN, MODE, NS, DL, PF, RG>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_f32<BM, BN, MODE, NS, DL, PF, RG, SPL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, MODE, NS, DL, PF, RG>), dim3(grid), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, MODE, NS, DL, PF, RG, SPL>), dim3(grid), dim3(256), lds, st, p);
+}
+
+template <int MODE, int SPL, int NS>
+void launch_split_ns(const ConvP& p, int bm, int bn, int grid, hipStream_t st) {
+    if (bm == 128 && bn == 128) launch<128, 128, MODE, NS, false, false, false, SPL>(p, grid, st);
+    else if (bm == 128 && bn == 64) launch<128, 64, MODE, NS, false, false, false, SPL>(p, grid, st);
+    else if (bm == 64 && bn == 128) launch<64, 128, MODE, NS, false, false, false, SPL>(p, grid, st);
+    else launch<64, 64, MODE, NS, false, false, false, SPL>(p, grid, st);
+}
+template <int MODE, int SPL>
+void launch_split(const ConvP& p, int bm, int bn, int stages, int grid, hipStream_t st) {
+    // stages 3: two register sets (the tile converted into LDS during an iteration was loaded a whole iteration earlier)
+    if (stages == 3) launch_split_ns<MODE, SPL, 3>(p, bm, bn, grid, st);
+    else launch_split_ns<MODE, SPL, 2>(p, bm, bn, grid, st);
 }
 
 }  // namespace
@@ -882,7 +981,12 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
         else if (d->stages == 3 && HAS3_) launch<BM_, BN_, MODE_, HAS3_ ? 3 : 2>(p, grid, st);        \
         else launch<BM_, BN_, MODE_, 2>(p, grid, st);                                                 \
     } while (0)
-    if (d->nlevels > 0) {                               // pyramid input: register-staged double buffer
+    if (d->mma != 0) {                                  // split-bf16 products (see SPL above); tensors stay fp32
+        YM_REQUIRE(d->mma == 3 || d->mma == 6, "conv: mma must be 0 (f32 MFMA), 3 (bf16x3) or 6 (bf16x6), got %d", d->mma);
+        YM_REQUIRE(d->nlevels == 0 && d->Cin % 32 == 0, "conv: split-bf16 mode needs Cin %% 32 == 0 and a single-size input");
+        if (d->transposed) { if (d->mma == 3) launch_split<2, 2>(p, pl.bm, pl.bn, d->stages, grid, st); else launch_split<2, 3>(p, pl.bm, pl.bn, d->stages, grid, st); }
+        else { if (d->mma == 3) launch_split<0, 2>(p, pl.bm, pl.bn, d->stages, grid, st); else launch_split<0, 3>(p, pl.bm, pl.bn, d->stages, grid, st); }
+    } else if (d->nlevels > 0) {                        // pyramid input: register-staged double buffer
         if (pl.bm == 128 && pl.bn == 128) launch<128, 128, 0, 2, false, false, true>(p, grid, st);
         else if (pl.bm == 128 && pl.bn == 64) launch<128, 64, 0, 2, false, false, true>(p, grid, st);
         else if (pl.bm == 64 && pl.bn == 128) launch<64, 128, 0, 2, false, false, true>(p, grid, st);

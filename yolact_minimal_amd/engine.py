@@ -34,6 +34,11 @@ TUNED_PATH = os.environ.get('YM_TUNED_PATH', os.path.join(os.path.dirname(os.pat
 _tuned = None
 
 
+def conv_mma():
+    """YM_CONV_MMA = 0 (default: f32 MFMA, the parity mode) | 3 (bf16x3) | 6 (bf16x6): see ym_conv_desc.mma."""
+    return int(os.environ.get('YM_CONV_MMA', '0') or 0)
+
+
 def tuned_table():
     """Per-shape (tile_m, tile_n, ksplit) choices measured on an MI355X by tools/autotune.py."""
     global _tuned
@@ -86,6 +91,7 @@ class _Conv:
         self.kwaves = 0
         self.stages = 0
         self.tail = (0, 0)           # (tail_tiles, tail_ksplit): see ym_conv_desc
+        self.mma = 0                 # 0 = f32 MFMA (parity mode); 3 / 6 = split-bf16 products (ym_conv_desc.mma)
 
     def refresh(self):
         """(Re)pack parameters from the nn.Modules into the kernel layout, on device."""
@@ -145,7 +151,34 @@ class _Conv:
             self.tail = (hit[5], hit[6]) if len(hit) > 6 else (0, 0)
             d.tile_m, d.tile_n, d.ksplit, d.kwaves, d.stages = hit[0], hit[1], hit[2], self.kwaves, self.stages
             d.tail_tiles, d.tail_ksplit = self.tail
+        self.apply_mma(conv_mma())
         return ho, wo
+
+    def tuned_key(self):
+        return self.sig + (f'_mma{self.mma}' if self.mma else '')
+
+    def apply_mma(self, mma):
+        """Select the matrix pipe of this conv (ym_conv_desc.mma) where the split-bf16 kernel applies: Cin % 32 == 0, workgroup
+        kernel.  Tile / split-K / tail choices are kept; the operand staging falls back to the register double buffer."""
+        d = self.desc
+        ok = mma in (3, 6) and not self.stem and d.Cin % 32 == 0 and d.nlevels == 0
+        self.mma = mma if ok else 0
+        hit = tuned_table().get(self.tuned_key()) if self.mma else None
+        if hit is None:
+            hit = tuned_table().get(self.sig)          # (no entry for this pipe: the f32 choice, incl. its wave kernel for tiny layers)
+        d.mma = self.mma
+        if hit and os.environ.get('YM_NO_TUNED', '0') != '1':     # each matrix pipe has its own measured tile / split-K / tail choice
+            self.tile, self.ksplit, self.kwaves = (hit[0], hit[1]), hit[2], (hit[3] if len(hit) > 3 else 0)
+            self.stages = hit[4] if len(hit) > 4 else 0
+            self.tail = (hit[5], hit[6]) if len(hit) > 6 else (0, 0)
+            d.tile_m, d.tile_n, d.ksplit, d.kwaves = self.tile[0], self.tile[1], self.ksplit, self.kwaves
+            d.tail_tiles, d.tail_ksplit = self.tail
+            if self.kwaves:                                         # the tuner may prefer the f32 wave kernel for a tiny layer
+                self.mma = 0
+                d.mma = 0
+        if self.mma:
+            self.stages = int(os.environ.get('YM_MMA_STAGES', '0'))     # 0/2: one register set, two workgroups per CU (measured best); 3: two sets
+        d.stages = self.stages
 
 
 def _bind_pyramid(layer, pyr, batch, shapes, segs):
@@ -458,10 +491,17 @@ class InferEngine:
             c.desc.kwaves = c.kwaves
             c.desc.stages = c.stages
             c.desc.tail_tiles, c.desc.tail_ksplit = c.tail
+            c.desc.mma = c.mma
         self._alloc_workspaces()
         self.graph = None
 
-    def autotune(self, iters=10, verbose=False):
+    def set_mma(self, mma):
+        """Switch every eligible conv of the plan between the f32 MFMA (0) and the split-bf16 modes (3 / 6)."""
+        for c in self.convs:
+            c.apply_mma(mma)
+        self.retune()
+
+    def autotune(self, iters=10, verbose=False, mma=0):
         """Time every (tile, ksplit) candidate of every distinct conv shape on this GPU; keep the fastest.
         Returns {signature: [tile_m, tile_n, ksplit, best_us, default_us]}."""
         results = {}
@@ -471,6 +511,7 @@ class InferEngine:
         def time_cfg(c, tile, ks, kwv=0, stg=0, tail=(0, 0)):
             d = c.desc
             d.tile_m, d.tile_n, d.ksplit, d.kwaves, d.stages = tile[0], tile[1], ks, kwv, stg
+            d.mma = mma if (split_ok(c) and kwv == 0) else 0
             d.tail_tiles, d.tail_ksplit = tail
             need = hip.conv_workspace_bytes(d)
             if need > big_ws.numel():
@@ -490,10 +531,16 @@ class InferEngine:
                 best = min(best, ev0.elapsed_time(ev1) / iters * 1e3)
             return best
 
+        def split_ok(c):
+            return mma in (3, 6) and not c.stem and c.desc.Cin % 32 == 0 and c.desc.nlevels == 0
+
         seen = {}
         for c in self.convs:
+            if mma and not split_ok(c):
+                continue
             if c.sig in seen:
                 c.tile, c.ksplit, c.kwaves, c.stages, c.tail = seen[c.sig]
+                c.mma = mma if (mma and c.kwaves == 0) else 0
                 continue
             d = c.desc
             M, nkt = d.B * d.Ho * d.Wo, d.k_pad // 32
@@ -538,14 +585,17 @@ class InferEngine:
                         if waves * kwv > 65536:
                             continue
                         cands.append(((tm, tn), 1, kwv, 0, (0, 0)))
+            if mma:                                          # split-bf16: one staging variant (register double buffer)
+                cands = sorted({(tile, ks, kwv, 0, tail) for tile, ks, kwv, stg, tail in cands})
             best = (base, (0, 0), 0, 0, 0, (0, 0))
             for tile, ks, kwv, stg, tail in cands:
                 t = time_cfg(c, tile, ks, kwv, stg, tail)
                 if t is not None and t < best[0] * 0.98:
                     best = (t, tile, ks, kwv, stg, tail)
             c.tile, c.ksplit, c.kwaves, c.stages, c.tail = best[1], best[2], best[3], best[4], best[5]
+            c.mma = mma if (mma and c.kwaves == 0) else 0
             seen[c.sig] = (c.tile, c.ksplit, c.kwaves, c.stages, c.tail)
-            results[c.sig] = [best[1][0], best[1][1], best[2], best[3], best[4], best[5][0], best[5][1], round(best[0], 2), round(base, 2)]
+            results[c.sig + (f'_mma{mma}' if mma else '')] = [best[1][0], best[1][1], best[2], best[3], best[4], best[5][0], best[5][1], round(best[0], 2), round(base, 2)]
             if verbose:
                 print(f'{c.sig:44s} default {base:8.1f} us -> {best[1]} ks={best[2]} kw={best[3]} st={best[4]} tail={best[5]} {best[0]:8.1f} us', flush=True)
         del big_ws

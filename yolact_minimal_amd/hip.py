@@ -51,7 +51,7 @@ class ConvDesc(ctypes.Structure):
                 ('ksplit', ctypes.c_int32), ('kwaves', ctypes.c_int32), ('transposed', ctypes.c_int32),
                 ('stages', ctypes.c_int32), ('bn_sum', ctypes.c_void_p), ('bn_sumsq', ctypes.c_void_p),
                 ('tile_counters', ctypes.c_void_p), ('nlevels', ctypes.c_int32), ('level_h', ctypes.c_int32 * 5),
-                ('level_w', ctypes.c_int32 * 5), ('tail_tiles', ctypes.c_int32), ('tail_ksplit', ctypes.c_int32)]
+                ('level_w', ctypes.c_int32 * 5), ('tail_tiles', ctypes.c_int32), ('tail_ksplit', ctypes.c_int32), ('mma', ctypes.c_int32)]
 
 
 class WgradDesc(ctypes.Structure):
