@@ -439,6 +439,24 @@ def main():
                                               frac_f32_mfma_peak=round(fl2 / tf2 / 1e12 / F32_MFMA_PEAK_TFLOPS, 4))
         if not args.no_extra and world == 1:
             extra['post'] = post_bench(net, cfg, device, args.img_size)
+            # split-bf16 fast modes (ym_conv_desc.mma): same plan, same fp32 tensors, products on the bf16 MFMA.  bf16x3 holds the
+            # reference's 544 px goldens inside the 1e-4 bar (tests/test_gpu_forward.py::test_forward_544_bs8_split_bf16_modes_...);
+            # `value` above stays the f32 parity mode.  Roofline here: 3 (6) bf16 MFMA flops per algorithmic flop vs 2.5 PF dense.
+            split = {}
+            for name, b, mma in ((args.cfg, 1, 3), (args.cfg, 8, 3), (args.cfg, 8, 6), ('res50_coco', 8, 3), ('swin_tiny_coco', 8, 3)):
+                n2, c2 = (net, cfg) if name == args.cfg else build_net(name, args.img_size, device)
+                w2 = Workload(n2, c2, b, args.img_size, device, with_post=not args.no_post)
+                w2.engine.set_mma(mma)
+                t2 = timed(w2, 10, 3, lambda: None) / 10
+                f2 = Workload(n2, c2, b, args.img_size, device, with_post=False)
+                tf2 = timed(f2, 10, 3, lambda: None) / 10
+                fl2 = f2.engine.total_flops
+                split[f'{name}_bs{b}_bf16x{mma}'] = dict(img_s=round(b / t2, 1), forward_only_img_s=round(b / tf2, 1),
+                                                         tflops_f32_equiv=round(fl2 / tf2 / 1e12, 1),
+                                                         frac_bf16_mfma_peak=round(mma * fl2 / tf2 / 1e12 / 2500.0, 4),
+                                                         convs_on_bf16_mfma=sum(1 for c in f2.engine.convs if c.mma))
+                w2.engine.set_mma(0)
+            extra['split_bf16'] = split
             extra['eval_metrics'] = eval_metrics_bench(device, cpu=not args.no_cpu_baseline)
             extra['train_aug'] = train_aug_bench(device, cpu=not args.no_cpu_baseline)
             extra['ann_to_mask'] = ann_to_mask_bench(device, cpu=not args.no_cpu_baseline)
@@ -447,6 +465,16 @@ def main():
                 torch.cuda.empty_cache()
                 extra['train_swin_tiny_coco'] = train_bench('swin_tiny_coco', args.img_size, args.train_batch, args.train_steps, 2, 1,
                                                             local_rank, device, lambda: None)
+                # opt-in fast training mode: forward + data-gradient convs on the bf16 MFMA (bf16x3 split products; NOT parity-grade,
+                # weight gradients stay on the f32 MFMA) and config 4's per-GPU batch (16) in the f32 parity mode
+                os.environ['YM_TRAIN_MMA'] = '3'
+                try:
+                    extra['train_bf16x3_fwd_dgrad'] = train_bench(args.cfg, args.img_size, args.train_batch, args.train_steps, 2, 1, local_rank,
+                                                                  device, lambda: None)
+                finally:
+                    os.environ['YM_TRAIN_MMA'] = '0'
+                torch.cuda.empty_cache()
+                extra['train_bs16'] = train_bench(args.cfg, args.img_size, 16, 4, 2, 1, local_rank, device, lambda: None)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             # the oracle's throughput depends on the thread count (128 threads on a 256-cpu shared host are SLOWER than 8: the

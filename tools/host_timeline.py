@@ -8,7 +8,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle.yolact_ref import synth_targets  # noqa: E402  (input generator)
+from yolact_minimal_amd.utils.synthetic import synth_targets  # noqa: E402
 from yolact_minimal_amd.config import build_cfg  # noqa: E402
 from yolact_minimal_amd.modules.yolact import Yolact  # noqa: E402
 from yolact_minimal_amd.trainer import Trainer  # noqa: E402

@@ -26,6 +26,10 @@ _TUNING = os.environ.get('YM_TUNE_TRAIN', '0') == '1'     # sweep unseen shapes 
 _new_entries = {}
 
 
+def train_mma():
+    return int(os.environ.get('YM_TRAIN_MMA', '0') or 0)
+
+
 def _table():
     from .engine import tuned_table
     return tuned_table()
@@ -89,6 +93,17 @@ def _configure_conv(d, key):
         d.kwaves = hit[3] if len(hit) > 3 else 0
         d.stages = hit[4] if len(hit) > 4 else 0
         d.tail_tiles, d.tail_ksplit = (hit[5], hit[6]) if len(hit) > 6 else (0, 0)
+    mma = train_mma()
+    if mma and d.Cin % 32 == 0 and d.nlevels == 0:
+        # opt-in FAST training mode (YM_TRAIN_MMA=3): forward and data-gradient convs on the bf16 MFMA (split-bf16 products, see
+        # ym_conv_desc.mma).  NOT the parity mode: per-product error ~2^-17 instead of 2^-24, which the ill-conditioned backward of
+        # a random-init net amplifies beyond the fp32 reference's own noise (tests keep the default, f32).
+        hit3 = _table().get(key + f'_mma{mma}')
+        if hit3 is not None:
+            d.tile_m, d.tile_n, d.ksplit, d.kwaves = hit3[0], hit3[1], hit3[2], (hit3[3] if len(hit3) > 3 else 0)
+            d.tail_tiles, d.tail_ksplit = (hit3[5], hit3[6]) if len(hit3) > 6 else (0, 0)
+        if d.kwaves == 0:
+            d.mma, d.stages = mma, 0
 
 
 def _configure_wgrad(d, key):
