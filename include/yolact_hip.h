@@ -223,6 +223,11 @@ typedef struct {
     float* dw;               /* OIHW [Cout_real][Cin_real][KH][KW], overwritten */
     int32_t B, H, W, Cin, Cin_real, Cout, Cout_real, KH, KW, stride, pad, Ho, Wo;
     int32_t msplit;          /* 0 = heuristic; pixel-range slices across the grid */
+    int32_t accumulate;      /* 1: dw += gradient (a weight shared by several convs of one step, e.g. the prediction head over the */
+                             /* five FPN levels, modules/yolact.py:149-153); 0: overwrite                                         */
+    int32_t row_end[2];      /* output-channel ranges routed to separate OIHW tensors (the head's conf | bbox | coef convs run as   */
+    float* dw_seg[2];        /* ONE 351-channel conv): rows [0,row_end[0]) -> dw, [row_end[0],row_end[1]) -> dw_seg[0],            */
+                             /* [row_end[1],Cout_real) -> dw_seg[1].  row_end[0] = 0 means a single tensor (dw).                 */
 } ym_wgrad_desc;
 size_t ym_conv2d_wgrad_workspace_bytes(const ym_wgrad_desc* d);
 int ym_conv2d_wgrad(const ym_wgrad_desc* d, void* workspace, size_t workspace_bytes, ym_stream_t s);
@@ -249,6 +254,19 @@ size_t ym_bn_train_bwd_workspace_bytes(int64_t M, int C);
 int ym_bn_train_bwd(const float* dout, const float* out, const float* y, int64_t M, int C, const float* gamma,
                     const float* beta, const float* save_mean, const float* save_invstd, int relu, float* dy, float* dres,
                     float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, ym_stream_t s);
+
+/* Gradient of the fused prediction-head output w.r.t. the 351(+pad)-channel conv output, for all FPN levels in one launch:
+ * the loss hands back dclass [B][N][nc], dbox [B][N][4], dcoef [B][N][cd] (N = anchors of all levels, anchor = (pixel, a) level by
+ * level); row r of dz (level-major "pyramid" order: level l owns rows lev_row[l] .. lev_row[l+1), each B*hw_l rows = (image, pixel))
+ * gets [na*nc | na*4 | na*cd * (1 - coef^2) | 0-pad] = the reference's permute/reshape/cat/tanh backward (modules/yolact.py:27-30,
+ * 155-157).  lev_row / lev_anchor: int32[nlev+1] on the HOST (row offsets, anchor offsets of the levels).  g_scale: optional device
+ * float[3] multiplying the class / box / coef parts (the upstream gradients of the loss terms), NULL = 1. */
+int ym_head_grad_gather(const float* dclass, const float* dbox, const float* dcoef, const float* coef, int B, int N, int nc, int cd,
+                        int na, int nlev, const int32_t* lev_row, const int32_t* lev_anchor, int pitch, const float* g_scale,
+                        float* dz, ym_stream_t s);
+/* dst_i[0..n_i) = src[off_i .. off_i + n_i) for up to three destinations (or += with accumulate): splits a concatenated bias /
+ * statistics vector back into the parameters' own gradient slots in one launch. */
+int ym_scatter3(const float* src, float* d0, int n0, float* d1, int n1, float* d2, int n2, int accumulate, ym_stream_t s);
 
 /* Backward of a fused conv epilogue `y = act(conv + bias)`: dz = dy * act'(y) (dz may be NULL or == dy for
  * YM_ACT_NONE), dbias[C] = column sums of dz (optional).  workspace >= 8*C bytes when dbias != NULL; with

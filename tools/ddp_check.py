@@ -35,9 +35,12 @@ def main():
         losses = tr.step(img, boxes, masks)
     torch.cuda.synchronize()
     digest = torch.stack([tr.opt.flat.double().sum(), tr.opt.flat.double().abs().sum(), tr.opt.buf.double().abs().sum(),
-                          tr.opt.flat[::997].double().pow(2).sum()]).cpu()
+                          tr.opt.flat[::997].double().pow(2).sum()])
+    if dist.get_backend() != 'nccl':
+        digest = digest.cpu()                               # (gloo gathers host tensors; RCCL needs device tensors)
     gathered = [torch.zeros_like(digest) for _ in range(world)]
     dist.all_gather(gathered, digest)
+    gathered = [g.cpu() for g in gathered]
     ok = all(torch.equal(gathered[0], g) for g in gathered) and all(bool(torch.isfinite(l)) for l in losses)
     bn = [b for b in tr.net.buffers() if b.is_floating_point()]
     if bn:                                              # BN running statistics follow rank 0 (broadcast at the start of each step)

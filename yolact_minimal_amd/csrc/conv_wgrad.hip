@@ -168,8 +168,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradP p) {
     }
 }
 
-// sum the msplit slabs in order and scatter [n][tap][ci] -> OIHW [n][ci][kh][kw] (ci < Cin_real)
-__global__ __launch_bounds__(256) void wgrad_reduce_unpack(const float* __restrict__ ws, float* __restrict__ dw_oihw, int msplit,
+// sum the msplit slabs in order and scatter [n][tap][ci] -> OIHW [n][ci][kh][kw] (ci < Cin_real); rows may be routed to up to three
+// OIHW tensors (ym_wgrad_desc.row_end / dw_seg) and added to what is there (accumulate)
+struct WOut { float* dw[3]; int row_end[3]; int accumulate; };
+__global__ __launch_bounds__(256) void wgrad_reduce_unpack(const float* __restrict__ ws, const WOut o, int msplit,
                                                            int Cout_real, int Cout, int Ktot, int Cinp, int Cin_real, int KHW) {
     const size_t total = (size_t)Cout_real * Ktot;
     const size_t slab = (size_t)Cout * Ktot;
@@ -179,7 +181,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_unpack(const float* __restri
         if (ci >= Cin_real) continue;
         float v = 0.f;
         for (int s = 0; s < msplit; ++s) v += ws[(size_t)s * slab + e];
-        dw_oihw[((size_t)n * Cin_real + ci) * KHW + tap] = v;
+        const int seg = n < o.row_end[0] ? 0 : (n < o.row_end[1] ? 1 : 2);
+        const int n_local = n - (seg == 0 ? 0 : o.row_end[seg - 1]);
+        float* dst = o.dw[seg] + ((size_t)n_local * Cin_real + ci) * KHW + tap;
+        *dst = o.accumulate ? *dst + v : v;
     }
 }
 
@@ -266,7 +271,17 @@ extern "C" int ym_conv2d_wgrad(const ym_wgrad_desc* d, void* workspace, size_t w
     const size_t total = (size_t)d->Cout_real * pl.Ktot;
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_unpack, dim3(grid), dim3(256), 0, st, (const float*)workspace, d->dw, pl.msplit, d->Cout_real,
+    WOut o;
+    o.accumulate = d->accumulate ? 1 : 0;
+    if (d->row_end[0] > 0) {
+        YM_REQUIRE(d->row_end[0] < d->row_end[1] && d->row_end[1] < d->Cout_real && d->dw_seg[0] && d->dw_seg[1], "wgrad: bad output segments");
+        o.dw[0] = d->dw; o.dw[1] = d->dw_seg[0]; o.dw[2] = d->dw_seg[1];
+        o.row_end[0] = d->row_end[0]; o.row_end[1] = d->row_end[1]; o.row_end[2] = d->Cout_real;
+    } else {
+        o.dw[0] = d->dw; o.dw[1] = d->dw; o.dw[2] = d->dw;
+        o.row_end[0] = d->Cout_real; o.row_end[1] = d->Cout_real; o.row_end[2] = d->Cout_real;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_unpack, dim3(grid), dim3(256), 0, st, (const float*)workspace, o, pl.msplit, d->Cout_real,
                        d->Cout, pl.Ktot, d->Cin, d->Cin_real, d->KH * d->KW);
     return ym_check_launch("wgrad_reduce_unpack");
 }

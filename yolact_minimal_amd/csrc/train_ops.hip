@@ -691,3 +691,72 @@ extern "C" int ym_sgd_step(float* param, const float* grad, float* momentum_buf,
                        momentum, weight_decay, first_step);
     return ym_check_launch("sgd_step");
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Backward glue of the fused prediction head (modules/yolact.py:27-30,149-157): the loss returns gradients of the CONCATENATED
+// [B][N][*] tensors; the data / weight gradient convs of the 351-channel head want dz [rows][pitch] per level.
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+struct HeadLevels { int row[6]; int anchor[6]; int nlev; };
+
+__global__ __launch_bounds__(256) void k_head_grad_gather(const float* __restrict__ dclass, const float* __restrict__ dbox,
+                                                           const float* __restrict__ dcoef, const float* __restrict__ coef, int B,
+                                                           int N, int nc, int cd, int na, const HeadLevels lv, int pitch,
+                                                           const float* __restrict__ g_scale, float* __restrict__ dz) {
+    const int c_conf = na * nc, c_box = na * 4, c_coef = na * cd;
+    const long long total = (long long)lv.row[lv.nlev] * pitch;
+    const float gc = g_scale ? g_scale[0] : 1.f, gb = g_scale ? g_scale[1] : 1.f, gm = g_scale ? g_scale[2] : 1.f;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int r = (int)(e / pitch), c = (int)(e - (long long)r * pitch);
+        int l = 0;
+#pragma unroll
+        for (int q = 1; q < 5; ++q)
+            if (q < lv.nlev && r >= lv.row[q]) l = q;
+        const int hw = (lv.row[l + 1] - lv.row[l]) / B;
+        const int local = r - lv.row[l];
+        const int b = local / hw, pix = local - b * hw;
+        const long long a0 = (long long)b * N + lv.anchor[l] + (long long)pix * na;      // first anchor of this pixel
+        float v = 0.f;
+        if (c < c_conf) v = dclass[a0 * nc + c] * gc;
+        else if (c < c_conf + c_box) v = dbox[a0 * 4 + (c - c_conf)] * gb;
+        else if (c < c_conf + c_box + c_coef) {
+            const long long i = a0 * cd + (c - c_conf - c_box);
+            const float t = coef[i];
+            v = dcoef[i] * gm * (1.f - t * t);                                             // tanh'
+        }
+        dz[e] = v;
+    }
+}
+
+__global__ void k_scatter3(const float* __restrict__ src, float* d0, int n0, float* d1, int n1, float* d2, int n2, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n0 + n1 + n2) return;
+    float* dst = i < n0 ? d0 + i : (i < n0 + n1 ? d1 + (i - n0) : d2 + (i - n0 - n1));
+    *dst = accumulate ? *dst + src[i] : src[i];
+}
+}  // namespace
+
+extern "C" int ym_head_grad_gather(const float* dclass, const float* dbox, const float* dcoef, const float* coef, int B, int N, int nc,
+                                   int cd, int na, int nlev, const int32_t* lev_row, const int32_t* lev_anchor, int pitch,
+                                   const float* g_scale, float* dz, ym_stream_t s) {
+    YM_REQUIRE(dclass && dbox && dcoef && coef && dz && lev_row && lev_anchor, "head_grad_gather: null pointer");
+    YM_REQUIRE(nlev >= 1 && nlev <= 5 && B > 0 && pitch >= na * (nc + 4 + cd), "head_grad_gather: bad shape");
+    HeadLevels lv;
+    lv.nlev = nlev;
+    for (int l = 0; l <= nlev; ++l) { lv.row[l] = lev_row[l]; lv.anchor[l] = lev_anchor[l]; }
+    for (int l = 0; l < nlev; ++l)
+        YM_REQUIRE((lev_row[l + 1] - lev_row[l]) % B == 0 && (lev_anchor[l + 1] - lev_anchor[l]) == (lev_row[l + 1] - lev_row[l]) / B * na,
+                   "head_grad_gather: level %d rows / anchors inconsistent", l);
+    const long long total = (long long)lev_row[nlev] * pitch;
+    hipLaunchKernelGGL(k_head_grad_gather, dim3(ew_grid((size_t)total)), dim3(256), 0, (hipStream_t)s, dclass, dbox, dcoef, coef, B, N,
+                       nc, cd, na, lv, pitch, g_scale, dz);
+    return ym_check_launch("head_grad_gather");
+}
+
+extern "C" int ym_scatter3(const float* src, float* d0, int n0, float* d1, int n1, float* d2, int n2, int accumulate, ym_stream_t s) {
+    YM_REQUIRE(src && n0 >= 0 && n1 >= 0 && n2 >= 0 && (n0 == 0 || d0) && (n1 == 0 || d1) && (n2 == 0 || d2), "scatter3: bad args");
+    const int n = n0 + n1 + n2;
+    if (n == 0) return YM_OK;
+    hipLaunchKernelGGL(k_scatter3, dim3(ym_cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, src, d0, n0, d1, n1, d2, n2, accumulate);
+    return ym_check_launch("scatter3");
+}

@@ -22,7 +22,7 @@ ABI_SYMBOLS = (
     'ym_softmax_rows', 'ym_nms_workspace_bytes', 'ym_detect_fast_nms', 'ym_detect_greedy_nms',
     'ym_greedy_nms_workspace_bytes', 'ym_greedy_nms', 'ym_mask_assemble', 'ym_mask_resize_binarize',
     'ym_boxes_to_pixels', 'ym_expf_cr', 'ym_nms_batch_workspace_bytes', 'ym_detect_fast_nms_batch', 'ym_after_nms_batch_workspace_bytes',
-    'ym_after_nms_batch',
+    'ym_after_nms_batch', 'ym_head_grad_gather', 'ym_scatter3',
     'ym_pack_conv_weight_dgrad', 'ym_pack_conv_weights_batch', 'ym_conv2d_wgrad_workspace_bytes', 'ym_conv2d_wgrad', 'ym_bn_train_fwd',
     'ym_val_preprocess', 'ym_layernorm', 'ym_patch_merge_layernorm', 'ym_swin_window_attention',
     'ym_mask_loss_workspace_bytes', 'ym_mask_loss_fwd_bwd', 'ym_mask_loss_batch_workspace_bytes', 'ym_mask_loss_batch',
@@ -59,7 +59,8 @@ class WgradDesc(ctypes.Structure):
                 ('B', ctypes.c_int32), ('H', ctypes.c_int32), ('W', ctypes.c_int32), ('Cin', ctypes.c_int32),
                 ('Cin_real', ctypes.c_int32), ('Cout', ctypes.c_int32), ('Cout_real', ctypes.c_int32),
                 ('KH', ctypes.c_int32), ('KW', ctypes.c_int32), ('stride', ctypes.c_int32), ('pad', ctypes.c_int32),
-                ('Ho', ctypes.c_int32), ('Wo', ctypes.c_int32), ('msplit', ctypes.c_int32)]
+                ('Ho', ctypes.c_int32), ('Wo', ctypes.c_int32), ('msplit', ctypes.c_int32), ('accumulate', ctypes.c_int32),
+                ('row_end', ctypes.c_int32 * 2), ('dw_seg', ctypes.c_void_p * 2)]
 
 
 class AugPlanC(ctypes.Structure):
@@ -135,6 +136,8 @@ def lib():
         L.ym_after_nms_batch_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
         L.ym_after_nms_batch_workspace_bytes.restype = sz
         L.ym_after_nms_batch.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp]
+        L.ym_head_grad_gather.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp]
+        L.ym_scatter3.argtypes = [vp, vp, i32, vp, i32, vp, i32, i32, vp]
         L.ym_pack_conv_weight_dgrad.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
         L.ym_pack_conv_weights_batch.argtypes = [vp, i32, i32, vp]
         L.ym_conv2d_wgrad_workspace_bytes.argtypes = [ctypes.POINTER(WgradDesc)]
