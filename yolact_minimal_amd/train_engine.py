@@ -248,6 +248,8 @@ class _PackCache:
 
     def refresh(self):
         """Re-pack every live image in one launch."""
+        for hook in list(_pre_refresh_hooks):                # derived weights (the concatenated head filter) follow their sources first
+            hook()
         dead = [k for k, e in self.entries.items() if e['ref']() is None]
         for k in dead:
             del self.entries[k]
@@ -276,6 +278,7 @@ class _PackCache:
             e['stamp'] = (owner._version, _EPOCH[0])
 
 
+_pre_refresh_hooks = []     # callables run before a batched re-pack (see _HeadWeights)
 _pack_caches = {}          # one cache (and one device-side table) per device
 
 
@@ -313,20 +316,30 @@ def _pack_dgrad(weight, cout_pad):
     return wd
 
 
-def _conv_forward(x, wp, k_pad, cout_pad, kh, kw, stride, pad, shift, act, residual=None, bn_stats=None):
+def _conv_forward(x, wp, k_pad, cout_pad, kh, kw, stride, pad, shift, act, residual=None, bn_stats=None, out=None, segs=None):
+    """`out`: write into this [B,Ho,Wo,cout_pad] tensor instead of a fresh one.  `segs`: [(n0, n1, tensor_ptr, batch_stride, pitch,
+    act)] routes output-channel ranges to separate tensors (the fused prediction head); then nothing is returned."""
     b, h, w, cin = x.shape
     ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
-    y = torch.empty(b, ho, wo, cout_pad, device=x.device, dtype=torch.float32)
+    y = None
     d = ConvDesc()
     d.inp, d.weight = x.data_ptr(), wp.data_ptr()
     d.shift = shift.data_ptr() if shift is not None else None
     d.residual = residual.data_ptr() if residual is not None else None
     d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW = b, h, w, cin, cout_pad, kh, kw
-    d.stride, d.pad, d.Ho, d.Wo, d.k_pad, d.nseg = stride, pad, ho, wo, k_pad, 1
-    d.seg[0].n_begin, d.seg[0].n_end, d.seg[0].out = 0, cout_pad, y.data_ptr()
-    d.seg[0].batch_stride, d.seg[0].pitch, d.seg[0].act = ho * wo * cout_pad, cout_pad, act
+    d.stride, d.pad, d.Ho, d.Wo, d.k_pad = stride, pad, ho, wo, k_pad
+    if segs is None:
+        y = out if out is not None else torch.empty(b, ho, wo, cout_pad, device=x.device, dtype=torch.float32)
+        d.nseg = 1
+        d.seg[0].n_begin, d.seg[0].n_end, d.seg[0].out = 0, cout_pad, y.data_ptr()
+        d.seg[0].batch_stride, d.seg[0].pitch, d.seg[0].act = ho * wo * cout_pad, cout_pad, act
+    else:
+        d.nseg = len(segs)
+        for i, (n0, n1, ptr, bstride, pitch, a) in enumerate(segs):
+            d.seg[i].n_begin, d.seg[i].n_end, d.seg[i].out = n0, n1, ptr
+            d.seg[i].batch_stride, d.seg[i].pitch, d.seg[i].act = bstride, pitch, a
     if cin != 4:
-        _configure_conv(d, f'M{b * ho * wo}_N{cout_pad}_C{cin}_k{kh}_s{stride}_seg1_r{int(residual is not None)}')
+        _configure_conv(d, f'M{b * ho * wo}_N{cout_pad}_C{cin}_k{kh}_s{stride}_seg{d.nseg}_r{int(residual is not None)}')
     d.tile_counters = _tile_counters(x.device)
     fused = False
     if bn_stats is not None and hip.lib().ym_conv2d_fuses_bn_stats(ctypes.byref(d)) == 1:
@@ -339,14 +352,14 @@ def _conv_forward(x, wp, k_pad, cout_pad, kh, kw, stride, pad, shift, act, resid
     return y
 
 
-def _conv_dgrad(dz, weight, cout_pad, x_shape, stride, pad, add=None):
+def _conv_dgrad(dz, weight, cout_pad, x_shape, stride, pad, add=None, out=None):
     """dx [B,H,W,Cin] from dz [B,Ho,Wo,cout_pad] (cout_pad % 32 == 0) and the OIHW weight; `add` [B,H,W,Cin] (another
-    consumer's gradient of the same tensor) is summed in the epilogue."""
+    consumer's gradient of the same tensor) is summed in the epilogue; `out`: destination instead of a fresh tensor."""
     cout, cin, kh, kw = weight.shape
     b, h, w, cin_x = x_shape
     assert cin_x == cin and cout_pad % 32 == 0
     wd = _pack_dgrad(weight, cout_pad)
-    dx = torch.empty(b, h, w, cin, device=dz.device, dtype=torch.float32)
+    dx = out if out is not None else torch.empty(b, h, w, cin, device=dz.device, dtype=torch.float32)
     d = ConvDesc()
     d.inp, d.weight = dz.data_ptr(), wd.data_ptr()
     d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW = b, dz.shape[1], dz.shape[2], cout_pad, cin, kh, kw
@@ -374,15 +387,22 @@ def _grad_slot(param, shape):
     return torch.empty(shape, device=param.device if param is not None else None, dtype=torch.float32)
 
 
-def _conv_wgrad(x, dz, weight_shape, stride, pad, weight_param=None):
+def _conv_wgrad(x, dz, weight_shape, stride, pad, weight_param=None, dw=None, accumulate=False, segments=None):
+    """`dw`: destination OIHW tensor (default: the parameter's gradient slot / a fresh tensor).  `accumulate`: dw += gradient.
+    `segments` = (row_end0, row_end1, dw1, dw2): output channels [0,row_end0) -> dw, [row_end0,row_end1) -> dw1, the rest -> dw2."""
     cout, cin, kh, kw = weight_shape
     b, h, w, cin_p = x.shape
-    dw = _grad_slot(weight_param, (cout, cin, kh, kw)) if weight_param is not None else \
-        torch.empty(cout, cin, kh, kw, device=x.device, dtype=torch.float32)
+    if dw is None:
+        dw = _grad_slot(weight_param, (cout, cin, kh, kw)) if weight_param is not None else \
+            torch.empty(cout, cin, kh, kw, device=x.device, dtype=torch.float32)
     d = WgradDesc()
     d.x, d.dy, d.dw = x.data_ptr(), dz.data_ptr(), dw.data_ptr()
     d.B, d.H, d.W, d.Cin, d.Cin_real, d.Cout, d.Cout_real = b, h, w, cin_p, cin, dz.shape[3], cout
     d.KH, d.KW, d.stride, d.pad, d.Ho, d.Wo, d.msplit = kh, kw, stride, pad, dz.shape[1], dz.shape[2], 0
+    d.accumulate = int(accumulate)
+    if segments is not None:
+        d.row_end[0], d.row_end[1] = segments[0], segments[1]
+        d.dw_seg[0], d.dw_seg[1] = segments[2].data_ptr(), segments[3].data_ptr()
     _configure_wgrad(d, f'W_M{b * dz.shape[1] * dz.shape[2]}_N{dz.shape[3]}_C{cin_p}_k{kh}_s{stride}')
     nbytes = hip.lib().ym_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
     if nbytes == 0:
@@ -433,6 +453,139 @@ class ConvBias(torch.autograd.Function):
         if dbias is not None and cout_pad != weight.shape[0]:
             dbias = dbias[:weight.shape[0]].contiguous()
         return dx, dw, dbias, None, None, None, None, (dz if has_res else None)
+
+
+class _HeadWeights:
+    """The three sibling convs of the PredictionModule (conf | bbox | coef, modules/yolact.py:22-24) run as ONE 351-channel conv.
+    Their OIHW weights / biases are kept concatenated in persistent buffers that follow the parameters: three contiguous
+    device-to-device copies per optimizer step (before the batched re-pack of the weight images) instead of a `torch.cat` with
+    its autograd node, allocation and backward split every forward."""
+    _by_module = {}
+
+    def __init__(self, hd, pad):
+        convs = (hd.conf_layer, hd.bbox_layer, hd.coef_layer[0])
+        self.convs = convs
+        w0 = convs[0].weight
+        self.couts = [c.out_channels for c in convs]
+        self.cout = sum(self.couts)
+        self.w = torch.zeros(self.cout, *w0.shape[1:], device=w0.device, dtype=torch.float32)
+        self.b = torch.zeros(pad, device=w0.device, dtype=torch.float32)
+        self.w._ym_grad_slot = self.w           # marks the buffer as "refreshed only by its owner" for the pack cache
+        self.stamp = None
+        _pre_refresh_hooks.append(self.sync)
+
+    @classmethod
+    def of(cls, hd, pad):
+        key = id(hd)
+        e = cls._by_module.get(key)
+        if e is None or e.convs[0].weight.device != e.w.device or e.convs[0] is not hd.conf_layer:
+            e = cls._by_module[key] = cls(hd, pad)
+        return e
+
+    def sync(self):
+        stamp = tuple(c.weight._version for c in self.convs) + tuple(c.bias._version for c in self.convs) + (_EPOCH[0],)
+        if stamp == self.stamp:
+            return
+        with torch.no_grad():
+            r = 0
+            for c, n in zip(self.convs, self.couts):
+                self.w[r:r + n].copy_(c.weight.detach())
+                self.b[r:r + n].copy_(c.bias.detach())
+                r += n
+        self.stamp = stamp
+
+
+class PredictionHead(torch.autograd.Function):
+    """The shared PredictionModule over all FPN levels as ONE autograd node (modules/yolact.py:26-31,149-157): per level the
+    upfeature conv (+ReLU) and one 351-channel conv whose segmented epilogue writes conf / box / tanh(coef) straight into the
+    concatenated [B, N, *] tensors (no permute / reshape / cat / tanh kernels).  Backward: one gather turns the loss's gradients
+    of those tensors into the per-level [rows][352] conv-output gradients (tanh' included), one column-sum pair gives the two
+    bias gradients for all levels, and the per-level weight-gradient launches ACCUMULATE into the parameters' gradient slots
+    (the reference's autograd sums five per-level gradients with separate kernels)."""
+
+    @staticmethod
+    def forward(ctx, w_up, b_up, w_conf, b_conf, w_box, b_box, w_coef, b_coef, hd, nc, cd, na, *levels):
+        dev = levels[0].device
+        bsz = levels[0].shape[0]
+        shapes = [(lv.shape[1], lv.shape[2]) for lv in levels]
+        row_off, anc_off = [0], [0]
+        for h, w in shapes:
+            row_off.append(row_off[-1] + bsz * h * w)
+            anc_off.append(anc_off[-1] + h * w * na)
+        n_total = anc_off[-1]
+        c_conf, c_box, c_coef = na * nc, na * 4, na * cd
+        cout = c_conf + c_box + c_coef
+        pad = _ru(cout, 32)
+        hw_ = _HeadWeights.of(hd, pad)
+        hw_.sync()
+        wp_up, k_up = _pack_fwd(w_up, 256, 256)
+        wp_hd, k_hd = _pack_fwd(hw_.w, 256, pad)
+        xh_all = torch.empty(row_off[-1], 256, device=dev, dtype=torch.float32)
+        conf = torch.empty(bsz, n_total, nc, device=dev, dtype=torch.float32)
+        box = torch.empty(bsz, n_total, 4, device=dev, dtype=torch.float32)
+        coef = torch.empty(bsz, n_total, cd, device=dev, dtype=torch.float32)
+        b_up_c = b_up.detach().contiguous()
+        for l, lv in enumerate(levels):
+            h, w = shapes[l]
+            xh = xh_all[row_off[l]:row_off[l + 1]].view(bsz, h, w, 256)
+            _conv_forward(lv, wp_up, k_up, 256, 3, 3, 1, 1, b_up_c, ACT_RELU, out=xh)
+            off = anc_off[l]
+            segs = [(0, c_conf, conf.data_ptr() + off * nc * 4, n_total * nc, c_conf, ACT_NONE),
+                    (c_conf, c_conf + c_box, box.data_ptr() + off * 4 * 4, n_total * 4, c_box, ACT_NONE),
+                    (c_conf + c_box, cout, coef.data_ptr() + off * cd * 4, n_total * cd, c_coef, ACT_TANH)]
+            _conv_forward(xh, wp_hd, k_hd, cout, 3, 3, 1, 1, hw_.b, ACT_NONE, segs=segs)
+        ctx.save_for_backward(w_up, xh_all, coef, *levels)
+        ctx.meta = (hd, nc, cd, na, shapes, row_off, anc_off, pad, b_up, (w_conf, b_conf, w_box, b_box, w_coef, b_coef))
+        return conf, box, coef
+
+    @staticmethod
+    def backward(ctx, dconf, dbox, dcoef):
+        w_up, xh_all, coef, *levels = ctx.saved_tensors
+        hd, nc, cd, na, shapes, row_off, anc_off, pad, b_up, (w_conf, b_conf, w_box, b_box, w_coef, b_coef) = ctx.meta
+        dev = xh_all.device
+        bsz = levels[0].shape[0]
+        n_total = anc_off[-1]
+        mtot = row_off[-1]
+        c_conf, c_box, c_coef = na * nc, na * 4, na * cd
+        hw_ = _HeadWeights.of(hd, pad)
+        L = hip.lib()
+        nlev = len(levels)
+        rows_c = (ctypes.c_int32 * (nlev + 1))(*row_off)
+        ancs_c = (ctypes.c_int32 * (nlev + 1))(*anc_off)
+        dz_all = torch.empty(mtot, pad, device=dev, dtype=torch.float32)
+        hip.check(L.ym_head_grad_gather(hip.ptr(dconf.contiguous()), hip.ptr(dbox.contiguous()), hip.ptr(dcoef.contiguous()), hip.ptr(coef),
+                                        bsz, n_total, nc, cd, na, nlev, rows_c, ancs_c, pad, None, hip.ptr(dz_all), hip.stream_ptr()),
+                  'ym_head_grad_gather')
+        # head biases: column sums over all levels' rows, then split into the three parameters' slots
+        ws = scratch(dev, L.ym_bn_train_bwd_workspace_bytes(mtot, pad))
+        db_cat = torch.empty(pad, device=dev, dtype=torch.float32)
+        hip.check(L.ym_act_bias_bwd(hip.ptr(dz_all), None, mtot, pad, ACT_NONE, None, hip.ptr(db_cat), ctypes.c_void_p(ws.data_ptr()),
+                                    ws.numel(), hip.stream_ptr()), 'ym_act_bias_bwd')
+        db = [_grad_slot(b_conf, (c_conf,)), _grad_slot(b_box, (c_box,)), _grad_slot(b_coef, (c_coef,))]
+        hip.check(L.ym_scatter3(hip.ptr(db_cat), hip.ptr(db[0]), c_conf, hip.ptr(db[1]), c_box, hip.ptr(db[2]), c_coef, 0,
+                                hip.stream_ptr()), 'ym_scatter3')
+        dw = [_grad_slot(w_conf, tuple(w_conf.shape)), _grad_slot(w_box, tuple(w_box.shape)), _grad_slot(w_coef, tuple(w_coef.shape))]
+        dxh_all = torch.empty(mtot, 256, device=dev, dtype=torch.float32)
+        for l in range(nlev):
+            h, w = shapes[l]
+            dz = dz_all[row_off[l]:row_off[l + 1]].view(bsz, h, w, pad)
+            xh = xh_all[row_off[l]:row_off[l + 1]].view(bsz, h, w, 256)
+            _conv_dgrad(dz, hw_.w, pad, (bsz, h, w, 256), 1, 1, out=dxh_all[row_off[l]:row_off[l + 1]].view(bsz, h, w, 256))
+            _conv_wgrad(xh, dz, tuple(hw_.w.shape), 1, 1, dw=dw[0], accumulate=l > 0, segments=(c_conf, c_conf + c_box, dw[1], dw[2]))
+        # upfeature: ReLU backward + bias column sums for all levels at once, then per-level data / weight gradients
+        dzu_all = torch.empty_like(dxh_all)
+        db_up = _grad_slot(b_up, (256,))
+        ws = scratch(dev, L.ym_bn_train_bwd_workspace_bytes(mtot, 256))
+        hip.check(L.ym_act_bias_bwd(hip.ptr(dxh_all), hip.ptr(xh_all), mtot, 256, ACT_RELU, hip.ptr(dzu_all), hip.ptr(db_up),
+                                    ctypes.c_void_p(ws.data_ptr()), ws.numel(), hip.stream_ptr()), 'ym_act_bias_bwd')
+        dw_up = _grad_slot(w_up, tuple(w_up.shape))
+        dlevels = []
+        for l, lv in enumerate(levels):
+            h, w = shapes[l]
+            dzu = dzu_all[row_off[l]:row_off[l + 1]].view(bsz, h, w, 256)
+            dlevels.append(_conv_dgrad(dzu, w_up, 256, lv.shape, 1, 1) if ctx.needs_input_grad[12 + l] else None)
+            _conv_wgrad(lv, dzu, tuple(w_up.shape), 1, 1, dw=dw_up, accumulate=l > 0)
+        return (dw_up, db_up, dw[0], db[0], dw[1], db[1], dw[2], db[2], None, None, None, None, *dlevels)
 
 
 class ResGradLink:
@@ -615,6 +768,12 @@ def train_features(net, img):
 
     hd = net.prediction_layers
     nc, cd, na = net.cfg.num_classes, net.coef_dim, len(net.cfg.aspect_ratios)
+    if os.environ.get('YM_FUSED_HEAD', '1') != '0':
+        conf_all, box_all, coef_all = PredictionHead.apply(
+            hd.upfeature[0].weight, hd.upfeature[0].bias, hd.conf_layer.weight, hd.conf_layer.bias, hd.bbox_layer.weight,
+            hd.bbox_layer.bias, hd.coef_layer[0].weight, hd.coef_layer[0].bias, hd, nc, cd, na, *levels)
+        seg = _conv_bias(p3, net.semantic_seg_conv, ACT_NONE, _ru(nc - 1, 32))[..., :nc - 1].permute(0, 3, 1, 2)
+        return conf_all, box_all, coef_all, proto, seg
     c_conf, c_box, c_coef = na * nc, na * 4, na * cd
     w_head = torch.cat([hd.conf_layer.weight, hd.bbox_layer.weight, hd.coef_layer[0].weight], 0)
     b_head = torch.cat([hd.conf_layer.bias, hd.bbox_layer.bias, hd.coef_layer[0].bias], 0)
