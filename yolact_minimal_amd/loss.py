@@ -25,6 +25,22 @@ def _vp(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+# The loss kernels write d(loss_i)/d(input) in their forward pass; backward only has to scale them by the incoming gradient of
+# loss_i.  `Trainer.step` sums the four terms itself (train.py:124: loss_total = loss_c + loss_b + loss_m + loss_s), so that
+# gradient is exactly 1 there: inside `unit_loss_grads()` the stored gradients are handed on as they are (no 4 elementwise
+# passes over the [B, N, 81] / [B, Hp, Wp, 32] tensors).  Anywhere else (a caller that weights the terms) they are scaled.
+_UNIT = [False]
+
+
+class unit_loss_grads:
+    def __enter__(self):
+        self.prev, _UNIT[0] = _UNIT[0], True
+
+    def __exit__(self, *exc):
+        _UNIT[0] = self.prev
+        return False
+
+
 def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
@@ -64,6 +80,8 @@ class _ClassBoxLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_c, g_b):
         dclass, dbox = ctx.saved_tensors
+        if _UNIT[0]:
+            return dclass, dbox, None, None, None, None, None, None
         return dclass * g_c, dbox * g_b, None, None, None, None, None, None
 
 
@@ -100,6 +118,8 @@ class _MaskLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         dproto, dcoef = ctx.saved_tensors
+        if _UNIT[0]:
+            return dproto, dcoef, None, None, None, None, None, None
         return dproto * grad_out, dcoef * grad_out, None, None, None, None, None, None
 
 

@@ -368,7 +368,9 @@ class Trainer:
             all_loss = torch.stack([l.detach() for l in losses])
             dist.all_reduce(all_loss)                 # 16-byte logging collective, train.py:121-122
         total = losses[0] + losses[1] + losses[2] + losses[3]
-        total.backward()
+        from .loss import unit_loss_grads
+        with unit_loss_grads():                       # d(total)/d(loss_i) = 1: the loss kernels' stored gradients pass through unscaled
+            total.backward()
         if self.reducer is not None:
             self.reducer.finish()
         self.opt.step()
