@@ -9,7 +9,7 @@ import sys
 os.environ['YM_TUNE_TRAIN'] = '1'
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
-from oracle.yolact_ref import synth_targets  # noqa: E402  (input generator)
+from yolact_minimal_amd.utils.synthetic import synth_targets  # noqa: E402
 from yolact_minimal_amd import train_engine  # noqa: E402
 from yolact_minimal_amd.config import build_cfg  # noqa: E402
 from yolact_minimal_amd.modules.yolact import Yolact  # noqa: E402

@@ -14,7 +14,6 @@ using namespace ymk;
 
 namespace {
 
-constexpr int TBN = 128;   // n tile
 constexpr int TBK = 128;   // kk tile
 constexpr int TBM = 32;    // pixels per step
 constexpr int LP = 132;    // LDS row pitch (floats): 16-byte aligned rows, skewed banks for the float4 writes
@@ -37,13 +36,16 @@ __device__ __forceinline__ f32x4 buf_ld16(__amdgpu_buffer_rsrc_t r, unsigned byt
 }
 __device__ __forceinline__ unsigned fastdiv(unsigned m, unsigned mg, unsigned sh) { return (__umulhi(m, mg) + m) >> sh; }
 
-template <int INCR>
+// TBN = n tile.  128: waves 2 x 2, each 64(n) x 64(kk).  64 (layers with <= 64 output channels: a 128-wide tile would spend half of
+// its MFMAs on zero padding — 35 TFLOP/s on the 64-channel layers of layer1): waves 1 x 4, each 64(n) x 32(kk).
+template <int INCR, int TBN>
 __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradP p) {
+    constexpr int KT = TBN == 128 ? 2 : 1;          // 32-wide kk tiles per wave
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ys = smem;                       // [2][TBM][LP]
     float* Xs = smem + 2 * TBM * LP;        // [2][TBM][LP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave >> 1, wk = wave & 1;
+    const int wn = TBN == 128 ? (wave >> 1) : 0, wk = TBN == 128 ? (wave & 1) : wave;
 
     int id = ym_xcd_remap(blockIdx.x, gridDim.x);
     const int ms = id % p.msplit;
@@ -119,11 +121,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradP p) {
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][KT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < KT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -135,16 +137,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradP p) {
     for (int mt = m_beg; mt < m_end; mt += TBM) {
         load(mt + TBM);
         const float* ya = Ys + cur * TBM * LP + wn * 64 + fr;
-        const float* xb = Xs + cur * TBM * LP + wk * 64 + fr;
+        const float* xb = Xs + cur * TBM * LP + wk * (32 * KT) + fr;
 #pragma unroll
         for (int s = 0; s < TBM / 2; ++s) {
             const int row = 2 * s + khalf;
             const float a0 = ya[row * LP], a1 = ya[row * LP + 32];
-            const float b0 = xb[row * LP], b1 = xb[row * LP + 32];
+            const float b0 = xb[row * LP];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            if constexpr (KT == 2) {
+                const float b1 = xb[row * LP + 32];
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
         }
         store(cur ^ 1);
         __syncthreads();
@@ -154,8 +159,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradP p) {
     // D[i = n][j = kk]: col = lane&31 -> kk, row = (r&3) + 8*(r>>2) + 4*khalf -> n
     float* wsb = p.ws + (size_t)ms * p.Cout * p.Ktot;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int kcol = k0 + wk * 64 + j * 32 + fr;
+    for (int j = 0; j < KT; ++j) {
+        const int kcol = k0 + wk * (32 * KT) + j * 32 + fr;
         if (kcol >= p.Ktot) continue;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_unpack(const float* __restri
     }
 }
 
-struct WPlan { int M, Ktot, tiles_n, tiles_k, msplit, m_per_split; };
+struct WPlan { int M, Ktot, tiles_n, tiles_k, msplit, m_per_split, tbn; };
 
 void fastdiv_make(unsigned d, unsigned* mg, unsigned* sh) {
     unsigned s = 0;
@@ -208,7 +213,8 @@ int wplan(const ym_wgrad_desc* d, WPlan* pl) {
     YM_REQUIRE(M * d->Cout < (1ll << 31) && (long long)d->B * d->H * d->W * d->Cin < (1ll << 31), "wgrad: tensor too large");
     pl->M = (int)M;
     pl->Ktot = d->KH * d->KW * d->Cin;
-    pl->tiles_n = ym_cdiv(d->Cout, TBN);
+    pl->tbn = d->Cout_real <= 64 ? 64 : 128;
+    pl->tiles_n = ym_cdiv(d->Cout, pl->tbn);
     pl->tiles_k = ym_cdiv(pl->Ktot, TBK);
     int ms = d->msplit;
     if (ms <= 0) {
@@ -257,15 +263,22 @@ extern "C" int ym_conv2d_wgrad(const ym_wgrad_desc* d, void* workspace, size_t w
     const size_t lds = (size_t)4 * TBM * LP * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_f32<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_f32<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_f32<0, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_f32<1, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_f32<0, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_f32<1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     // incremental coordinates need: (rows advanced per step) + 1 < 2 * Ho, so that two conditional wraps suffice
     p.incr = (TBM / d->Wo + 2 <= 2 * d->Ho) ? 1 : 0;
     const dim3 wgrid(pl.tiles_n * pl.tiles_k * pl.msplit);
-    if (p.incr) hipLaunchKernelGGL(conv_wgrad_f32<1>, wgrid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL(conv_wgrad_f32<0>, wgrid, dim3(256), lds, st, p);
+    if (pl.tbn == 64) {
+        if (p.incr) hipLaunchKernelGGL((conv_wgrad_f32<1, 64>), wgrid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((conv_wgrad_f32<0, 64>), wgrid, dim3(256), lds, st, p);
+    } else {
+        if (p.incr) hipLaunchKernelGGL((conv_wgrad_f32<1, 128>), wgrid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((conv_wgrad_f32<0, 128>), wgrid, dim3(256), lds, st, p);
+    }
     rc = ym_check_launch("conv_wgrad_f32");
     if (rc != YM_OK) return rc;
     const size_t total = (size_t)d->Cout_real * pl.Ktot;
