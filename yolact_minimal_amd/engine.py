@@ -177,7 +177,11 @@ class _Conv:
                 self.mma = 0
                 d.mma = 0
         if self.mma:
-            self.stages = int(os.environ.get('YM_MMA_STAGES', '0'))     # 0/2: one register set, two workgroups per CU (measured best); 3: two sets
+            # split modes stage through registers: 0/2 = one register set (fewer VGPRs: two workgroups per CU on the big tiles),
+            # 3 = two sets (the tile being converted arrived an iteration earlier: wins where occupancy is one wave per SIMD anyway)
+            self.stages = 3 if self.stages == 3 else 0
+            if os.environ.get('YM_MMA_STAGES'):
+                self.stages = int(os.environ['YM_MMA_STAGES'])
         d.stages = self.stages
 
 
@@ -585,8 +589,8 @@ class InferEngine:
                         if waves * kwv > 65536:
                             continue
                         cands.append(((tm, tn), 1, kwv, 0, (0, 0)))
-            if mma:                                          # split-bf16: one staging variant (register double buffer)
-                cands = sorted({(tile, ks, kwv, 0, tail) for tile, ks, kwv, stg, tail in cands})
+            if mma:                                          # split-bf16: register staging with one (0) or two (3) register sets
+                cands = sorted({(tile, ks, kwv, st, tail) for tile, ks, kwv, stg, tail in cands for st in ((0, 3) if kwv == 0 else (0,))})
             best = (base, (0, 0), 0, 0, 0, (0, 0))
             for tile, ks, kwv, stg, tail in cands:
                 t = time_cfg(c, tile, ks, kwv, stg, tail)
