@@ -129,6 +129,25 @@ def test_forward_544_bs8_split_bf16_modes_hold_the_1e4_bar(golden_dir, name, mma
     check_bs8_digest(g, out, 1)
 
 
+def test_set_conv_mode_switches_engines_and_back():
+    net, cfg = make_net('res50_coco', 128, 5)
+    net = net.to(DEV)
+    img = torch.randn(2, 3, 128, 128, generator=torch.Generator().manual_seed(6)).to(DEV)
+    with torch.no_grad():
+        base = [t.clone() for t in net(img)]
+        net.set_conv_mode('bf16x3')
+        fast = [t.clone() for t in net(img)]
+        assert sum(1 for c in net._engine(img).convs if c.mma == 3) > 40
+        net.set_conv_mode('f32')
+        again = net(img)
+    for a, b, c in zip(base, fast, again):
+        assert torch.equal(a, c)                                   # back on the f32 MFMA: bit-identical
+        _close(b, a, 'bf16x3 vs f32')
+        assert not torch.equal(a, b)
+    with pytest.raises(ValueError):
+        net.set_conv_mode('fp8')
+
+
 def test_batch_equals_per_image():
     """bs=8-style batching: image i of a batch equals the bs=1 result."""
     net, cfg = make_net('res50_coco', 64, 77)

@@ -138,6 +138,19 @@ class Yolact(nn.Module):
         print(f'Number of all parameters: {sum(p.numel() for p in self.parameters())}\n')
 
     # ---- forward -----------------------------------------------------------------------------
+    CONV_MODES = {'f32': 0, 'bf16x3': 3, 'bf16x6': 6}
+
+    def set_conv_mode(self, mode):
+        """Matrix pipe of the inference convolutions (not part of the reference's surface; `ym_conv_desc.mma`): 'f32' = exact
+        fp32 products on the f32 MFMA (default, the parity mode); 'bf16x3' / 'bf16x6' = fp32 operands split into 2 / 3 bf16 terms
+        on the bf16 MFMA with fp32 accumulation (bf16x3: ~1.6x the bs=8 throughput, within 1e-4 of the reference on its 544 px
+        goldens; bf16x6: fp32-grade).  Tensors, weights and the state dict stay fp32."""
+        if mode not in self.CONV_MODES:
+            raise ValueError(f'conv mode must be one of {sorted(self.CONV_MODES)}, got {mode!r}')
+        self._conv_mma = self.CONV_MODES[mode]
+        for eng in self._engines.values():
+            eng.set_mma(self._conv_mma)
+
     def _engine(self, img):
         from ..engine import InferEngine
         key = (img.device.index, img.shape[0], img.shape[2], img.shape[3])
@@ -145,6 +158,8 @@ class Yolact(nn.Module):
         if eng is None:
             eng = InferEngine(self, batch=img.shape[0], height=img.shape[2], width=img.shape[3],
                               device=img.device)
+            if getattr(self, '_conv_mma', None) is not None:
+                eng.set_mma(self._conv_mma)
             self._engines[key] = eng
         return eng
 
