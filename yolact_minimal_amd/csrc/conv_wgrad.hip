@@ -38,12 +38,15 @@ __device__ __forceinline__ unsigned fastdiv(unsigned m, unsigned mg, unsigned sh
 
 // TBN = n tile.  128: waves 2 x 2, each 64(n) x 64(kk).  64 (layers with <= 64 output channels: a 128-wide tile would spend half of
 // its MFMAs on zero padding — 35 TFLOP/s on the 64-channel layers of layer1): waves 1 x 4, each 64(n) x 32(kk).
-template <int INCR, int TBN>
+// NB = LDS buffers.  2: the next pixel step is written while the current one is read (one barrier per step, 68 KB: two workgroups
+// per CU).  1: one buffer, two barriers per step (34 KB: three workgroups per CU at 152 VGPRs) — the extra barrier is hidden by
+// the third resident workgroup; the counters showed this kernel at 1.3 resident waves per SIMD and 57 % MFMA-busy with NB = 2.
+template <int INCR, int TBN, int NB>
 __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradP p) {
     constexpr int KT = TBN == 128 ? 2 : 1;          // 32-wide kk tiles per wave
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ys = smem;                       // [2][TBM][LP]
-    float* Xs = smem + 2 * TBM * LP;        // [2][TBM][LP]
+    float* Ys = smem;                       // [NB][TBM][LP]
+    float* Xs = smem + NB * TBM * LP;       // [NB][TBM][LP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = TBN == 128 ? (wave >> 1) : 0, wk = TBN == 128 ? (wave & 1) : wave;
 
@@ -151,9 +154,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradP p) {
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
             }
         }
-        store(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+        if constexpr (NB == 2) {
+            store(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        } else {
+            __syncthreads();               // every wave is done reading the buffer ...
+            store(0);                      // ... before the next step overwrites it
+            __syncthreads();
+        }
     }
 
     // D[i = n][j = kk]: col = lane&31 -> kk, row = (r&3) + 8*(r>>2) + 4*khalf -> n
@@ -193,7 +202,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_unpack(const float* __restri
     }
 }
 
-struct WPlan { int M, Ktot, tiles_n, tiles_k, msplit, m_per_split, tbn; };
+struct WPlan { int M, Ktot, tiles_n, tiles_k, msplit, m_per_split, tbn, nb; };
 
 void fastdiv_make(unsigned d, unsigned* mg, unsigned* sh) {
     unsigned s = 0;
@@ -214,6 +223,7 @@ int wplan(const ym_wgrad_desc* d, WPlan* pl) {
     pl->M = (int)M;
     pl->Ktot = d->KH * d->KW * d->Cin;
     pl->tbn = d->Cout_real <= 64 ? 64 : 128;
+    pl->nb = d->lds_buffers == 1 ? 1 : 2;
     pl->tiles_n = ym_cdiv(d->Cout, pl->tbn);
     pl->tiles_k = ym_cdiv(pl->Ktot, TBK);
     int ms = d->msplit;
@@ -260,25 +270,27 @@ extern "C" int ym_conv2d_wgrad(const ym_wgrad_desc* d, void* workspace, size_t w
         fastdiv_make((unsigned)d->Wo, &p.mg_wo, &p.sh_wo);
     }
     hipStream_t st = (hipStream_t)s;
-    const size_t lds = (size_t)4 * TBM * LP * sizeof(float);
+    const size_t lds = (size_t)2 * pl.nb * TBM * LP * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_f32<0, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_f32<1, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_f32<0, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_f32<1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const int big = (int)((size_t)4 * TBM * LP * sizeof(float));
+#define YM_WG_ATTR(I, T, N) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_f32<I, T, N>), hipFuncAttributeMaxDynamicSharedMemorySize, big)
+        YM_WG_ATTR(0, 128, 2); YM_WG_ATTR(1, 128, 2); YM_WG_ATTR(0, 64, 2); YM_WG_ATTR(1, 64, 2);
+        YM_WG_ATTR(0, 128, 1); YM_WG_ATTR(1, 128, 1); YM_WG_ATTR(0, 64, 1); YM_WG_ATTR(1, 64, 1);
+#undef YM_WG_ATTR
         attr_set = true;
     }
     // incremental coordinates need: (rows advanced per step) + 1 < 2 * Ho, so that two conditional wraps suffice
     p.incr = (TBM / d->Wo + 2 <= 2 * d->Ho) ? 1 : 0;
     const dim3 wgrid(pl.tiles_n * pl.tiles_k * pl.msplit);
-    if (pl.tbn == 64) {
-        if (p.incr) hipLaunchKernelGGL((conv_wgrad_f32<1, 64>), wgrid, dim3(256), lds, st, p);
-        else hipLaunchKernelGGL((conv_wgrad_f32<0, 64>), wgrid, dim3(256), lds, st, p);
-    } else {
-        if (p.incr) hipLaunchKernelGGL((conv_wgrad_f32<1, 128>), wgrid, dim3(256), lds, st, p);
-        else hipLaunchKernelGGL((conv_wgrad_f32<0, 128>), wgrid, dim3(256), lds, st, p);
-    }
+#define YM_WG_LAUNCH(T, N)                                                                          \
+    do {                                                                                            \
+        if (p.incr) hipLaunchKernelGGL((conv_wgrad_f32<1, T, N>), wgrid, dim3(256), lds, st, p);   \
+        else hipLaunchKernelGGL((conv_wgrad_f32<0, T, N>), wgrid, dim3(256), lds, st, p);          \
+    } while (0)
+    if (pl.tbn == 64) { if (pl.nb == 1) YM_WG_LAUNCH(64, 1); else YM_WG_LAUNCH(64, 2); }
+    else { if (pl.nb == 1) YM_WG_LAUNCH(128, 1); else YM_WG_LAUNCH(128, 2); }
+#undef YM_WG_LAUNCH
     rc = ym_check_launch("conv_wgrad_f32");
     if (rc != YM_OK) return rc;
     const size_t total = (size_t)d->Cout_real * pl.Ktot;

@@ -60,7 +60,7 @@ class WgradDesc(ctypes.Structure):
                 ('Cin_real', ctypes.c_int32), ('Cout', ctypes.c_int32), ('Cout_real', ctypes.c_int32),
                 ('KH', ctypes.c_int32), ('KW', ctypes.c_int32), ('stride', ctypes.c_int32), ('pad', ctypes.c_int32),
                 ('Ho', ctypes.c_int32), ('Wo', ctypes.c_int32), ('msplit', ctypes.c_int32), ('accumulate', ctypes.c_int32),
-                ('row_end', ctypes.c_int32 * 2), ('dw_seg', ctypes.c_void_p * 2)]
+                ('row_end', ctypes.c_int32 * 2), ('dw_seg', ctypes.c_void_p * 2), ('lds_buffers', ctypes.c_int32)]
 
 
 class AugPlanC(ctypes.Structure):

@@ -110,25 +110,30 @@ def _configure_wgrad(d, key):
     hit = _table().get(key)
     if hit is None and _TUNING:
         big = scratch(torch.device('cuda', torch.cuda.current_device()), 1 << 28)
-        best = (1e30, 0)
-        tiles = -(-d.Cout // 128) * -(-(d.KH * d.KW * d.Cin) // 128)
-        # pixel splits that make the grid a whole number of rounds of the chip (2 workgroups of 68 KB LDS per CU = 512 slots):
-        # power-of-two splits alone left e.g. 756 workgroups = 1.5 rounds for the layer3 3x3 (msplit 14 -> 504 = one round)
-        fill = {max(1, round(256 * j / tiles)) for j in (1, 2, 3, 4, 6, 8, 12, 16)} | {max(1, (256 * j) // tiles) for j in (2, 4, 6, 8)}
-        for ms in sorted({0, 1, 2, 4, 8, 16, 32, 64, 128, 256} | {m_ for m_ in fill if m_ <= 256}):
-            d.msplit = ms
-            need = hip.lib().ym_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
-            if need == 0 or need > big.numel():
-                continue
-            t = _time_launch(lambda: hip.check(hip.lib().ym_conv2d_wgrad(ctypes.byref(d), ctypes.c_void_p(big.data_ptr()),
-                                                                        big.numel(), hip.stream_ptr()), 'wgrad'))
-            if t < best[0] * 0.98:
-                best = (t, ms)
-        hit = [best[1]]
+        best = (1e30, 0, 2)
+        tbn = 64 if d.Cout_real <= 64 else 128
+        tiles = -(-d.Cout // tbn) * -(-(d.KH * d.KW * d.Cin) // 128)
+        for nb, slots in ((2, 512), (1, 768)):
+            # pixel splits that make the grid a whole number of rounds of the chip (2 workgroups of 68 KB LDS per CU = 512 slots,
+            # 3 of 34 KB with the single-buffer variant = 768): power-of-two splits alone left e.g. 756 workgroups = 1.5 rounds
+            # for the layer3 3x3 (msplit 14 -> 504 = one round)
+            half = slots // 2
+            fill = {max(1, round(half * j / tiles)) for j in (1, 2, 3, 4, 6, 8, 12, 16)} | {max(1, (half * j) // tiles) for j in (2, 4, 6, 8)}
+            for ms in sorted({0, 1, 2, 4, 8, 16, 32, 64, 128, 256} | {m_ for m_ in fill if m_ <= 256}):
+                d.msplit, d.lds_buffers = ms, nb
+                need = hip.lib().ym_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
+                if need == 0 or need > big.numel():
+                    continue
+                t = _time_launch(lambda: hip.check(hip.lib().ym_conv2d_wgrad(ctypes.byref(d), ctypes.c_void_p(big.data_ptr()),
+                                                                            big.numel(), hip.stream_ptr()), 'wgrad'))
+                if t < best[0] * 0.98:
+                    best = (t, ms, nb)
+        hit = [best[1], best[2]]
         _table()[key] = hit
         _new_entries[key] = hit
     if hit is not None:
         d.msplit = hit[0]
+        d.lds_buffers = hit[1] if len(hit) > 1 else 2
 
 
 def dump_new_entries(path):
