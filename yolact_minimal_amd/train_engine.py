@@ -20,6 +20,7 @@ from . import hip
 from .hip import ConvDesc, WgradDesc, ACT_NONE, ACT_RELU, ACT_TANH
 
 _scratch = {}
+_desc_cache = {}      # shape key -> (descriptor with every shape-dependent field set, ...): see _conv_forward
 
 # ---- per-shape kernel configuration (measured on MI355X; same JSON as the inference engine) ---------------------
 _TUNING = os.environ.get('YM_TUNE_TRAIN', '0') == '1'     # sweep unseen shapes inline and remember the winner
@@ -327,30 +328,55 @@ def _conv_forward(x, wp, k_pad, cout_pad, kh, kw, stride, pad, shift, act, resid
     b, h, w, cin = x.shape
     ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
     y = None
-    d = ConvDesc()
-    d.inp, d.weight = x.data_ptr(), wp.data_ptr()
+    # Everything of the descriptor that depends only on the layer's SHAPE (sizes, tile / split-K choice, workspace size, whether
+    # the BN statistics fuse) is built once per shape and reused: per call only the pointers change.  (The host spends ~35 us per
+    # launch in a step of ~1100 launches; with the convs on the bf16 pipe the step is host-bound.)
+    key = ('f', x.device.index, b, h, w, cin, cout_pad, kh, kw, stride, pad, act, residual is not None, bn_stats is not None,
+           None if segs is None else tuple((n0, n1, bs, pt, a) for n0, n1, _, bs, pt, a in segs), train_mma())
+    ent = _desc_cache.get(key)
+    if ent is None:
+        d = ConvDesc()
+        d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW = b, h, w, cin, cout_pad, kh, kw
+        d.stride, d.pad, d.Ho, d.Wo, d.k_pad = stride, pad, ho, wo, k_pad
+        if segs is None:
+            d.nseg = 1
+            d.seg[0].n_begin, d.seg[0].n_end = 0, cout_pad
+            d.seg[0].batch_stride, d.seg[0].pitch, d.seg[0].act = ho * wo * cout_pad, cout_pad, act
+        else:
+            d.nseg = len(segs)
+            for i, (n0, n1, ptr, bstride, pitch, a) in enumerate(segs):
+                d.seg[i].n_begin, d.seg[i].n_end = n0, n1
+                d.seg[i].batch_stride, d.seg[i].pitch, d.seg[i].act = bstride, pitch, a
+        # pointers of this first call: the inline sweep (YM_TUNE_TRAIN=1) launches with them, and the two queries below look at
+        # their alignment (torch allocations are 256-byte aligned, so every later call answers the same)
+        d.inp, d.weight = x.data_ptr(), wp.data_ptr()
+        d.shift = shift.data_ptr() if shift is not None else None
+        d.residual = residual.data_ptr() if residual is not None else None
+        if segs is None:
+            y = out if out is not None else torch.empty(b, ho, wo, cout_pad, device=x.device, dtype=torch.float32)
+            d.seg[0].out = y.data_ptr()
+        else:
+            for i, sg in enumerate(segs):
+                d.seg[i].out = sg[2]
+        if cin != 4:
+            _configure_conv(d, f'M{b * ho * wo}_N{cout_pad}_C{cin}_k{kh}_s{stride}_seg{d.nseg}_r{int(residual is not None)}')
+        d.tile_counters = _tile_counters(x.device)
+        fuses = bn_stats is not None and hip.lib().ym_conv2d_fuses_bn_stats(ctypes.byref(d)) == 1
+        ent = _desc_cache[key] = (d, fuses, hip.conv_workspace_bytes(d))
+    d, fused, ws_bytes = ent
+    d.inp, d.weight, d.k_pad = x.data_ptr(), wp.data_ptr(), k_pad
     d.shift = shift.data_ptr() if shift is not None else None
     d.residual = residual.data_ptr() if residual is not None else None
-    d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW = b, h, w, cin, cout_pad, kh, kw
-    d.stride, d.pad, d.Ho, d.Wo, d.k_pad = stride, pad, ho, wo, k_pad
     if segs is None:
-        y = out if out is not None else torch.empty(b, ho, wo, cout_pad, device=x.device, dtype=torch.float32)
-        d.nseg = 1
-        d.seg[0].n_begin, d.seg[0].n_end, d.seg[0].out = 0, cout_pad, y.data_ptr()
-        d.seg[0].batch_stride, d.seg[0].pitch, d.seg[0].act = ho * wo * cout_pad, cout_pad, act
+        if y is None:
+            y = out if out is not None else torch.empty(b, ho, wo, cout_pad, device=x.device, dtype=torch.float32)
+        d.seg[0].out = y.data_ptr()
     else:
-        d.nseg = len(segs)
-        for i, (n0, n1, ptr, bstride, pitch, a) in enumerate(segs):
-            d.seg[i].n_begin, d.seg[i].n_end, d.seg[i].out = n0, n1, ptr
-            d.seg[i].batch_stride, d.seg[i].pitch, d.seg[i].act = bstride, pitch, a
-    if cin != 4:
-        _configure_conv(d, f'M{b * ho * wo}_N{cout_pad}_C{cin}_k{kh}_s{stride}_seg{d.nseg}_r{int(residual is not None)}')
-    d.tile_counters = _tile_counters(x.device)
-    fused = False
-    if bn_stats is not None and hip.lib().ym_conv2d_fuses_bn_stats(ctypes.byref(d)) == 1:
+        for i, sg in enumerate(segs):
+            d.seg[i].out = sg[2]
+    if fused:
         d.bn_sum, d.bn_sumsq = bn_stats.data_ptr(), bn_stats.data_ptr() + cout_pad * 8
-        fused = True
-    ws = scratch(x.device, hip.conv_workspace_bytes(d))
+    ws = scratch(x.device, ws_bytes)
     hip.conv2d_fwd(d, ws)
     if bn_stats is not None:
         return y, fused
@@ -365,19 +391,26 @@ def _conv_dgrad(dz, weight, cout_pad, x_shape, stride, pad, add=None, out=None):
     assert cin_x == cin and cout_pad % 32 == 0
     wd = _pack_dgrad(weight, cout_pad)
     dx = out if out is not None else torch.empty(b, h, w, cin, device=dz.device, dtype=torch.float32)
-    d = ConvDesc()
-    d.inp, d.weight = dz.data_ptr(), wd.data_ptr()
-    d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW = b, dz.shape[1], dz.shape[2], cout_pad, cin, kh, kw
-    d.stride, d.pad, d.Ho, d.Wo, d.k_pad, d.nseg = stride, pad, h, w, kh * kw * cout_pad, 1
-    d.seg[0].n_begin, d.seg[0].n_end, d.seg[0].out = 0, cin, dx.data_ptr()
-    d.seg[0].batch_stride, d.seg[0].pitch, d.seg[0].act = h * w * cin, cin, ACT_NONE
-    d.transposed = 1
+    key = ('d', dz.device.index, b, dz.shape[1], dz.shape[2], cout_pad, cin, kh, kw, stride, pad, h, w, add is not None, train_mma())
+    ent = _desc_cache.get(key)
+    if ent is None:
+        d = ConvDesc()
+        d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW = b, dz.shape[1], dz.shape[2], cout_pad, cin, kh, kw
+        d.stride, d.pad, d.Ho, d.Wo, d.k_pad, d.nseg = stride, pad, h, w, kh * kw * cout_pad, 1
+        d.seg[0].n_begin, d.seg[0].n_end = 0, cin
+        d.seg[0].batch_stride, d.seg[0].pitch, d.seg[0].act = h * w * cin, cin, ACT_NONE
+        d.transposed = 1
+        d.inp, d.weight, d.seg[0].out = dz.data_ptr(), wd.data_ptr(), dx.data_ptr()
+        d.residual = add.data_ptr() if add is not None else None
+        _configure_conv(d, f'T_M{b * h * w}_N{cin}_C{cout_pad}_k{kh}_s{stride}')
+        d.tile_counters = _tile_counters(dz.device)
+        ent = _desc_cache[key] = (d, hip.conv_workspace_bytes(d))
+    d, ws_bytes = ent
+    d.inp, d.weight, d.seg[0].out = dz.data_ptr(), wd.data_ptr(), dx.data_ptr()
     if add is not None:
         assert tuple(add.shape) == (b, h, w, cin) and add.is_contiguous()
         d.residual = add.data_ptr()
-    _configure_conv(d, f'T_M{b * h * w}_N{cin}_C{cout_pad}_k{kh}_s{stride}')
-    d.tile_counters = _tile_counters(dz.device)
-    ws = scratch(dz.device, hip.conv_workspace_bytes(d))
+    ws = scratch(dz.device, ws_bytes)
     hip.conv2d_fwd(d, ws)
     return dx
 
@@ -400,18 +433,27 @@ def _conv_wgrad(x, dz, weight_shape, stride, pad, weight_param=None, dw=None, ac
     if dw is None:
         dw = _grad_slot(weight_param, (cout, cin, kh, kw)) if weight_param is not None else \
             torch.empty(cout, cin, kh, kw, device=x.device, dtype=torch.float32)
-    d = WgradDesc()
+    key = ('w', x.device.index, b, h, w, cin_p, cin, dz.shape[1], dz.shape[2], dz.shape[3], cout, kh, kw, stride, pad,
+           None if segments is None else (segments[0], segments[1]))
+    ent = _desc_cache.get(key)
+    if ent is None:
+        d = WgradDesc()
+        d.x, d.dy, d.dw = x.data_ptr(), dz.data_ptr(), dw.data_ptr()
+        d.B, d.H, d.W, d.Cin, d.Cin_real, d.Cout, d.Cout_real = b, h, w, cin_p, cin, dz.shape[3], cout
+        d.KH, d.KW, d.stride, d.pad, d.Ho, d.Wo, d.msplit = kh, kw, stride, pad, dz.shape[1], dz.shape[2], 0
+        if segments is not None:
+            d.row_end[0], d.row_end[1] = segments[0], segments[1]
+            d.dw_seg[0], d.dw_seg[1] = segments[2].data_ptr(), segments[3].data_ptr()
+        _configure_wgrad(d, f'W_M{b * dz.shape[1] * dz.shape[2]}_N{dz.shape[3]}_C{cin_p}_k{kh}_s{stride}')
+        nbytes = hip.lib().ym_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
+        if nbytes == 0:
+            raise RuntimeError('ym_conv2d_wgrad_workspace_bytes: ' + hip.lib().ym_last_error().decode())
+        ent = _desc_cache[key] = (d, nbytes)
+    d, nbytes = ent
     d.x, d.dy, d.dw = x.data_ptr(), dz.data_ptr(), dw.data_ptr()
-    d.B, d.H, d.W, d.Cin, d.Cin_real, d.Cout, d.Cout_real = b, h, w, cin_p, cin, dz.shape[3], cout
-    d.KH, d.KW, d.stride, d.pad, d.Ho, d.Wo, d.msplit = kh, kw, stride, pad, dz.shape[1], dz.shape[2], 0
     d.accumulate = int(accumulate)
     if segments is not None:
-        d.row_end[0], d.row_end[1] = segments[0], segments[1]
         d.dw_seg[0], d.dw_seg[1] = segments[2].data_ptr(), segments[3].data_ptr()
-    _configure_wgrad(d, f'W_M{b * dz.shape[1] * dz.shape[2]}_N{dz.shape[3]}_C{cin_p}_k{kh}_s{stride}')
-    nbytes = hip.lib().ym_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
-    if nbytes == 0:
-        raise RuntimeError('ym_conv2d_wgrad_workspace_bytes: ' + hip.lib().ym_last_error().decode())
     ws = scratch(x.device, nbytes)
     hip.check(hip.lib().ym_conv2d_wgrad(ctypes.byref(d), ctypes.c_void_p(ws.data_ptr()), ws.numel(), hip.stream_ptr()),
               'ym_conv2d_wgrad')
