@@ -106,6 +106,14 @@ typedef struct {
                              /* bf16 terms and the 3 / 6 most significant cross products run on v_mfma_f32_32x32x16_bf16 with fp32     */
                              /* accumulation (relative error per product ~2^-17 / ~2^-23; tensors in HBM stay fp32).  Needs Cin % 32   */
                              /* == 0, kwaves == 0, no pyramid input; stages is ignored (register-staged double buffer).               */
+    int32_t bnb_relu;        /* Train-mode BatchNorm BACKWARD statistics, fused.  A data-gradient launch (transposed = 1) writes the   */
+    const float* bnb_y;      /* gradient dout[M][Cout] of the PREVIOUS layer's BN output; with bnb_y != NULL its epilogue also adds    */
+    const float* bnb_out;    /* that BN's two backward sums to bn_sum / bn_sumsq (zeroed by the caller): bn_sum[c] += sum_m dz,        */
+    const float* bnb_mean;   /* bn_sumsq[c] += sum_m dz * xhat, where xhat = (y - mean) * invstd, y = bnb_y = that layer's raw conv    */
+    const float* bnb_invstd; /* output [M][Cout], and dz = dout masked by the layer's ReLU when bnb_relu: out > 0 with                 */
+    const float* bnb_gamma;  /* bnb_out = its saved output, or (bnb_out == NULL) xhat * gamma + beta > 0 re-derived exactly as the     */
+    const float* bnb_beta;   /* forward pass computed it.  Same sums as the first pass of ym_bn_train_bwd, which                       */
+                             /* ym_bn_train_bwd_apply then skips.  Needs ym_conv2d_fuses_bn_stats(desc) == 1.                          */
 } ym_conv_desc;
 
 /* y = act(conv(x, w) * scale + shift + residual), one launch (plus a reduce launch if K is split).
@@ -255,6 +263,12 @@ size_t ym_bn_train_bwd_workspace_bytes(int64_t M, int C);
 int ym_bn_train_bwd(const float* dout, const float* out, const float* y, int64_t M, int C, const float* gamma,
                     const float* beta, const float* save_mean, const float* save_invstd, int relu, float* dy, float* dres,
                     float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, ym_stream_t s);
+
+/* Second pass of ym_bn_train_bwd alone: `stats` = fp64 sum_m dz [C] | sum_m dz*xhat [C], already accumulated by the epilogue of the
+ * data-gradient conv that produced `dout` (ym_conv_desc.bnb_*).  Every other argument as in ym_bn_train_bwd. */
+int ym_bn_train_bwd_apply(const float* dout, const float* out, const float* y, int64_t M, int C, const float* gamma,
+                          const float* beta, const float* save_mean, const float* save_invstd, int relu, float* dy, float* dres,
+                          float* dgamma, float* dbeta, const void* stats, ym_stream_t s);
 
 /* Gradient of the fused prediction-head output w.r.t. the 351(+pad)-channel conv output, for all FPN levels in one launch:
  * the loss hands back dclass [B][N][nc], dbox [B][N][4], dcoef [B][N][cd] (N = anchors of all levels, anchor = (pixel, a) level by

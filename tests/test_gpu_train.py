@@ -107,6 +107,67 @@ def test_conv_bn_fn_grads(cin, cout, k, stride, hw, relu, res):
         torch.testing.assert_close(_nchw(rg.grad).cpu(), rc.grad, rtol=1e-4, atol=1e-5)
 
 
+def test_bn_backward_sums_ride_on_the_consumers_dgrad():
+    """Two identity Bottlenecks (modules/resnet.py:20-40) in train mode: with BnGradLink the backward sums of bn1, bn2 and of the
+    first block's bn3 are accumulated by the epilogue of the data-gradient conv that writes their `dout`; the gradients must be
+    those of the two-pass BN backward (same terms, fp64 sums in a different order) and of torch's CPU autograd."""
+    import torch.nn as nn
+    from yolact_minimal_amd import train_engine as T
+
+    class Block(nn.Module):
+        def __init__(self, c, p):
+            super().__init__()
+            self.conv1, self.bn1 = nn.Conv2d(c, p, 1, bias=False), nn.BatchNorm2d(p)
+            self.conv2, self.bn2 = nn.Conv2d(p, p, 3, 1, 1, bias=False), nn.BatchNorm2d(p)
+            self.conv3, self.bn3 = nn.Conv2d(p, c, 1, bias=False), nn.BatchNorm2d(c)
+
+        def forward(self, x):
+            y = F.relu(self.bn1(self.conv1(x)))
+            y = F.relu(self.bn2(self.conv2(y)))
+            return F.relu(self.bn3(self.conv3(y)) + x)
+
+    torch.manual_seed(5)
+    blocks = nn.ModuleList([Block(128, 32), Block(128, 32)]).train()
+    for m in blocks.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            nn.init.uniform_(m.weight, 0.5, 1.5)
+            nn.init.normal_(m.bias, 0, 0.2)
+    x = torch.randn(3, 128, 19, 19)
+    gy = torch.randn(3, 128, 19, 19)
+    xc = x.clone().requires_grad_()
+    y = xc
+    for blk in blocks:
+        y = blk(y)
+    y.backward(gy)
+    ref = {n: p.grad.clone() for n, p in blocks.named_parameters()}
+    ref_dx = xc.grad.clone()
+
+    blocks.to(DEV)
+    results = {}
+    for fuse in (False, True):
+        T._FUSE_BN_BWD = fuse
+        T.bn_bwd_fused_launches[0] = 0
+        blocks.zero_grad(set_to_none=True)
+        xg = _nhwc(x).to(DEV).requires_grad_()
+        T._stats_pool.begin(xg.device)
+        t = xg
+        for blk in blocks:
+            link = T.ResGradLink()
+            h = T._conv_bn(t, blk.conv1, blk.bn1, link=link, role='take', sole_grad=True)
+            h = T._conv_bn(h, blk.conv2, blk.bn2, sole_grad=True)
+            t = T._conv_bn(h, blk.conv3, blk.bn3, relu=True, residual=t, link=link, role='give', sole_grad=True)
+        t.backward(_nhwc(gy).to(DEV))
+        # bn1, bn2 of both blocks + bn3 of the first one (the second block's output has no ConvBn consumer)
+        assert T.bn_bwd_fused_launches[0] == (5 if fuse else 0)
+        results[fuse] = ({n: p.grad.cpu().clone() for n, p in blocks.named_parameters()}, _nchw(xg.grad).cpu())
+    T._FUSE_BN_BWD = True
+    for n in ref:
+        torch.testing.assert_close(results[True][0][n], results[False][0][n], rtol=2e-5, atol=2e-6, msg=lambda m: f'{n}: {m}')
+        assert float((results[True][0][n] - ref[n]).norm() / ref[n].norm()) < 2e-4, n        # torch CPU autograd, per tensor
+    torch.testing.assert_close(results[True][1], results[False][1], rtol=2e-5, atol=2e-6)
+    assert float((results[True][1] - ref_dx).norm() / ref_dx.norm()) < 2e-4
+
+
 def test_pool_and_upsample_backward():
     from yolact_minimal_amd.train_engine import MaxPool, Bilinear2x
     g = torch.Generator().manual_seed(0)

@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--cfg', default='res101_coco')
 ap.add_argument('--batch', type=int, default=8)
 ap.add_argument('--steps', type=int, default=8)
+ap.add_argument('--ab', default='', help="A/B inside one process: name of a boolean switch of train_engine (e.g. _FUSE_BN_BWD)")
 args = ap.parse_args()
 dev = torch.device('cuda:0')
 cfg = build_cfg(args.cfg, 'train', 544, train_bs=args.batch, bs_per_gpu=args.batch)
@@ -33,3 +34,18 @@ for _ in range(args.steps):
     tr.step(img, boxes, masks)
 torch.cuda.synchronize()
 print(f'{(time.perf_counter() - t0) / args.steps * 1e3:.2f} ms/step over {args.steps} steps (+2 warm-up)')
+if args.ab:
+    from yolact_minimal_amd import train_engine as T  # noqa: E402
+    for rep in range(3):
+        for val in (False, True):
+            setattr(T, args.ab, val)
+            T._desc_cache.clear()
+            for _ in range(2):
+                tr.step(img, boxes, masks)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                tr.step(img, boxes, masks)
+            torch.cuda.synchronize()
+            print(f'  {args.ab}={val}: {(time.perf_counter() - t0) / args.steps * 1e3:.2f} ms/step')
+    print('fused BN-backward launches so far:', T.bn_bwd_fused_launches[0])

@@ -26,6 +26,8 @@ for key, hit in sorted(table.items()):
     M, n, c, k, s = (int(v) for v in m.groups())
     b = 8
     ho = int(round(math.sqrt(M / b)))
+    if ho * ho * b != M or (s == 2 and ho not in S2_IN):
+        continue                      # entries of other batch sizes / the pyramid-batched head
     h = S2_IN[ho] if s == 2 else ho
     pad = k // 2
     x = torch.randn(b, h, h, c, device=dev)
@@ -36,6 +38,7 @@ for key, hit in sorted(table.items()):
     d.x, d.dy, d.dw = x.data_ptr(), dy.data_ptr(), dw.data_ptr()
     d.B, d.H, d.W, d.Cin, d.Cin_real, d.Cout, d.Cout_real = b, h, h, c, cin_real, n, n
     d.KH, d.KW, d.stride, d.pad, d.Ho, d.Wo, d.msplit = k, k, s, pad, ho, ho, hit[0]
+    d.lds_buffers = hit[1] if len(hit) > 1 else 2
     need = hip.lib().ym_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
     if need == 0 or need > big.numel():
         print(key, 'skipped', need)

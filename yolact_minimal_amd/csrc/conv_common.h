@@ -35,6 +35,13 @@ struct ConvP {
     float* ws;  // split-K partials [ksplit][M][Cout] (only when ksplit > 1)
     double* bn_sum;    // optional fused per-channel sum / sum of squares of the OUTPUT (train-mode BatchNorm)
     double* bn_sumsq;
+    const float* bnb_y;       // optional (with bn_sum): BN-backward sums of the layer whose output gradient this launch writes
+    const float* bnb_out;     // (ym_conv_desc.bnb_*): bn_sum += dz, bn_sumsq += dz * xhat
+    const float* bnb_mean;
+    const float* bnb_invstd;
+    const float* bnb_gamma;
+    const float* bnb_beta;
+    int bnb_relu;
     int* counters;     // optional per-output-tile arrival counters: fused split-K finish (see ym_conv_desc.tile_counters)
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, Kpad;
     int M, HoWo, nkt, ksplit, kt_per_split, tiles_m, tiles_n;

@@ -607,6 +607,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
             }
             const int act = p.seg[0].act;
             float* outb = p.seg[0].out + n;
+            const bool fwd_stats = p.bn_sum != nullptr && p.bnb_y == nullptr;
             const float* resb = (p.residual && !(direct && PRE_RES)) ? p.residual + n : nullptr;
 #pragma unroll
             for (int rk = 0; rk < BM / RPP; ++rk) {
@@ -633,9 +634,46 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = ym_apply_act(v[e], act);
                     *reinterpret_cast<f32x4*>(outb + (size_t)m * p.Cout) = v;
-                    if (p.bn_sum) {
+                    if (fwd_stats) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { const double dv = v[e]; bsum[e] += dv; bsq[e] += dv * dv; }
+                    }
+                }
+            }
+            if (p.bnb_y) {
+                // BN-BACKWARD sums of the layer whose output gradient this launch just wrote (ym_conv_desc.bnb_*; the terms of
+                // k_col_reduce<1>).  A second, rolled loop that re-reads this lane's own float4s of dout (L2 hits) instead of
+                // work inside the unrolled loop above: there the extra loads and constants cost every instantiation of this
+                // kernel 16-24 VGPRs (64x64 tile: 124 -> 144 = one resident wave per SIMD less), whether it used them or not.
+                const f32x4 b_mu = *reinterpret_cast<const f32x4*>(p.bnb_mean + n), b_is = *reinterpret_cast<const f32x4*>(p.bnb_invstd + n);
+                f32x4 b_g = {1.f, 1.f, 1.f, 1.f}, b_bt = {0.f, 0.f, 0.f, 0.f};
+                const bool remask = p.bnb_relu && !p.bnb_out;
+                if (remask) { b_g = *reinterpret_cast<const f32x4*>(p.bnb_gamma + n); b_bt = *reinterpret_cast<const f32x4*>(p.bnb_beta + n); }
+                constexpr int NR = BM / RPP, UR = 2;                     // rows of this lane; UR of them in flight at a time (4: +16 VGPRs)
+#pragma unroll 1
+                for (int rk0 = 0; rk0 < NR; rk0 += UR) {
+                    f32x4 dv[UR], yy[UR], o[UR];
+#pragma unroll
+                    for (int u = 0; u < UR; ++u) {
+                        const int m = m0 + row0 + (rk0 + u) * RPP;
+                        const size_t off = (size_t)(m < p.M ? m : p.M - 1) * p.Cout + n;       // (rows past the end: a valid address, value unused)
+                        dv[u] = *reinterpret_cast<const f32x4*>(p.seg[0].out + off);
+                        yy[u] = *reinterpret_cast<const f32x4*>(p.bnb_y + off);
+                        if (p.bnb_out) o[u] = *reinterpret_cast<const f32x4*>(p.bnb_out + off);
+                    }
+#pragma unroll
+                    for (int u = 0; u < UR; ++u) {
+                        if (m0 + row0 + (rk0 + u) * RPP >= p.M) continue;
+                        if (!p.bnb_out) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[u][e] = remask ? bn_affine(yy[u][e], b_mu[e], b_is[e], b_g[e], b_bt[e]) : 1.f;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const double dd = o[u][e] > 0.f ? dv[u][e] : 0.f;
+                            bsum[e] += dd;
+                            bsq[e] += dd * (double)((yy[u][e] - b_mu[e]) * b_is[e]);
+                        }
                     }
                 }
             }
@@ -947,6 +985,8 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
         p.vec = (vec_epilogue(d) && ((uintptr_t)workspace & 15) == 0) ? 1 : 0;
     }
     p.bn_sum = d->bn_sum; p.bn_sumsq = d->bn_sumsq;
+    p.bnb_y = d->bnb_y; p.bnb_out = d->bnb_out; p.bnb_mean = d->bnb_mean; p.bnb_invstd = d->bnb_invstd;
+    p.bnb_gamma = d->bnb_gamma; p.bnb_beta = d->bnb_beta; p.bnb_relu = d->bnb_relu;
     p.trace = nullptr;
 #ifdef YM_TRACE
     if (const char* e = getenv("YM_TRACE_PTR")) p.trace = (long long*)strtoull(e, nullptr, 10);
@@ -968,6 +1008,12 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
     if (d->bn_sum) {
         YM_REQUIRE(d->bn_sumsq && p.vec && (pl.slots() == 1 || p.counters) && d->kwaves == 0,
                    "conv: bn_sum given but this configuration cannot fuse the statistics (ask ym_conv2d_fuses_bn_stats)");
+    }
+    if (d->bnb_y) {
+        YM_REQUIRE(d->bn_sum && d->bnb_mean && d->bnb_invstd && (!d->bnb_relu || d->bnb_out || (d->bnb_gamma && d->bnb_beta)),
+                   "conv: bnb_y needs bn_sum / bn_sumsq, bnb_mean, bnb_invstd and (with bnb_relu) bnb_out or bnb_gamma + bnb_beta");
+        YM_REQUIRE(d->Cout % 4 == 0 && ((uintptr_t)d->bnb_y & 15) == 0 && ((uintptr_t)d->bnb_out & 15) == 0,
+                   "conv: bnb_y / bnb_out must be 16-byte aligned [M][Cout] tensors");
     }
     hipStream_t st = (hipStream_t)s;
     if (d->kwaves > 0) return ym_launch_conv_wave(p, pl.bm, pl.bn, d->kwaves, st);

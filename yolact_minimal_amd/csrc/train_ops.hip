@@ -21,12 +21,7 @@ inline int rows_grid(long long M, int C4, int rows_per_block_hint = 64) {
 // ---- column reductions ------------------------------------------------------------------------------------
 // Thread (cq, rl): channel quad cq = tid % CQ, row lane rl = tid / CQ, CQ = min(C/4, 256).  Each block walks rows
 // rl + k*RL of its row range; partials are combined through LDS and then one fp64 atomicAdd per (block, channel).
-// The normalise + affine step of train-mode BN, in ONE fixed operation order (sub, mul, fused multiply-add): the forward pass and
-// the backward kernels that re-derive the ReLU mask from y instead of reading `out` must agree on the sign bit for bit.
-__device__ __forceinline__ float bn_affine(float v, float mu, float is, float g, float b) {
-    return __builtin_fmaf((v - mu) * is, g, b);
-}
-
+// (bn_affine, the normalise + affine step in its one fixed operation order, lives in ym_common.h)
 // MODE 0: sum x, sum x^2           (bn forward statistics)
 // MODE 1: sum dz, sum dz*xhat      (bn backward; dz = dout masked by relu(out); out == nullptr: the mask is re-derived from y)
 // MODE 2: sum dz                   (bias gradient; dz = dy * act'(y))
@@ -612,6 +607,18 @@ extern "C" int ym_bn_train_bwd(const float* dout, const float* out, const float*
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid((size_t)M * (C / 4))), dim3(256), 0, st, dout, out, y, save_mean,
                        save_invstd, gamma, beta, db, dg, relu, dy, dres, (long long)M, C, dgamma, dbeta);
     return ym_check_launch("bn_train_bwd");
+}
+
+extern "C" int ym_bn_train_bwd_apply(const float* dout, const float* out, const float* y, int64_t M, int C, const float* gamma,
+                                     const float* beta, const float* save_mean, const float* save_invstd, int relu, float* dy,
+                                     float* dres, float* dgamma, float* dbeta, const void* stats, ym_stream_t s) {
+    YM_REQUIRE(dout && y && gamma && save_mean && save_invstd && dy && dgamma && dbeta && stats && (out || !relu || beta),
+               "bn_train_bwd_apply: null pointer (relu needs `out`, or `beta` to re-derive the mask from y)");
+    YM_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_train_bwd_apply: C %% 4 != 0");
+    const double* db = (const double*)stats;
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid((size_t)M * (C / 4))), dim3(256), 0, (hipStream_t)s, dout, out, y, save_mean,
+                       save_invstd, gamma, beta, db, db + C, relu, dy, dres, (long long)M, C, dgamma, dbeta);
+    return ym_check_launch("bn_train_bwd_apply");
 }
 
 extern "C" int ym_act_bias_bwd(const float* dy, const float* y, int64_t M, int C, int act, float* dz, float* dbias,

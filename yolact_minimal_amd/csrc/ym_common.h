@@ -37,6 +37,13 @@ __device__ __forceinline__ int ym_xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
+// The normalise + affine step of train-mode BN, in ONE fixed operation order (sub, mul, fused multiply-add): the forward pass and
+// every backward kernel that re-derives the ReLU mask from y instead of reading `out` (train_ops.hip, the fused statistics of
+// the data-gradient epilogue in conv_mfma.hip) must agree on the sign bit for bit.
+__device__ __forceinline__ float bn_affine(float v, float mu, float is, float g, float b) {
+    return __builtin_fmaf((v - mu) * is, g, b);
+}
+
 __device__ __forceinline__ float ym_apply_act(float v, int act) {
     if (act == YM_ACT_RELU) return v < 0.f ? 0.f : v;   // NaN stays NaN, like torch.relu
     if (act == YM_ACT_TANH) return tanhf(v);

@@ -31,7 +31,7 @@ ABI_SYMBOLS = (
     'ym_swin_window_attention_bwd', 'ym_adamw_step',
     'ym_match_anchors', 'ym_match_anchors_batch', 'ym_loss_workspace_bytes', 'ym_class_box_loss', 'ym_semantic_loss',
     'ym_semantic_loss_batch',
-    'ym_bn_train_bwd_workspace_bytes', 'ym_bn_train_bwd', 'ym_act_bias_bwd', 'ym_conv2d_fuses_bn_stats', 'ym_bn_train_fwd_stats', 'ym_maxpool3x3s2_bwd', 'ym_maxpool3x3s2_fwd_idx', 'ym_maxpool3x3s2_bwd_idx', 'ym_bilinear2x_bwd', 'ym_sgd_step',
+    'ym_bn_train_bwd_workspace_bytes', 'ym_bn_train_bwd', 'ym_bn_train_bwd_apply', 'ym_act_bias_bwd', 'ym_conv2d_fuses_bn_stats', 'ym_bn_train_fwd_stats', 'ym_maxpool3x3s2_bwd', 'ym_maxpool3x3s2_fwd_idx', 'ym_maxpool3x3s2_bwd_idx', 'ym_bilinear2x_bwd', 'ym_sgd_step',
 )
 
 
@@ -51,7 +51,10 @@ class ConvDesc(ctypes.Structure):
                 ('ksplit', ctypes.c_int32), ('kwaves', ctypes.c_int32), ('transposed', ctypes.c_int32),
                 ('stages', ctypes.c_int32), ('bn_sum', ctypes.c_void_p), ('bn_sumsq', ctypes.c_void_p),
                 ('tile_counters', ctypes.c_void_p), ('nlevels', ctypes.c_int32), ('level_h', ctypes.c_int32 * 5),
-                ('level_w', ctypes.c_int32 * 5), ('tail_tiles', ctypes.c_int32), ('tail_ksplit', ctypes.c_int32), ('mma', ctypes.c_int32)]
+                ('level_w', ctypes.c_int32 * 5), ('tail_tiles', ctypes.c_int32), ('tail_ksplit', ctypes.c_int32), ('mma', ctypes.c_int32),
+                ('bnb_relu', ctypes.c_int32), ('bnb_y', ctypes.c_void_p), ('bnb_out', ctypes.c_void_p),
+                ('bnb_mean', ctypes.c_void_p), ('bnb_invstd', ctypes.c_void_p), ('bnb_gamma', ctypes.c_void_p),
+                ('bnb_beta', ctypes.c_void_p)]
 
 
 class WgradDesc(ctypes.Structure):
@@ -186,6 +189,7 @@ def lib():
         L.ym_bn_train_bwd_workspace_bytes.argtypes = [i64, i32]
         L.ym_bn_train_bwd_workspace_bytes.restype = sz
         L.ym_bn_train_bwd.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, sz, vp]
+        L.ym_bn_train_bwd_apply.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]
         L.ym_act_bias_bwd.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp, sz, vp]
         L.ym_maxpool3x3s2_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
         L.ym_maxpool3x3s2_fwd_idx.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]

@@ -383,15 +383,18 @@ def _conv_forward(x, wp, k_pad, cout_pad, kh, kw, stride, pad, shift, act, resid
     return y
 
 
-def _conv_dgrad(dz, weight, cout_pad, x_shape, stride, pad, add=None, out=None):
+def _conv_dgrad(dz, weight, cout_pad, x_shape, stride, pad, add=None, out=None, bn_bwd=None):
     """dx [B,H,W,Cin] from dz [B,Ho,Wo,cout_pad] (cout_pad % 32 == 0) and the OIHW weight; `add` [B,H,W,Cin] (another
-    consumer's gradient of the same tensor) is summed in the epilogue; `out`: destination instead of a fresh tensor."""
+    consumer's gradient of the same tensor) is summed in the epilogue; `out`: destination instead of a fresh tensor.
+    `bn_bwd`: the BnGradLink of the ConvBn that PRODUCED x, when dx is the whole gradient of that tensor: the epilogue then
+    also accumulates that BatchNorm's backward sums (ym_conv_desc.bnb_*) and leaves them in the link."""
     cout, cin, kh, kw = weight.shape
     b, h, w, cin_x = x_shape
     assert cin_x == cin and cout_pad % 32 == 0
     wd = _pack_dgrad(weight, cout_pad)
     dx = out if out is not None else torch.empty(b, h, w, cin, device=dz.device, dtype=torch.float32)
-    key = ('d', dz.device.index, b, dz.shape[1], dz.shape[2], cout_pad, cin, kh, kw, stride, pad, h, w, add is not None, train_mma())
+    key = ('d', dz.device.index, b, dz.shape[1], dz.shape[2], cout_pad, cin, kh, kw, stride, pad, h, w, add is not None, train_mma(),
+           bn_bwd is not None)
     ent = _desc_cache.get(key)
     if ent is None:
         d = ConvDesc()
@@ -404,14 +407,23 @@ def _conv_dgrad(dz, weight, cout_pad, x_shape, stride, pad, add=None, out=None):
         d.residual = add.data_ptr() if add is not None else None
         _configure_conv(d, f'T_M{b * h * w}_N{cin}_C{cout_pad}_k{kh}_s{stride}')
         d.tile_counters = _tile_counters(dz.device)
-        ent = _desc_cache[key] = (d, hip.conv_workspace_bytes(d))
-    d, ws_bytes = ent
+        fuses = bn_bwd is not None and hip.lib().ym_conv2d_fuses_bn_stats(ctypes.byref(d)) == 1
+        ent = _desc_cache[key] = (d, hip.conv_workspace_bytes(d), fuses)
+    d, ws_bytes, fuses = ent
     d.inp, d.weight, d.seg[0].out = dz.data_ptr(), wd.data_ptr(), dx.data_ptr()
     if add is not None:
         assert tuple(add.shape) == (b, h, w, cin) and add.is_contiguous()
         d.residual = add.data_ptr()
+    if fuses:
+        assert bn_bwd.c == cin and bn_bwd.m == b * h * w
+        stats = _stats_pool.take(2 * cin, dz.device)                 # zeroed
+        d.bn_sum, d.bn_sumsq = stats.data_ptr(), stats.data_ptr() + cin * 8
+        d.bnb_y, d.bnb_out, d.bnb_mean, d.bnb_invstd = bn_bwd.y, bn_bwd.out, bn_bwd.mean, bn_bwd.invstd
+        d.bnb_gamma, d.bnb_beta, d.bnb_relu = bn_bwd.gamma, bn_bwd.beta, bn_bwd.relu
     ws = scratch(dz.device, ws_bytes)
     hip.conv2d_fwd(d, ws)
+    if fuses:
+        bn_bwd.stats, bn_bwd.dout_ptr = stats, dx.data_ptr()
     return dx
 
 
@@ -645,13 +657,30 @@ class ResGradLink:
         self.grad = None
 
 
+class BnGradLink:
+    """Joins a ConvBn with the ONE backward launch that writes the gradient of its output (the data-gradient conv of its only
+    consumer, or of the consumer that collects every contribution: ResGradLink 'take').  Forward fills in where the BN's saved
+    tensors live (raw pointers: the tensors themselves are owned by the node's saved_tensors, which outlive the consumer's
+    backward); the consumer's backward leaves the two fp64 column sums in `stats` and the address of the gradient it wrote in
+    `dout_ptr`, and the BN's own backward skips its statistics pass when that is the gradient it was handed."""
+    __slots__ = ('y', 'out', 'mean', 'invstd', 'gamma', 'beta', 'relu', 'c', 'm', 'stats', 'dout_ptr')
+
+    def __init__(self):
+        self.stats = self.dout_ptr = None
+
+
+_FUSE_BN_BWD = os.environ.get('YM_FUSE_BN_BWD', '1') != '0'
+bn_bwd_fused_launches = [0]      # BN backward passes that skipped their statistics pass (tests / tools look at it)
+
+
 class ConvBn(torch.autograd.Function):
     """out = relu?(BN_train(conv(x, W)) + residual?) — one Bottleneck stage (modules/resnet.py:23-38) in train mode."""
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, running_mean, running_var, residual, stride, pad, relu, momentum, eps, link=None,
-                role=None):
+                role=None, producer=None, own=None):
         ctx.link, ctx.role = link, role
+        ctx.producer, ctx.own = producer, own
         cout, cin, kh, kw = weight.shape
         wp, k_pad = _pack_fwd(weight, x.shape[-1], cout)
         stats = _stats_pool.take(2 * cout, x.device)           # zeroed (the fused epilogue accumulates into it)
@@ -672,9 +701,14 @@ class ConvBn(torch.autograd.Function):
                                                 hip.ptr(out), hip.ptr(mean), hip.ptr(invstd), ctypes.c_void_p(stats.data_ptr()),
                                                 stats.numel() * 8, hip.stream_ptr()), 'ym_bn_train_fwd')
         # `out` is only needed for the ReLU mask when a residual was added; otherwise backward re-derives the mask from y
-        ctx.save_for_backward(x, weight, gamma, y, out if (relu and (residual is not None or beta is None)) else None, mean, invstd)
+        mask_out = out if (relu and (residual is not None or beta is None)) else None
+        ctx.save_for_backward(x, weight, gamma, y, mask_out, mean, invstd)
         ctx.meta = (stride, pad, relu, residual is not None)
         ctx.beta_param = beta
+        if own is not None:
+            own.y, own.out = y.data_ptr(), (mask_out.data_ptr() if mask_out is not None else None)
+            own.mean, own.invstd, own.gamma = mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr()
+            own.beta, own.relu, own.c, own.m = (beta.data_ptr() if beta is not None else None), int(relu), cout, m
         return out
 
     @staticmethod
@@ -688,13 +722,24 @@ class ConvBn(torch.autograd.Function):
         dres = torch.empty_like(y) if has_res else None
         dgamma = _grad_slot(gamma, (cout,))
         dbeta = _grad_slot(ctx.beta_param, (cout,)) if ctx.beta_param is not None else torch.empty(cout, device=y.device)
-        ws = scratch(y.device, hip.lib().ym_bn_train_bwd_workspace_bytes(m, cout))
-        hip.check(hip.lib().ym_bn_train_bwd(hip.ptr(dout), hip.ptr(out) if (relu and out is not None) else None, hip.ptr(y), m, cout,
-                                            hip.ptr(gamma.detach()),
-                                            hip.ptr(ctx.beta_param.detach()) if ctx.beta_param is not None else None, hip.ptr(mean),
-                                            hip.ptr(invstd), int(relu), hip.ptr(dy),
-                                            hip.ptr(dres) if has_res else None, hip.ptr(dgamma), hip.ptr(dbeta),
-                                            ctypes.c_void_p(ws.data_ptr()), ws.numel(), hip.stream_ptr()), 'ym_bn_train_bwd')
+        own = ctx.own
+        out_ptr = hip.ptr(out) if (relu and out is not None) else None
+        beta_ptr = hip.ptr(ctx.beta_param.detach()) if ctx.beta_param is not None else None
+        if own is not None and own.stats is not None and own.dout_ptr == dout.data_ptr():
+            # the launch that wrote `dout` already summed dz and dz * xhat over the pixels (BnGradLink): apply pass only
+            hip.check(hip.lib().ym_bn_train_bwd_apply(hip.ptr(dout), out_ptr, hip.ptr(y), m, cout, hip.ptr(gamma.detach()), beta_ptr,
+                                                      hip.ptr(mean), hip.ptr(invstd), int(relu), hip.ptr(dy),
+                                                      hip.ptr(dres) if has_res else None, hip.ptr(dgamma), hip.ptr(dbeta),
+                                                      ctypes.c_void_p(own.stats.data_ptr()), hip.stream_ptr()), 'ym_bn_train_bwd_apply')
+            bn_bwd_fused_launches[0] += 1
+        else:
+            ws = scratch(y.device, hip.lib().ym_bn_train_bwd_workspace_bytes(m, cout))
+            hip.check(hip.lib().ym_bn_train_bwd(hip.ptr(dout), out_ptr, hip.ptr(y), m, cout, hip.ptr(gamma.detach()), beta_ptr,
+                                                hip.ptr(mean), hip.ptr(invstd), int(relu), hip.ptr(dy),
+                                                hip.ptr(dres) if has_res else None, hip.ptr(dgamma), hip.ptr(dbeta),
+                                                ctypes.c_void_p(ws.data_ptr()), ws.numel(), hip.stream_ptr()), 'ym_bn_train_bwd')
+        if own is not None:
+            own.stats = own.dout_ptr = None
         need_dx = ctx.needs_input_grad[0]
         if need_dx and cout % 32 != 0:
             raise RuntimeError('ConvBn dgrad needs Cout % 32 == 0')
@@ -704,9 +749,9 @@ class ConvBn(torch.autograd.Function):
                 ctx.link.grad, dres = dres, None                  # handed to the consumer that shares the tensor
             elif ctx.role == 'take' and need_dx:
                 add, ctx.link.grad = ctx.link.grad, None
-        dx = _conv_dgrad(dy, weight, cout, x.shape, stride, pad, add) if need_dx else None
+        dx = _conv_dgrad(dy, weight, cout, x.shape, stride, pad, add, bn_bwd=ctx.producer) if need_dx else None
         dw = _conv_wgrad(x, dy, weight.shape, stride, pad, weight)
-        return dx, dw, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None
+        return dx, dw, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None, None
 
 
 class MaxPool(torch.autograd.Function):
@@ -753,9 +798,15 @@ class Bilinear2x(torch.autograd.Function):
         return dx, None
 
 
-def _conv_bn(x, conv, bn, relu=True, residual=None, link=None, role=None):
+def _conv_bn(x, conv, bn, relu=True, residual=None, link=None, role=None, sole_grad=False):
+    """`sole_grad`: this conv's data-gradient launch writes the WHOLE gradient of x (x has no other consumer, or this is the
+    ResGradLink 'take' end that folds the other one in) -> it may carry the backward statistics of the BN that produced x."""
+    producer = getattr(x, '_ym_bn_link', None) if (sole_grad and _FUSE_BN_BWD) else None
+    own = BnGradLink() if _FUSE_BN_BWD else None
     out = ConvBn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, conv.stride[0],
-                       conv.padding[0], relu, float(bn.momentum), float(bn.eps), link, role)
+                       conv.padding[0], relu, float(bn.momentum), float(bn.eps), link, role, producer, own)
+    if own is not None:
+        out._ym_bn_link = own
     if not getattr(bn, '_ym_nbt_flat', False):               # the trainer bumps all counters with one launch
         bn.num_batches_tracked += 1
     return out
@@ -788,10 +839,11 @@ def train_features(net, img):
             for blk in stage:
                 # identity blocks: x feeds conv1 and the residual add; their two gradients meet in conv1's dgrad epilogue
                 link = ResGradLink() if (blk.downsample is None and x.requires_grad and _FUSE_RES_GRAD) else None
-                y = _conv_bn(x, blk.conv1, blk.bn1, link=link, role='take')
-                y = _conv_bn(y, blk.conv2, blk.bn2)
+                # (with the link, conv1's dgrad writes the whole gradient of x: it also carries the previous bn3's backward sums)
+                y = _conv_bn(x, blk.conv1, blk.bn1, link=link, role='take', sole_grad=link is not None)
+                y = _conv_bn(y, blk.conv2, blk.bn2, sole_grad=True)
                 skip = _conv_bn(x, blk.downsample[0], blk.downsample[1], relu=False) if blk.downsample is not None else x
-                x = _conv_bn(y, blk.conv3, blk.bn3, relu=True, residual=skip, link=link, role='give')
+                x = _conv_bn(y, blk.conv3, blk.bn3, relu=True, residual=skip, link=link, role='give', sole_grad=True)
             outs.append(x)
         c3, c4, c5 = outs[1:4]
     fpn = net.fpn
