@@ -5,9 +5,8 @@
 //     statistics recomputed from x; per-workgroup partial dgamma/dbeta + an ordered second pass (deterministic).
 //   Patch-merge LayerNorm backward: same, with the 2x2 gather of the forward turned into a scatter of dx.
 //   GELU (exact erf form, :92-96) forward / backward on the saved pre-activation.
-//   Window attention backward (:172-200 + pad / roll / partition of :249-283): one 64-lane workgroup per (window, head),
-//     lane = token; the 49x49 score matrix is rebuilt in registers row by row, dV / dK reduce over queries through LDS.  Attention
-//     is 1.5 % of the network's FLOPs, so this is plain FMA code: no MFMA tiling.
+//   Window attention backward (:172-200 + pad / roll / partition of :249-283): one wave per (window, head) on the f32 MFMA, the
+//     49x49 matrices held in registers in both orientations (see k_window_attention_bwd).
 #include "ym_common.h"
 
 namespace {
@@ -147,7 +146,7 @@ __global__ void k_gelu_bwd(const float* __restrict__ dy, const float* __restrict
 }
 
 // ---- window attention backward ------------------------------------------------------------------------------------------
-constexpr int WS = 7, NTOK = 49, HD = 32, LP = HD + 1, PP = NTOK /* odd pitch: lane-private rows are conflict-free */, NREL = (2 * WS - 1) * (2 * WS - 1);
+constexpr int WS = 7, NTOK = 49, HD = 32, NREL = (2 * WS - 1) * (2 * WS - 1);
 
 struct AttnBwdP {
     const float* qkv;        // [B*H*W][3C]
@@ -161,144 +160,293 @@ struct AttnBwdP {
     float scale;
 };
 
-// grid = heads * nblk workgroups of 64 lanes; workgroup (head, k) walks windows k, k + nblk, ... of its head, so the
-// relative-position-bias gradient of the head is accumulated in LDS and flushed once.
-__global__ __launch_bounds__(64) void k_window_attention_bwd(const AttnBwdP p) {
-    __shared__ float s_q[NTOK][LP], s_k[NTOK][LP], s_v[NTOK][LP], s_do[NTOK][LP];
-    __shared__ float s_p[NTOK][PP], s_ds[NTOK][PP];
-    __shared__ float s_bias[NREL], s_dbias[NREL];
-    __shared__ int s_tok[64], s_reg[64];
-    const int lane = threadIdx.x;
+// One WAVE per (window, head) on the f32 MFMA (v_mfma_f32_32x32x2_f32), 49 tokens padded to 64.  Workgroup = 4 waves of ONE head:
+// workgroup (head, k) walks windows 4k + wave, 4(k + nblk) + wave, ... so the head's relative-position-bias gradient is summed in
+// LDS and flushed once.  A 64x64 matrix of the wave lives in registers in one of two layouts:
+//   T: X^T[key][q] — key = kt*32 + (r&3) + 8*(r>>2) + 4h across the 16 accumulator registers r and the lane half h, q = qt*32 +
+//      (lane&31) across lanes (the D layout of MFMA(A = key-major operand, B = query-major operand));
+//   N: X[q][key]  — the same with the roles of the operands swapped.
+// A register of layout T is exactly the A-operand element (i = q, k = key) of one MFMA step of (X . B[key][d]); layout N serves
+// (X^T . B[q][d]).  So no matrix is ever transposed through LDS; both layouts are simply computed (7 x 64 MFMAs per unit):
+//   phase T:  S^T = K Q_s^T -> P^T (softmax over keys = over registers + one cross-half shuffle, as in the forward kernel);
+//             dP^T = V dO^T;  rowsum[q] = sum_key P^T dP^T;  dS^T = P^T o (dP^T - rowsum);  dbias[rel(q,key)] += dS;
+//             dQ = scale * dS K          (A = dS^T registers)
+//   phase N:  S = Q_s K^T -> P with the row max / 1/sum of phase T (per-wave LDS vectors);  dP = dO V^T;  dS likewise;
+//             dV = P^T dO, dK = dS^T Q_s (A = P / dS registers).
+// The scalar-FMA predecessor of this kernel (one lane per token, operands broadcast from LDS) took 633 us per launch against
+// 54 us for the forward kernel: 15.6 % of a Swin-T training step.
+// The wave's four operand matrices (Q_s = scale * q, K, V, dO), each [64 tokens][32] floats at pitch MP in LDS, staged once per
+// unit with coalesced loads (tokens >= 49 stay zero; padded tokens carry the qkv bias, dO = 0 there).  Every fragment below is an
+// LDS read: fetched straight from global memory (16 bytes per lane at a 3C-float stride, each tile ~8 times per unit) the kernel
+// ran at 351 us per launch, bound by L1/L2 traffic, for ~32 us of MFMA work.
+constexpr int MP = 36, MAT = 64 * MP;
+enum { M_Q = 0, M_K = 1, M_V = 2, M_DO = 3 };
+
+// operand fragments of ONE 32-token tile: 4 float4 (d = 8g + 4h ..) of token tl*32 + (lane & 31)
+__device__ __forceinline__ void attn_frag(const float* m, int tl, int row, int h, f32x4 (&f)[4]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) f[g] = *reinterpret_cast<const f32x4*>(m + (tl * 32 + row) * MP + g * 8 + h * 4);
+}
+
+// B operand of the second-stage products: element (k = token f(r) + 4h of tile t, j = d = lane & 31)
+__device__ __forceinline__ void attn_rows(const float* m, int row, int h, float (&v)[2][16]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[t][r] = m[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * MP + row];
+}
+
+// D[i = token f(r) + 4h of tile t][j = d = lane & 31] -> row of dqkv (or the padded tokens' share of the qkv-bias gradient)
+// `pad`: the workgroup's LDS accumulator [32] of this matrix for the padded tokens (they carry the qkv bias, so their gradient is
+// a bias gradient).  All workgroups of a head used to add into the same 96 global floats with one atomic per (padded token, d):
+// 2.6 M atomics on 288 addresses in a stage-1 launch (5.8 % of its tokens are padding), serialised in the L2 — most of the 350 us
+// this kernel took with every operand already in LDS.
+__device__ __forceinline__ void attn_store(const AttnBwdP& p, const f32x16& o, int t, int col, const int* tokrow, int row, int h,
+                                           float mul, float* pad) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int tk = tokrow[t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+        if (tk >= 0) p.dqkv[(size_t)tk * (3 * p.C) + col + row] = o[r] * mul;
+        else if (tk == -1) atomicAdd(pad + row, o[r] * mul);
+    }
+}
+
+// acc[t] (t = 0, 1) = (tile t of matrix a as the A operand) x (the tile bf as the B operand)
+__device__ __forceinline__ void attn_mm(const float* a, int row, int h, const f32x4 (&bf)[4], f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        f32x4 af[4];
+        attn_frag(a, t, row, h, af);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][s2], bf[g][s2], acc[t], 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(512) void k_window_attention_bwd(const AttnBwdP p) {
+    __shared__ float s_bias[176], s_dbias[176], s_dpad[3][32];
+    __shared__ int s_tok[4][64], s_reg[4][64];
+    __shared__ float s_mx[4][64], s_inv[4][64], s_rs[4][64];
+    extern __shared__ __attribute__((aligned(16))) float s_mat[];       // [4 waves][4 matrices][64][MP]
+    const int lane = threadIdx.x & 63, wv = (threadIdx.x >> 6) >> 1, half = (threadIdx.x >> 6) & 1;   // wv = unit slot 0..3
     const int head = blockIdx.x % p.heads, k0 = blockIdx.x / p.heads;
     const int C3 = 3 * p.C;
     const long long nwin = (long long)p.B * p.nWh * p.nWw;
-    for (int i = lane; i < NREL; i += 64) { s_bias[i] = p.table[i * p.heads + head]; s_dbias[i] = 0.f; }
-    for (long long win = k0; win < nwin; win += p.nblk) {
-        long long t = win;
+    for (int i = threadIdx.x; i < NREL; i += 512) { s_bias[i] = p.table[i * p.heads + head]; s_dbias[i] = 0.f; }
+    for (int i = threadIdx.x; i < 4 * 4 * MAT; i += 512) s_mat[i] = 0.f;       // (rows 49..63 of every tile stay zero)
+    if (threadIdx.x < 96) s_dpad[threadIdx.x >> 5][threadIdx.x & 31] = 0.f;
+    __syncthreads();
+    float* const mq = s_mat + wv * 4 * MAT;
+    const float *const mk = mq + M_K * MAT, *const mv = mq + M_V * MAT, *const mdo = mq + M_DO * MAT;
+    const int row = lane & 31, h = lane >> 5;
+    const int* tokrow = s_tok[wv];
+    const int qc = head * HD, kc = p.C + head * HD, vc = 2 * p.C + head * HD;
+    // every wave runs the same number of iterations (the pair of a unit meets at workgroup barriers): a slot past the last window idles
+    for (long long base = (long long)k0 * 4; base < nwin; base += (long long)p.nblk * 4) {
+        const long long win = base + wv;
+        const bool valid = win < nwin;
+        long long t = valid ? win : 0;
         const int wx = (int)(t % p.nWw); t /= p.nWw;
         const int wy = (int)(t % p.nWh);
         const int b = (int)(t / p.nWh);
-        __syncthreads();
-        int tok = -2, reg = 0;
-        if (lane < NTOK) {
-            const int iy = lane / WS, ix = lane - iy * WS;
-            const int py = wy * WS + iy, px = wx * WS + ix;
-            int oy = py + p.shift, ox = px + p.shift;
-            if (oy >= p.Hp) oy -= p.Hp;
-            if (ox >= p.Wp) ox -= p.Wp;
-            tok = (oy < p.H && ox < p.W) ? (b * p.H + oy) * p.W + ox : -1;
-            if (p.shift > 0) {
-                const int hr = py < p.Hp - WS ? 0 : (py < p.Hp - p.shift ? 1 : 2);
-                const int wr = px < p.Wp - WS ? 0 : (px < p.Wp - p.shift ? 1 : 2);
-                reg = hr * 3 + wr;
+        {
+            int tok = -2, reg = 0;
+            if (lane < NTOK) {
+                const int iy = lane / WS, ix = lane - iy * WS;
+                const int py = wy * WS + iy, px = wx * WS + ix;
+                int oy = py + p.shift, ox = px + p.shift;
+                if (oy >= p.Hp) oy -= p.Hp;
+                if (ox >= p.Wp) ox -= p.Wp;
+                tok = (oy < p.H && ox < p.W) ? (b * p.H + oy) * p.W + ox : -1;
+                if (p.shift > 0) {
+                    const int hr = py < p.Hp - WS ? 0 : (py < p.Hp - p.shift ? 1 : 2);
+                    const int wr = px < p.Wp - WS ? 0 : (px < p.Wp - p.shift ? 1 : 2);
+                    reg = hr * 3 + wr;
+                }
             }
+            // (both waves of the pair write the same values; the previous unit ended on a workgroup barrier)
+            s_tok[wv][lane] = tok;
+            s_reg[wv][lane] = reg;
         }
-        s_tok[lane] = tok;
-        s_reg[lane] = reg;
-        float q[HD], dO[HD];
-        if (lane < NTOK) {
-            const float* src = tok >= 0 ? p.qkv + (size_t)tok * C3 : p.qkv_bias;
+        __syncthreads();                      // token table visible to both waves of the unit
+        // stage Q_s, K, V, dO of the 49 tokens: 8 lanes x 16 bytes per token row, 8 tokens per pass, passes split between the pair
 #pragma unroll
-            for (int d4 = 0; d4 < HD / 4; ++d4) {
-                const f32x4 qv = *reinterpret_cast<const f32x4*>(src + head * HD + d4 * 4);
-                const f32x4 kv = *reinterpret_cast<const f32x4*>(src + p.C + head * HD + d4 * 4);
-                const f32x4 vv = *reinterpret_cast<const f32x4*>(src + 2 * p.C + head * HD + d4 * 4);
+        for (int it = 0; it < 4; ++it) {
+            const int j = (it * 2 + half) * 8 + (lane >> 3), c = (lane & 7) * 4;
+            if (valid && j < NTOK) {
+                const int tk = tokrow[j];
+                const float* src = tk >= 0 ? p.qkv + (size_t)tk * C3 : p.qkv_bias;
                 f32x4 dv = {0.f, 0.f, 0.f, 0.f};
-                if (tok >= 0) dv = *reinterpret_cast<const f32x4*>(p.dout + (size_t)tok * p.C + head * HD + d4 * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    q[d4 * 4 + e] = qv[e] * p.scale;
-                    dO[d4 * 4 + e] = dv[e];
-                    s_q[lane][d4 * 4 + e] = qv[e] * p.scale;
-                    s_k[lane][d4 * 4 + e] = kv[e];
-                    s_v[lane][d4 * 4 + e] = vv[e];
-                    s_do[lane][d4 * 4 + e] = dv[e];
-                }
+                if (tk >= 0) dv = *reinterpret_cast<const f32x4*>(p.dout + (size_t)tk * p.C + qc + c);
+                *reinterpret_cast<f32x4*>(mq + M_Q * MAT + j * MP + c) = *reinterpret_cast<const f32x4*>(src + qc + c) * p.scale;
+                *reinterpret_cast<f32x4*>(mq + M_K * MAT + j * MP + c) = *reinterpret_cast<const f32x4*>(src + kc + c);
+                *reinterpret_cast<f32x4*>(mq + M_V * MAT + j * MP + c) = *reinterpret_cast<const f32x4*>(src + vc + c);
+                *reinterpret_cast<f32x4*>(mq + M_DO * MAT + j * MP + c) = dv;
             }
         }
         __syncthreads();
-        if (lane < NTOK) {
-            // row `lane` of S = q_s K^T + bias + mask, P = softmax(S), dP = dO V^T, dS = P o (dP - rowsum(P o dP))
-            const int qiy = lane / WS, qix = lane - qiy * WS;
-            float* pr = s_p[lane];                       // this lane's rows live in LDS (lane-private until the column phase)
-            float* dsr = s_ds[lane];
-            float mx = -INFINITY;
-            for (int j = 0; j < NTOK; ++j) {
-                float sc = 0.f;
-#pragma unroll
-                for (int d = 0; d < HD; ++d) sc += q[d] * s_k[j][d];
-                const int kiy = j / WS, kix = j - kiy * WS;
-                sc += s_bias[(qiy - kiy + WS - 1) * (2 * WS - 1) + (qix - kix + WS - 1)];
-                if (p.shift > 0 && s_reg[j] != reg) sc += -100.f;
-                pr[j] = sc;
-                mx = fmaxf(mx, sc);
+
+        // ------------------------------------------------- phase T: [key registers][query lanes]; this wave: query tile `half`
+        if (valid) {
+            const int qt = half;
+            const int q = qt * 32 + row;
+            const int qiy = q / WS, qix = q - qiy * WS;
+            f32x16 st[2], dpt[2];             // [kt]
+            {
+                f32x4 qf[4];
+                attn_frag(mq, qt, row, h, qf);
+                attn_mm(mk, row, h, qf, st);                 // S^T = K Q_s^T
             }
-            float sum = 0.f;
-            for (int j = 0; j < NTOK; ++j) { const float e = expf(pr[j] - mx); pr[j] = e; sum += e; }
-            const float inv = 1.f / sum;
-            float rowsum = 0.f;
-            for (int j = 0; j < NTOK; ++j) {
-                const float pj = pr[j] * inv;
-                pr[j] = pj;
-                float a = 0.f;
+            // bias + mask + softmax over keys of this query column: the forward kernel's sequence (swin_ops.hip k_window_attention)
+            {
+                const int qreg = s_reg[wv][q];
+                float mx = -INFINITY;
 #pragma unroll
-                for (int d = 0; d < HD; ++d) a += dO[d] * s_v[j][d];
-                dsr[j] = a;
-                rowsum += pj * a;
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        float v = -INFINITY;
+                        if (key < NTOK && q < NTOK) {
+                            const int kiy = key / WS, kix = key - kiy * WS;
+                            v = st[kt][r] + s_bias[(qiy - kiy + WS - 1) * (2 * WS - 1) + (qix - kix + WS - 1)];
+                            if (p.shift > 0 && s_reg[wv][key] != qreg) v += -100.f;
+                        } else if (key < NTOK) {
+                            v = 0.f;
+                        }
+                        st[kt][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                float sum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float e = expf(st[kt][r] - mx);
+                        st[kt][r] = e;
+                        sum += e;
+                    }
+                sum += __shfl_xor(sum, 32);
+                const float inv = 1.f / sum;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st[kt][r] *= inv;
+                s_mx[wv][q] = mx;                       // (both lane halves hold the same q: same value twice)
+                s_inv[wv][q] = inv;
             }
-            float dq[HD];
-#pragma unroll
-            for (int d = 0; d < HD; ++d) dq[d] = 0.f;
-            for (int j = 0; j < NTOK; ++j) {
-                const float ds = pr[j] * (dsr[j] - rowsum);
-                dsr[j] = ds;
-                const int kiy = j / WS, kix = j - kiy * WS;
-                atomicAdd(&s_dbias[(qiy - kiy + WS - 1) * (2 * WS - 1) + (qix - kix + WS - 1)], ds);   // distinct per lane for a given j
-#pragma unroll
-                for (int d = 0; d < HD; ++d) dq[d] += ds * s_k[j][d];
+            {
+                f32x4 dof[4];
+                attn_frag(mdo, qt, row, h, dof);
+                attn_mm(mv, row, h, dof, dpt);               // dP^T = V dO^T
             }
-            // dq = scale * dq_s
-            if (tok >= 0) {
-                float* dst = p.dqkv + (size_t)tok * C3 + head * HD;
+            float rs = 0.f;
 #pragma unroll
-                for (int d4 = 0; d4 < HD / 4; ++d4)
-                    *reinterpret_cast<f32x4*>(dst + d4 * 4) = f32x4{dq[d4 * 4] * p.scale, dq[d4 * 4 + 1] * p.scale, dq[d4 * 4 + 2] * p.scale, dq[d4 * 4 + 3] * p.scale};
-            } else {
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int d = 0; d < HD; ++d) atomicAdd(p.dbias_pad + head * HD + d, dq[d] * p.scale);
+                for (int r = 0; r < 16; ++r) rs += st[kt][r] * dpt[kt][r];
+            rs += __shfl_xor(rs, 32);
+            s_rs[wv][q] = rs;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const bool live = key < NTOK && q < NTOK;
+                    const float ds = live ? st[kt][r] * (dpt[kt][r] - rs) : 0.f;
+                    dpt[kt][r] = ds;
+                    if (live) {
+                        const int kiy = key / WS, kix = key - kiy * WS;
+                        atomicAdd(&s_dbias[(qiy - kiy + WS - 1) * (2 * WS - 1) + (qix - kix + WS - 1)], ds);
+                    }
+                }
+            {
+                float kk[2][16];
+                attn_rows(mk, row, h, kk);
+                f32x16 o;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o = __builtin_amdgcn_mfma_f32_32x32x2f32(dpt[kt][r], kk[kt][r], o, 0, 0, 0);
+                attn_store(p, o, qt, qc, tokrow, row, h, p.scale, s_dpad[0]);                               // dQ = scale * dS K
             }
         }
-        __syncthreads();
-        if (lane < NTOK) {
-            // column `lane`: dK[j] = sum_i dS[i][j] q_s[i], dV[j] = sum_i P[i][j] dO[i]
-            float dk[HD], dv[HD];
-#pragma unroll
-            for (int d = 0; d < HD; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
-#pragma unroll 7
-            for (int i = 0; i < NTOK; ++i) {
-                const float ds = s_ds[i][lane], pp = s_p[i][lane];
-#pragma unroll
-                for (int d = 0; d < HD; ++d) { dk[d] += ds * s_q[i][d]; dv[d] += pp * s_do[i][d]; }
+        __syncthreads();                      // s_mx / s_inv / s_rs of both query tiles are there
+
+        // ------------------------------------------------- phase N: [query registers][key lanes]; this wave: key tile `half`
+        if (valid) {
+            const int kt = half;
+            const int key = kt * 32 + row;
+            const int kiy = key / WS, kix = key - kiy * WS;
+            const int kreg = s_reg[wv][key];
+            f32x16 sn[2], dpn[2];             // [qt]
+            {
+                f32x4 kf[4];
+                attn_frag(mk, kt, row, h, kf);
+                attn_mm(mq, row, h, kf, sn);                 // S = Q_s K^T
             }
-            if (tok >= 0) {
-                float* dst = p.dqkv + (size_t)tok * C3 + head * HD;
+            {
+                f32x4 vf[4];
+                attn_frag(mv, kt, row, h, vf);
+                attn_mm(mdo, row, h, vf, dpn);               // dP = dO V^T
+            }
 #pragma unroll
-                for (int d4 = 0; d4 < HD / 4; ++d4) {
-                    *reinterpret_cast<f32x4*>(dst + p.C + d4 * 4) = f32x4{dk[d4 * 4], dk[d4 * 4 + 1], dk[d4 * 4 + 2], dk[d4 * 4 + 3]};
-                    *reinterpret_cast<f32x4*>(dst + 2 * p.C + d4 * 4) = f32x4{dv[d4 * 4], dv[d4 * 4 + 1], dv[d4 * 4 + 2], dv[d4 * 4 + 3]};
-                }
-            } else {
+            for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-                for (int d = 0; d < HD; ++d) {
-                    atomicAdd(p.dbias_pad + p.C + head * HD + d, dk[d]);
-                    atomicAdd(p.dbias_pad + 2 * p.C + head * HD + d, dv[d]);
+                for (int r = 0; r < 16; ++r) {
+                    const int q = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    float pv = 0.f, ds = 0.f;
+                    if (key < NTOK && q < NTOK) {
+                        const int qiy = q / WS, qix = q - qiy * WS;
+                        float v = sn[qt][r] + s_bias[(qiy - kiy + WS - 1) * (2 * WS - 1) + (qix - kix + WS - 1)];
+                        if (p.shift > 0 && s_reg[wv][q] != kreg) v += -100.f;
+                        pv = expf(v - s_mx[wv][q]) * s_inv[wv][q];
+                        ds = pv * (dpn[qt][r] - s_rs[wv][q]);
+                    }
+                    sn[qt][r] = pv;
+                    dpn[qt][r] = ds;
                 }
+            {
+                float dd[2][16];
+                attn_rows(mdo, row, h, dd);
+                f32x16 o;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o = __builtin_amdgcn_mfma_f32_32x32x2f32(sn[qt][r], dd[qt][r], o, 0, 0, 0);
+                attn_store(p, o, kt, vc, tokrow, row, h, 1.f, s_dpad[2]);                                    // dV = P^T dO
+            }
+            {
+                float qq[2][16];
+                attn_rows(mq, row, h, qq);
+                f32x16 o;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o = __builtin_amdgcn_mfma_f32_32x32x2f32(dpn[qt][r], qq[qt][r], o, 0, 0, 0);
+                attn_store(p, o, kt, kc, tokrow, row, h, 1.f, s_dpad[1]);                                    // dK = dS^T Q_s
             }
         }
+        __syncthreads();                      // both waves are done with the unit's tiles before the next one is staged
     }
     __syncthreads();
-    for (int i = lane; i < NREL; i += 64)
+    for (int i = threadIdx.x; i < NREL; i += 512)
         if (s_dbias[i] != 0.f) atomicAdd(p.dtable + i * p.heads + head, s_dbias[i]);
+    if (threadIdx.x < 96) {
+        const float v = s_dpad[threadIdx.x >> 5][threadIdx.x & 31];
+        if (v != 0.f) atomicAdd(p.dbias_pad + (threadIdx.x >> 5) * p.C + head * HD + (threadIdx.x & 31), v);
+    }
 }
 
 // ---- AdamW (torch.optim.AdamW single-tensor update order) --------------------------------------------------------------
@@ -382,10 +530,18 @@ extern "C" int ym_swin_window_attention_bwd(const float* qkv, const float* qkv_b
     p.Hp = p.nWh * WS; p.Wp = p.nWw * WS;
     p.scale = 1.0f / sqrtf((float)HD);
     const long long nwin = (long long)B * p.nWh * p.nWw;
-    long long nblk = (2048 + heads - 1) / heads;              // ~8 workgroups per CU
-    if (nblk > nwin) nblk = nwin;
+    const long long wgs_needed = (nwin + 3) / 4;               // one window per wave, 4 waves of one head per workgroup
+    long long nblk = 256 / heads;                              // one workgroup per CU (its operand tiles fill the LDS): the grid must
+    if (nblk < 1) nblk = 1;                                    // not exceed 256, or its last few workgroups run as a second round
+    if (nblk > wgs_needed) nblk = wgs_needed;
     p.nblk = (int)nblk;
-    hipLaunchKernelGGL(k_window_attention_bwd, dim3((int)(nblk * heads)), dim3(64), 0, (hipStream_t)s, p);
+    const size_t lds = (size_t)4 * 4 * MAT * sizeof(float);          // 144 KB: one workgroup (4 waves) per CU
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_window_attention_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_window_attention_bwd, dim3((int)(nblk * heads)), dim3(512), lds, (hipStream_t)s, p);
     return ym_check_launch("window_attention_bwd");
 }
 
