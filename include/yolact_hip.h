@@ -136,6 +136,12 @@ int ym_layernorm_bwd(const float* dy, const float* x, const float* gamma, float 
  * element written), dgamma / dbeta [4C].  workspace >= ym_layernorm_bwd_workspace_bytes(4*C). */
 int ym_patch_merge_layernorm_bwd(const float* dy, const float* x, int B, int H, int W, int C, const float* gamma, float eps,
                                  float* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, ym_stream_t s);
+/* DropPath + residual add in one pass (modules/swin_transformer.py:71-82 with the call sites :285,288): out = res + (y / keep) *
+ * floor(keep + rnd[b]) in the reference's operation order; rnd [B] is the raw torch.rand draw, res / y / out are [B][per_sample]
+ * (per_sample % 4 == 0).  Backward: the residual's gradient is dout, dy = (dout * mask) / keep. */
+int ym_drop_path_add(const float* res, const float* y, const float* rnd, float keep, float* out, int B, int64_t per_sample,
+                     ym_stream_t s);
+int ym_drop_path_bwd(const float* dout, const float* rnd, float keep, float* dy, int B, int64_t per_sample, ym_stream_t s);
 /* Exact (erf) GELU of Mlp.forward (modules/swin_transformer.py:92-96) on a saved pre-activation; n % 4 == 0. */
 int ym_gelu_fwd(const float* z, float* out, int64_t n, ym_stream_t s);
 int ym_gelu_bwd(const float* dy, const float* z, float* dz, int64_t n, ym_stream_t s);

@@ -219,6 +219,27 @@ def test_swin_block_gradients_match_oracle(h, w, heads, shift):
         torch.testing.assert_close(p_.grad.cpu().double(), ref, rtol=1e-3, atol=tol, msg=lambda m, n_=n_: f'{n_}: {m}')
 
 
+def test_drop_path_residual_kernel_is_the_reference_arithmetic():
+    """shortcut + DropPath(y) (modules/swin_transformer.py:71-82,285,288): forward and both gradients bit-identical to the reference
+    expression evaluated by torch on the CPU with the same uniform draws (div, floor, mul, add in that order)."""
+    from yolact_minimal_amd.swin_train import DropPathAddFn
+    g = torch.Generator().manual_seed(3)
+    b, keep = 8, 1 - 0.13
+    res, y, dout = (torch.randn(b, 9, 11, 96, generator=g) for _ in range(3))
+    rnd = torch.rand(b, generator=g)
+    rc, yc = res.clone().requires_grad_(), y.clone().requires_grad_()
+    mask = (keep + rnd.reshape(b, 1, 1, 1)).floor_()
+    want = rc + yc.div(keep) * mask
+    want.backward(dout)
+    assert 0 < int(mask.sum()) < b                                  # both kept and dropped samples
+    rg, yg = res.to(DEV).requires_grad_(), y.to(DEV).requires_grad_()
+    got = DropPathAddFn.apply(rg, yg, rnd.to(DEV), keep)
+    got.backward(dout.to(DEV))
+    assert torch.equal(got.detach().cpu(), want.detach())
+    assert torch.equal(rg.grad.cpu(), rc.grad)
+    assert torch.equal(yg.grad.cpu(), yc.grad)
+
+
 def test_adamw_kernel_matches_torch():
     from yolact_minimal_amd.trainer import FlatAdamW
     g = torch.Generator().manual_seed(0)

@@ -112,13 +112,37 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__
     }
 }
 
-__global__ void k_ln_param_grad(const float* __restrict__ part, int blocks, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// dgamma / dbeta = ordered sum of the per-workgroup partials [blocks][2][C]: 16 channels x 16 block slices per workgroup, slices
+// combined through LDS in a fixed order (deterministic).  (One thread per channel walking all the blocks in a dependent chain took
+// 68 us per call whatever the size: 2.1 ms of a Swin-T training step.)
+__global__ __launch_bounds__(256) void k_ln_param_grad(const float* __restrict__ part, int blocks, int C, float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta) {
+    __shared__ double red[2][16][17];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double sg = 0.0, sb = 0.0;
-    for (int b = 0; b < blocks; ++b) { sg += part[((size_t)b * 2) * C + c]; sb += part[((size_t)b * 2 + 1) * C + c]; }
-    dgamma[c] = (float)sg;
-    dbeta[c] = (float)sb;
+    if (c < C) {
+        int b = sl;
+        for (; b + 48 < blocks; b += 64) {
+            float g[4], bb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                g[u] = part[((size_t)(b + 16 * u) * 2) * C + c];
+                bb[u] = part[((size_t)(b + 16 * u) * 2 + 1) * C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { sg += g[u]; sb += bb[u]; }
+        }
+        for (; b < blocks; b += 16) { sg += part[((size_t)b * 2) * C + c]; sb += part[((size_t)b * 2 + 1) * C + c]; }
+    }
+    red[0][sl][cl] = sg;
+    red[1][sl][cl] = sb;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        for (int r = 1; r < 16; ++r) { sg += red[0][r][cl]; sb += red[1][r][cl]; }
+        dgamma[c] = (float)sg;
+        dbeta[c] = (float)sb;
+    }
 }
 
 // ---- GELU ------------------------------------------------------------------------------------------------------------------
@@ -142,6 +166,35 @@ __global__ void k_gelu_bwd(const float* __restrict__ dy, const float* __restrict
             o[e] = d[e] * (cdf + v[e] * pdf);
         }
         *reinterpret_cast<f32x4*>(dz + i * 4) = o;
+    }
+}
+
+// ---- DropPath + residual (modules/swin_transformer.py:71-82 and the `x = shortcut + self.drop_path(x)` call sites :285,288) ------
+// out = res + (y / keep) * floor(keep + rand[b]) in the reference's operation order, one pass (the reference graph is div, mul, add
+// = three passes forward and two backward); rand [B] is the raw torch.rand draw, so the random stream is the reference's.
+__global__ __launch_bounds__(256) void k_drop_path_add(const float* __restrict__ res, const float* __restrict__ y,
+                                                        const float* __restrict__ rnd, float keep, float* __restrict__ out,
+                                                        long long per4, long long total4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const float m = floorf(keep + rnd[i / per4]);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(y + i * 4), r = *reinterpret_cast<const f32x4*>(res + i * 4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = r[e] + (v[e] / keep) * m;
+        *reinterpret_cast<f32x4*>(out + i * 4) = o;
+    }
+}
+
+// dy = (dout * mask) / keep (autograd's order for y.div(keep) * mask); the residual's gradient is dout itself
+__global__ __launch_bounds__(256) void k_drop_path_bwd(const float* __restrict__ dout, const float* __restrict__ rnd, float keep,
+                                                        float* __restrict__ dy, long long per4, long long total4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const float m = floorf(keep + rnd[i / per4]);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dout + i * 4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (d[e] * m) / keep;
+        *reinterpret_cast<f32x4*>(dy + i * 4) = o;
     }
 }
 
@@ -464,14 +517,16 @@ __global__ void k_adamw(float* __restrict__ p, const float* __restrict__ g, floa
     }
 }
 
+constexpr int LN_BWD_MAX_BLOCKS = 2048;      // (256 left one workgroup per CU: 0.5 TB/s on the 170 MB of a stage-1 LayerNorm)
 int ln_bwd_blocks(long long M) {
-    long long b = (M + 3) / 4;
-    return (int)(b > 256 ? 256 : b);
+    long long b = (M + 15) / 16;                 // >= 4 rows per wave
+    if (b < 1) b = 1;
+    return (int)(b > LN_BWD_MAX_BLOCKS ? LN_BWD_MAX_BLOCKS : b);
 }
 
 }  // namespace
 
-extern "C" size_t ym_layernorm_bwd_workspace_bytes(int C) { return (size_t)256 * 2 * C * sizeof(float); }
+extern "C" size_t ym_layernorm_bwd_workspace_bytes(int C) { return (size_t)LN_BWD_MAX_BLOCKS * 2 * C * sizeof(float); }
 
 extern "C" int ym_layernorm_bwd(const float* dy, const float* x, const float* gamma, float eps, int64_t M, int C, float* dx,
                                 float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, ym_stream_t s) {
@@ -481,7 +536,7 @@ extern "C" int ym_layernorm_bwd(const float* dy, const float* x, const float* ga
     const int blocks = ln_bwd_blocks(M);
     hipLaunchKernelGGL(k_layernorm_bwd<0>, dim3(blocks), dim3(256), 0, (hipStream_t)s, dy, x, gamma, eps, dx, (float*)workspace,
                        (long long)M, C, 0, 0, 0, 0);
-    hipLaunchKernelGGL(k_ln_param_grad, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)s, (const float*)workspace, blocks, C, dgamma, dbeta);
+    hipLaunchKernelGGL(k_ln_param_grad, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)s, (const float*)workspace, blocks, C, dgamma, dbeta);
     return ym_check_launch("layernorm_bwd");
 }
 
@@ -495,7 +550,7 @@ extern "C" int ym_patch_merge_layernorm_bwd(const float* dy, const float* x, int
     const int blocks = ln_bwd_blocks(M);
     hipLaunchKernelGGL(k_layernorm_bwd<1>, dim3(blocks), dim3(256), 0, (hipStream_t)s, dy, x, gamma, eps, dx, (float*)workspace, M, 4 * C,
                        B, H, W, C);
-    hipLaunchKernelGGL(k_ln_param_grad, dim3((4 * C + 255) / 256), dim3(256), 0, (hipStream_t)s, (const float*)workspace, blocks, 4 * C,
+    hipLaunchKernelGGL(k_ln_param_grad, dim3((4 * C + 15) / 16), dim3(256), 0, (hipStream_t)s, (const float*)workspace, blocks, 4 * C,
                        dgamma, dbeta);
     return ym_check_launch("patch_merge_layernorm_bwd");
 }
@@ -514,6 +569,25 @@ extern "C" int ym_gelu_bwd(const float* dy, const float* z, float* dz, int64_t n
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_gelu_bwd, dim3((int)blocks), dim3(256), 0, (hipStream_t)s, dy, z, dz, (long long)(n / 4));
     return ym_check_launch("gelu_bwd");
+}
+
+extern "C" int ym_drop_path_add(const float* res, const float* y, const float* rnd, float keep, float* out, int B, int64_t per_sample,
+                                ym_stream_t s) {
+    YM_REQUIRE(res && y && rnd && out && B > 0 && per_sample > 0 && per_sample % 4 == 0 && keep > 0.f, "drop_path_add: bad args");
+    const long long total4 = (long long)B * (per_sample / 4);
+    long long blocks = (total4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_drop_path_add, dim3((int)blocks), dim3(256), 0, (hipStream_t)s, res, y, rnd, keep, out, (long long)(per_sample / 4), total4);
+    return ym_check_launch("drop_path_add");
+}
+
+extern "C" int ym_drop_path_bwd(const float* dout, const float* rnd, float keep, float* dy, int B, int64_t per_sample, ym_stream_t s) {
+    YM_REQUIRE(dout && rnd && dy && B > 0 && per_sample > 0 && per_sample % 4 == 0 && keep > 0.f, "drop_path_bwd: bad args");
+    const long long total4 = (long long)B * (per_sample / 4);
+    long long blocks = (total4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_drop_path_bwd, dim3((int)blocks), dim3(256), 0, (hipStream_t)s, dout, rnd, keep, dy, (long long)(per_sample / 4), total4);
+    return ym_check_launch("drop_path_bwd");
 }
 
 extern "C" int ym_swin_window_attention_bwd(const float* qkv, const float* qkv_bias, const float* rel_bias_table, const float* dout,

@@ -6,8 +6,9 @@ Reference: `SwinTransformer.forward` `/root/reference/modules/swin_transformer.p
 `torch.autograd.Function` is only the tape.  Every Linear is the 1x1 case of `train_engine.ConvBias` (forward, data gradient
 and weight gradient on the f32 MFMA conv kernels; the residual adds of the block are fused into the proj / fc2 epilogues when
 DropPath is inactive); LayerNorm, the patch-merge gather + LayerNorm, GELU and the shifted-window attention have their own
-forward / backward kernels (`csrc/swin_ops.hip`, `csrc/swin_train.hip`).  DropPath draws its per-sample mask with `torch.rand` on
-the device exactly like the reference (`:76-79`) — a host-level RNG call, kept for parity of the random stream.
+forward / backward kernels (`csrc/swin_ops.hip`, `csrc/swin_train.hip`).  DropPath draws its per-sample numbers with `torch.rand` on
+the device exactly like the reference (`:76-79`) — a host-level RNG call, kept for parity of the random stream; mask, scaling and the
+residual add are one kernel (`DropPathAddFn`).
 """
 import ctypes
 
@@ -143,15 +144,36 @@ def _linear(x, lin, residual=None):
     return ConvBias.apply(x, _w4(lin), lin.bias, 1, 0, ACT_NONE, lin.out_features, residual)
 
 
-def _drop_path(y, drop_prob, training):
-    """DropPath.forward (:71-82): per-sample Bernoulli(keep) mask / keep, drawn with torch.rand on the device."""
-    if drop_prob == 0. or not training:
-        return y
-    keep = 1 - drop_prob
-    shape = (y.shape[0],) + (1,) * (y.ndim - 1)
-    mask = keep + torch.rand(shape, dtype=y.dtype, device=y.device)
-    mask.floor_()
-    return y.div(keep) * mask
+class DropPathAddFn(torch.autograd.Function):
+    """shortcut + DropPath(y) (:71-82, :285, :288) as one kernel each way; `rnd` [B] is the raw torch.rand draw."""
+
+    @staticmethod
+    def forward(ctx, res, y, rnd, keep):
+        res, y = res.contiguous(), y.contiguous()
+        out = torch.empty_like(y)
+        b = y.shape[0]
+        hip.check(hip.lib().ym_drop_path_add(hip.ptr(res), hip.ptr(y), hip.ptr(rnd), keep, hip.ptr(out), b, y.numel() // b,
+                                             hip.stream_ptr()), 'ym_drop_path_add')
+        ctx.save_for_backward(rnd)
+        ctx.keep = keep
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        rnd, = ctx.saved_tensors
+        dout = dout.contiguous()
+        dy = torch.empty_like(dout)
+        b = dout.shape[0]
+        hip.check(hip.lib().ym_drop_path_bwd(hip.ptr(dout), hip.ptr(rnd), ctx.keep, hip.ptr(dy), b, dout.numel() // b,
+                                             hip.stream_ptr()), 'ym_drop_path_bwd')
+        return dout, dy, None, None
+
+
+def _residual_drop_path(res, y, drop_prob):
+    """res + DropPath(y) in train mode with drop_prob > 0: the reference's torch.rand draw (same shape, dtype and device: same random
+    stream), everything else fused."""
+    rnd = torch.rand((y.shape[0],) + (1,) * (y.ndim - 1), dtype=y.dtype, device=y.device)
+    return DropPathAddFn.apply(res, y, rnd.reshape(-1), 1 - drop_prob)
 
 
 def swin_block(x, blk, heads, window, training=True):
@@ -165,12 +187,12 @@ def swin_block(x, blk, heads, window, training=True):
     if fuse:
         x = _linear(att, blk.attn.proj, residual=x)
     else:
-        x = x + _drop_path(_linear(att, blk.attn.proj), dp, training)
+        x = _residual_drop_path(x, _linear(att, blk.attn.proj), dp)
     n2 = LayerNormFn.apply(x, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
     hid = GeluFn.apply(_linear(n2, blk.mlp.fc1))
     if fuse:
         return _linear(hid, blk.mlp.fc2, residual=x)
-    return x + _drop_path(_linear(hid, blk.mlp.fc2), dp, training)
+    return _residual_drop_path(x, _linear(hid, blk.mlp.fc2), dp)
 
 
 def swin_backbone_train(bb, x_nhwc4, training=True):
