@@ -168,6 +168,47 @@ def test_bn_backward_sums_ride_on_the_consumers_dgrad():
     assert float((results[True][1] - ref_dx).norm() / ref_dx.norm()) < 2e-4
 
 
+@pytest.mark.parametrize('cin,cout,k,stride,hw,b,msplit', [(128, 256, 1, 1, 34, 4, 7), (64, 128, 3, 1, 23, 3, 5), (128, 160, 3, 2, 30, 2, 3),
+                                                           (4, 96, 7, 2, 64, 2, 9), (256, 352, 3, 1, 9, 8, 2)])
+def test_conv_wgrad_staging_variants_agree(cin, cout, k, stride, hw, b, msplit):
+    """Weight gradient under every operand-staging variant (ym_wgrad_desc.lds_buffers: registers 2 / 1, DMA rings 22 / 23 / 24): the
+    pixel reduction runs in the same order in all of them, so for one msplit the results are the SAME BITS; repeated launches of
+    the DMA variants must not differ (ring hazards show up as run-to-run differences); variant 2 against torch's conv2d weight
+    gradient on the CPU within fp32 accumulation noise."""
+    from yolact_minimal_amd import hip
+    from yolact_minimal_amd.hip import WgradDesc
+    g = torch.Generator().manual_seed(cin + cout + k + hw)
+    pad = k // 2
+    ho = (hw + 2 * pad - k) // stride + 1
+    cin_real = 3 if cin == 4 else cin
+    x = torch.randn(b, cin_real, hw, hw, generator=g)
+    dy = torch.randn(b, cout, ho, ho, generator=g)
+    want = torch.nn.grad.conv2d_weight(x, (cout, cin_real, k, k), dy, stride=stride, padding=pad)
+    xg = torch.zeros(b, hw, hw, cin)
+    xg[..., :cin_real] = _nhwc(x)
+    xg, dyg = xg.to(DEV), _nhwc(dy).to(DEV)
+    ws = torch.empty(1 << 27, dtype=torch.uint8, device=DEV)
+    outs = {}
+    for nb in (2, 1, 22, 23, 24):
+        d = WgradDesc()
+        dw = torch.full((cout, cin_real, k, k), float('nan'), device=DEV)
+        d.x, d.dy, d.dw = xg.data_ptr(), dyg.data_ptr(), dw.data_ptr()
+        d.B, d.H, d.W, d.Cin, d.Cin_real, d.Cout, d.Cout_real = b, hw, hw, cin, cin_real, cout, cout
+        d.KH, d.KW, d.stride, d.pad, d.Ho, d.Wo, d.msplit, d.lds_buffers = k, k, stride, pad, ho, ho, msplit, nb
+        runs = []
+        for _ in range(6 if nb >= 22 else 1):
+            dw.fill_(float('nan'))
+            hip.check(hip.lib().ym_conv2d_wgrad(ctypes.byref(d), ctypes.c_void_p(ws.data_ptr()), ws.numel(), hip.stream_ptr()), 'wgrad')
+            runs.append(dw.cpu().clone())
+        for r_ in runs[1:]:
+            assert torch.equal(r_, runs[0]), f'lds_buffers={nb}: run-to-run difference'
+        outs[nb] = runs[0]
+    for nb in (1, 22, 23, 24):
+        assert torch.equal(outs[nb], outs[2]), f'lds_buffers={nb} differs from the double-buffered variant'
+    scale = float(want.abs().max())
+    torch.testing.assert_close(outs[2], want, rtol=2e-4, atol=2e-5 * max(1.0, scale))
+
+
 def test_pool_and_upsample_backward():
     from yolact_minimal_amd.train_engine import MaxPool, Bilinear2x
     g = torch.Generator().manual_seed(0)

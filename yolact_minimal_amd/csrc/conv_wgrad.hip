@@ -15,8 +15,11 @@ using namespace ymk;
 namespace {
 
 constexpr int TBK = 128;   // kk tile
-constexpr int TBM = 32;    // pixels per step
+constexpr int TBM = 32;    // pixels per step (register-staged variants; the DMA variants choose 32 or 16)
 constexpr int LP = 132;    // LDS row pitch (floats): 16-byte aligned rows, skewed banks for the float4 writes
+constexpr int DP = 128;    // row pitch of the DMA variants: `buffer_load ... lds` places lane l's 16 bytes at base + 16*l, i.e. rows
+                           // of 128 floats back to back (the fragments are ds_read_b32 over 32 consecutive floats: any pitch is
+                           // conflict-free for them; the skew only ever served the float4 WRITES, which the DMA path does not have)
 
 struct WgradP {
     const float* x;     // NHWC [B][H][W][Cinp]
@@ -41,12 +44,19 @@ __device__ __forceinline__ unsigned fastdiv(unsigned m, unsigned mg, unsigned sh
 // NB = LDS buffers.  2: the next pixel step is written while the current one is read (one barrier per step, 68 KB: two workgroups
 // per CU).  1: one buffer, two barriers per step (34 KB: three workgroups per CU at 152 VGPRs) — the extra barrier is hidden by
 // the third resident workgroup; the counters showed this kernel at 1.3 resident waves per SIMD and 57 % MFMA-busy with NB = 2.
-template <int INCR, int TBN, int NB>
+// DL: both operand tiles go global -> LDS by DMA (`buffer_load_dwordx4 ... lds`): no staging registers (-32 VGPRs), no ds_write,
+// a ring of NB buffers with the loads NB-1 pixel steps ahead and ONE barrier per step (explicit `s_waitcnt vmcnt(n) lgkmcnt(0)` +
+// `s_barrier`, the discipline of conv_mfma.hip's DL path: lgkmcnt(0) retires this wave's reads of the buffer the next DMA
+// re-stages).  TM = pixels per step: 32 x ring 2 = 64 KB (two workgroups per CU), 16 x ring 3 = 48 KB (three).  TBN = 128 only.
+template <int INCR, int TBN, int NB, bool DL = false, int TM = TBM>
 __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradP p) {
     constexpr int KT = TBN == 128 ? 2 : 1;          // 32-wide kk tiles per wave
+    constexpr int TMS = TM;                          // pixels per step of this variant
+    constexpr int LPK = DL ? DP : LP;                // its LDS row pitch
+    static_assert(!DL || TBN == 128, "DMA staging: 128-wide n tile only");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ys = smem;                       // [NB][TBM][LP]
-    float* Xs = smem + NB * TBM * LP;       // [NB][TBM][LP]
+    float* Ys = smem;                       // [NB][TMS][LPK]
+    float* Xs = smem + NB * TMS * LPK;       // [NB][TMS][LPK]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = TBN == 128 ? (wave >> 1) : 0, wk = TBN == 128 ? (wave & 1) : wave;
 
@@ -68,15 +78,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradP p) {
 
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
-    f32x4 ry[4], rx[4];
+    constexpr int NR = TMS / 8;                  // staging rows per thread: r0 + 8*i
+    f32x4 ry[DL ? 1 : NR], rx[DL ? 1 : NR];
     // Branch-free operand fetch (raw buffer loads return zeros beyond the descriptor: rows past the slice, padding taps, tile
     // tails) with the per-step integer work kept small: the output-pixel coordinates (b, oh, ow) of each staging row are carried
     // across steps and ADVANCED by the 32-pixel step (a couple of compares) instead of being re-derived with two divisions per
     // row per step; everything that does not depend on the pixel (tap, channel, column masks) is hoisted.  INCR = 0 keeps the
     // division path for maps so small that one step wraps more than two image rows.
-    int pb[4], poh[4], pow_[4];
+    int pb[NR], poh[NR], pow_[NR];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NR; ++i) {
         const unsigned m = (unsigned)(m_beg + r0 + 8 * i);
         const unsigned b = fastdiv(m, p.mg_howo, p.sh_howo);
         const unsigned rem = m - b * p.HoWo;
@@ -85,17 +96,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradP p) {
     }
     const unsigned ymask = n_ok ? 0u : OOB, xmask = k_ok ? 0u : OOB;
     const unsigned ycol = (unsigned)(ncol * 4), xcol = (unsigned)(ci * 4);
-    const int dq = TBM / p.Wo, dr = TBM - dq * p.Wo;                  // a 32-pixel step = dq rows + dr columns
-    auto load = [&](int mt) {
+    const int dq = TMS / p.Wo, dr = TMS - dq * p.Wo;                  // a 32-pixel step = dq rows + dr columns
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    // `buf` (DL only): ring buffer the tile is DMA'd into; the wave's lanes 0-31 / 32-63 are rows 2*wave + 8i / + 1 of the tile, which
+    // is where base + 16*lane puts them at a pitch of 128 floats
+    auto load = [&](int mt, int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NR; ++i) {
             const int m = mt + r0 + 8 * i;
             const unsigned dead = m < m_end ? 0u : OOB;
-            ry[i] = buf_ld16(rs_y, ((unsigned)(m * p.Cout) * 4u + ycol) | ymask | dead);
+            const unsigned yoff = ((unsigned)(m * p.Cout) * 4u + ycol) | ymask | dead;
             const int ih = poh[i] * p.stride - p.pad + kh, iw = pow_[i] * p.stride - p.pad + kw;
             const unsigned inside = ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) ? 0u : OOB;
-            rx[i] = buf_ld16(rs_x, ((unsigned)(((pb[i] * p.H + ih) * p.W + iw) * p.Cinp) * 4u + xcol) | xmask | dead | inside);
-            if (INCR) {                                                // advance this row by TBM pixels
+            const unsigned xoff = ((unsigned)(((pb[i] * p.H + ih) * p.W + iw) * p.Cinp) * 4u + xcol) | xmask | dead | inside;
+            if constexpr (DL) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_ptr)(Ys + (buf * TMS + 2 * wave + 8 * i) * LPK), 16, (int)yoff, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr)(Xs + (buf * TMS + 2 * wave + 8 * i) * LPK), 16, (int)xoff, 0, 0, 0);
+            } else {
+                ry[i] = buf_ld16(rs_y, yoff);
+                rx[i] = buf_ld16(rs_x, xoff);
+            }
+            if (INCR) {                                                // advance this row by TMS pixels
                 int ow = pow_[i] + dr, oh = poh[i] + dq;
                 const bool c = ow >= p.Wo;
                 ow -= c ? p.Wo : 0;
@@ -108,7 +129,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradP p) {
                 pb[i] += c2 ? 1 : 0;
                 pow_[i] = ow; poh[i] = oh;
             } else {
-                const unsigned mn = (unsigned)(m + TBM);
+                const unsigned mn = (unsigned)(m + TMS);
                 const unsigned b = fastdiv(mn, p.mg_howo, p.sh_howo);
                 const unsigned rem = mn - b * p.HoWo;
                 const unsigned oh = fastdiv(rem, p.mg_wo, p.sh_wo);
@@ -118,9 +139,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradP p) {
     };
     auto store = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(Ys + (buf * TBM + r0 + 8 * i) * LP + c4 * 4) = ry[i];
-            *reinterpret_cast<f32x4*>(Xs + (buf * TBM + r0 + 8 * i) * LP + c4 * 4) = rx[i];
+        for (int i = 0; i < (DL ? 0 : NR); ++i) {
+            *reinterpret_cast<f32x4*>(Ys + (buf * TMS + r0 + 8 * i) * LPK + c4 * 4) = ry[i];
+            *reinterpret_cast<f32x4*>(Xs + (buf * TMS + r0 + 8 * i) * LPK + c4 * 4) = rx[i];
         }
     };
 
@@ -133,28 +154,44 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradP p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int fr = lane & 31, khalf = lane >> 5;
-    load(m_beg);
-    store(0);
-    __syncthreads();
-    int cur = 0;
-    for (int mt = m_beg; mt < m_end; mt += TBM) {
-        load(mt + TBM);
-        const float* ya = Ys + cur * TBM * LP + wn * 64 + fr;
-        const float* xb = Xs + cur * TBM * LP + wk * (32 * KT) + fr;
+    constexpr int D = NB - 1;                      // DL: prefetch distance in pixel steps
+    int cur = 0, nxt = DL ? D : 0;                 // DL: nxt = (cur + D) % NB = the buffer step t-1 was read from
+    if constexpr (DL) {
+        static_assert(2 * NR * (D > 0 ? D - 1 : 0) < 16, "vmcnt field");
 #pragma unroll
-        for (int s = 0; s < TBM / 2; ++s) {
+        for (int d = 0; d < D; ++d) load(m_beg + d * TMS, d);
+        __builtin_amdgcn_s_waitcnt(0x070 | (2 * NR * (D - 1)));     // vmcnt(2*NR*(D-1)) lgkmcnt(0): step 0 has landed
+        __builtin_amdgcn_s_barrier();
+    } else {
+        load(m_beg, 0);
+        store(0);
+        __syncthreads();
+    }
+    for (int mt = m_beg; mt < m_end; mt += TMS) {
+        load(mt + (DL ? D : 1) * TMS, nxt);
+        const float* ya = Ys + cur * TMS * LPK + wn * 64 + fr;
+        const float* xb = Xs + cur * TMS * LPK + wk * (32 * KT) + fr;
+#pragma unroll
+        for (int s = 0; s < TMS / 2; ++s) {
             const int row = 2 * s + khalf;
-            const float a0 = ya[row * LP], a1 = ya[row * LP + 32];
-            const float b0 = xb[row * LP];
+            const float a0 = ya[row * LPK], a1 = ya[row * LPK + 32];
+            const float b0 = xb[row * LPK];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             if constexpr (KT == 2) {
-                const float b1 = xb[row * LP + 32];
+                const float b1 = xb[row * LPK + 32];
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
             }
         }
-        if constexpr (NB == 2) {
+        if constexpr (DL) {
+            // this wave's DMA of step t+1 has landed and its reads of step t are retired (lgkmcnt(0): the DMA issued after the
+            // barrier re-stages that buffer) ... and so for every wave after the barrier
+            __builtin_amdgcn_s_waitcnt(0x070 | (2 * NR * (D - 1)));
+            __builtin_amdgcn_s_barrier();
+            cur = cur == NB - 1 ? 0 : cur + 1;
+            nxt = nxt == NB - 1 ? 0 : nxt + 1;
+        } else if constexpr (NB == 2) {
             store(cur ^ 1);
             __syncthreads();
             cur ^= 1;
@@ -165,6 +202,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradP p) {
         }
     }
 
+    if constexpr (DL) __builtin_amdgcn_s_waitcnt(0xF70);      // the past-the-end prefetches (zeros) are still landing in LDS
     // D[i = n][j = kk]: col = lane&31 -> kk, row = (r&3) + 8*(r>>2) + 4*khalf -> n
     float* wsb = p.ws + (size_t)ms * p.Cout * p.Ktot;
 #pragma unroll
@@ -224,6 +262,10 @@ int wplan(const ym_wgrad_desc* d, WPlan* pl) {
     pl->Ktot = d->KH * d->KW * d->Cin;
     pl->tbn = d->Cout_real <= 64 ? 64 : 128;
     pl->nb = d->lds_buffers == 1 ? 1 : 2;
+    if (d->lds_buffers == 22 || d->lds_buffers == 23 || d->lds_buffers == 24) {
+        YM_REQUIRE(pl->tbn == 128, "wgrad: the DMA-staged variants (lds_buffers 22/23/24) need more than 64 output channels");
+        pl->nb = d->lds_buffers;
+    }
     pl->tiles_n = ym_cdiv(d->Cout, pl->tbn);
     pl->tiles_k = ym_cdiv(pl->Ktot, TBK);
     int ms = d->msplit;
@@ -270,7 +312,9 @@ extern "C" int ym_conv2d_wgrad(const ym_wgrad_desc* d, void* workspace, size_t w
         fastdiv_make((unsigned)d->Wo, &p.mg_wo, &p.sh_wo);
     }
     hipStream_t st = (hipStream_t)s;
-    const size_t lds = (size_t)2 * pl.nb * TBM * LP * sizeof(float);
+    // 22: DMA, 32 pixels x ring of 2 (64 KB); 23: DMA, 16 pixels x ring of 3 (48 KB); 24: DMA, 16 pixels x ring of 4 (64 KB)
+    const size_t lds = pl.nb == 22 ? (size_t)2 * 2 * 32 * DP * 4 : pl.nb == 23 ? (size_t)2 * 3 * 16 * DP * 4
+                     : pl.nb == 24 ? (size_t)2 * 4 * 16 * DP * 4 : (size_t)2 * pl.nb * TBM * LP * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         const int big = (int)((size_t)4 * TBM * LP * sizeof(float));
@@ -278,6 +322,10 @@ extern "C" int ym_conv2d_wgrad(const ym_wgrad_desc* d, void* workspace, size_t w
         YM_WG_ATTR(0, 128, 2); YM_WG_ATTR(1, 128, 2); YM_WG_ATTR(0, 64, 2); YM_WG_ATTR(1, 64, 2);
         YM_WG_ATTR(0, 128, 1); YM_WG_ATTR(1, 128, 1); YM_WG_ATTR(0, 64, 1); YM_WG_ATTR(1, 64, 1);
 #undef YM_WG_ATTR
+#define YM_WG_ATTR_DL(I, N, T) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_f32<I, 128, N, true, T>), hipFuncAttributeMaxDynamicSharedMemorySize, big)
+        YM_WG_ATTR_DL(0, 2, 32); YM_WG_ATTR_DL(1, 2, 32); YM_WG_ATTR_DL(0, 3, 16); YM_WG_ATTR_DL(1, 3, 16);
+        YM_WG_ATTR_DL(0, 4, 16); YM_WG_ATTR_DL(1, 4, 16);
+#undef YM_WG_ATTR_DL
         attr_set = true;
     }
     // incremental coordinates need: (rows advanced per step) + 1 < 2 * Ho, so that two conditional wraps suffice
@@ -288,9 +336,18 @@ extern "C" int ym_conv2d_wgrad(const ym_wgrad_desc* d, void* workspace, size_t w
         if (p.incr) hipLaunchKernelGGL((conv_wgrad_f32<1, T, N>), wgrid, dim3(256), lds, st, p);   \
         else hipLaunchKernelGGL((conv_wgrad_f32<0, T, N>), wgrid, dim3(256), lds, st, p);          \
     } while (0)
-    if (pl.tbn == 64) { if (pl.nb == 1) YM_WG_LAUNCH(64, 1); else YM_WG_LAUNCH(64, 2); }
+#define YM_WG_LAUNCH_DL(N, T)                                                                                  \
+    do {                                                                                                       \
+        if (p.incr) hipLaunchKernelGGL((conv_wgrad_f32<1, 128, N, true, T>), wgrid, dim3(256), lds, st, p);   \
+        else hipLaunchKernelGGL((conv_wgrad_f32<0, 128, N, true, T>), wgrid, dim3(256), lds, st, p);          \
+    } while (0)
+    if (pl.nb == 22) YM_WG_LAUNCH_DL(2, 32);
+    else if (pl.nb == 23) YM_WG_LAUNCH_DL(3, 16);
+    else if (pl.nb == 24) YM_WG_LAUNCH_DL(4, 16);
+    else if (pl.tbn == 64) { if (pl.nb == 1) YM_WG_LAUNCH(64, 1); else YM_WG_LAUNCH(64, 2); }
     else { if (pl.nb == 1) YM_WG_LAUNCH(128, 1); else YM_WG_LAUNCH(128, 2); }
 #undef YM_WG_LAUNCH
+#undef YM_WG_LAUNCH_DL
     rc = ym_check_launch("conv_wgrad_f32");
     if (rc != YM_OK) return rc;
     const size_t total = (size_t)d->Cout_real * pl.Ktot;

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ a,
 
 // ordered sum of the per-workgroup partials: 16 channels x 16 block slices per workgroup, slices combined through LDS
 __global__ __launch_bounds__(256) void k_col_finish(const double* __restrict__ part, int blocks, int C, double* __restrict__ out0,
-                                                     double* __restrict__ out1) {
+                                                     double* __restrict__ out1, float* __restrict__ out0_f = nullptr) {
     __shared__ double red[2][16][17];
     const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
@@ -174,6 +174,7 @@ __global__ __launch_bounds__(256) void k_col_finish(const double* __restrict__ p
         for (int r = 0; r < 16; ++r) { sa += red[0][r][cl]; sb += red[1][r][cl]; }
         out0[c] = sa;
         out1[c] = sb;
+        if (out0_f) out0_f[c] = (float)sa;          // (the bias gradient: saves the separate fp64 -> fp32 launch)
     }
 }
 
@@ -640,7 +641,8 @@ extern "C" int ym_act_bias_bwd(const float* dy, const float* y, int64_t M, int C
             double* part = acc + 2 * C;
             hipLaunchKernelGGL(k_col_reduce<2>, dim3(big), dim3(256), 0, st, dy, y, nullptr, nullptr, nullptr, (long long)M, C, 0,
                                act, acc, acc + C, part);
-            hipLaunchKernelGGL(k_col_finish, dim3(ym_cdiv(C, 16)), dim3(256), 0, st, part, big, C, acc, acc + C);
+            hipLaunchKernelGGL(k_col_finish, dim3(ym_cdiv(C, 16)), dim3(256), 0, st, part, big, C, acc, acc + C, dbias);
+            return ym_check_launch("act_bias_bwd");
         } else {
             if (grid > 2048) grid = 2048;
             (void)hipMemsetAsync(acc, 0, (size_t)C * 8, st);
