@@ -167,7 +167,9 @@ typedef struct {
 } ym_aug_plan;
 /* img HWC BGR (uint8 if is_u8 else float32) -> out [3][S][S] normalised RGB planes, one launch. */
 int ym_train_aug_image(const void* img_hwc_bgr, int is_u8, const ym_aug_plan* plan, float* out_chw, ym_stream_t s);
-/* masks [n][H][W] (uint8 / float32), keep [k] indices of the surviving instances -> out [k][S][S] (bilinear, border 0). */
+/* masks [n][H][W] (uint8 / float32), keep [k] indices of the surviving instances -> out [k][S][S] (bilinear, border 0).  uint8 masks
+ * of an already-square crop (plan->cw == plan->ch) take OpenCV's 8-bit fixed-point resize, as in the reference (its masks stay uint8
+ * there: utils/augmentations.py:138-141,180-181): a {0,1} mask comes out {0,1}. */
 int ym_train_aug_masks(const void* masks, int is_u8, const int32_t* keep, int k, const ym_aug_plan* plan, float* out,
                        ym_stream_t s);
 

@@ -63,9 +63,48 @@ def resize_bilinear(x_hwc, size):
     return F.interpolate(t, (size, size), mode='bilinear', align_corners=False)[0].permute(1, 2, 0).numpy()
 
 
+def resize_bilinear_u8(x_hwc, size):
+    """cv2.resize(uint8 HxWxC, (size, size)) with the default INTER_LINEAR: OpenCV's 8-bit path is FIXED POINT (imgproc/resize.cpp:
+    horizontal pass with coefficients saturate_cast<short>(w * 2048) into int32, vertical pass
+    `(((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2`), so a {0,1} instance mask comes out {0,1}.  The reference
+    hits it when the cropped sample is already square: pad_to_square (:138-141) then returns the uint8 masks of annToMask untouched
+    and multi_scale_resize (:180-181) resizes them as uint8; every other sample goes through the float32 pad buffer (:147).
+    Restated from OpenCV's published algorithm — cv2 is absent here: PARITY UNPINNED for this primitive."""
+    x = np.ascontiguousarray(x_hwc)
+    assert x.dtype == np.uint8 and x.ndim == 3
+    h, w, _ = x.shape
+
+    def taps(n_src, n_dst, clamp_weights):
+        d = np.arange(n_dst, dtype=np.float64)
+        f = ((d + 0.5) * (n_src / n_dst) - 0.5).astype(np.float32)
+        i0 = np.floor(f).astype(np.int64)
+        fr = (f - i0.astype(np.float32)).astype(np.float32)
+        if clamp_weights:                       # x: weights forced to (1, 0) at the borders, taps inside the row
+            lo, hi = i0 < 0, i0 >= n_src - 1
+            fr = np.where(lo | hi, np.float32(0), fr)
+            i0 = np.where(lo, 0, np.where(hi, n_src - 1, i0))
+            i1 = np.minimum(i0 + 1, n_src - 1)
+        else:                                   # y: weights kept, row indices clipped
+            i1 = np.clip(i0 + 1, 0, n_src - 1)
+            i0 = np.clip(i0, 0, n_src - 1)
+        w0 = np.rint((np.float32(1) - fr) * np.float32(2048)).astype(np.int64)      # saturate_cast<short> = round half to even
+        w1 = np.rint(fr * np.float32(2048)).astype(np.int64)
+        return i0, i1, w0, w1
+
+    x0, x1, a0, a1 = taps(w, size, True)
+    y0, y1, b0, b1 = taps(h, size, False)
+    xi = x.astype(np.int64)
+    hor = xi[:, x0, :] * a0[None, :, None] + xi[:, x1, :] * a1[None, :, None]             # [h][size][c], scale 2048
+    s0, s1 = hor[y0] >> 4, hor[y1] >> 4
+    out = (((b0[:, None, None] * s0) >> 16) + ((b1[:, None, None] * s1) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
 def apply_plan(img, masks, plan):
     """img [H,W,3] BGR (uint8 / float), masks [n,H,W] -> (image [3,S,S] float32 normalised RGB, masks [k,S,S] float32)."""
     img = photometric(img, plan)
+    u8_square = masks.dtype == np.uint8 and plan.crop[2] == plan.crop[3]      # the reference keeps uint8 masks here (resize_bilinear_u8)
+    masks_u8 = masks
     masks = masks.astype(np.float32)
     if plan.mirror:
         img, masks = img[:, ::-1], masks[:, :, ::-1]
@@ -80,6 +119,10 @@ def apply_plan(img, masks, plan):
     r = plan.resize
     img = resize_bilinear(sq, r)
     masks = resize_bilinear(sm.transpose(1, 2, 0), r).transpose(2, 0, 1) if sm.shape[0] else sm[:, :r, :r]
+    if u8_square and sm.shape[0]:
+        mu = masks_u8[:, :, ::-1] if plan.mirror else masks_u8
+        mu = mu[:, cy:cy + ch, cx:cx + cw]                                       # (q == cw == ch, no pad)
+        masks = resize_bilinear_u8(mu.transpose(1, 2, 0), r).transpose(2, 0, 1).astype(np.float32)
     s = plan.size
     if plan.final_pad is not None:
         fx, fy = plan.final_pad

@@ -31,7 +31,8 @@ def import_reference_aug():
 
     def resize(img, size):
         x = img if img.ndim == 3 else img[:, :, None]
-        out = A.resize_bilinear(x.astype(np.float32), size[0])
+        # (uint8 in -> OpenCV's fixed-point 8-bit path, uint8 out: the masks of an already-square sample)
+        out = A.resize_bilinear_u8(x, size[0]) if x.dtype == np.uint8 else A.resize_bilinear(x.astype(np.float32), size[0])
         return out if img.ndim == 3 and out.shape[2] > 1 else out[:, :, 0] if out.shape[2] == 1 else out
 
     def cvt(img, code):
@@ -47,8 +48,9 @@ from yolact_minimal_amd.utils.synthetic import synth_sample  # noqa: E402,F401  
 def main():
     ref = import_reference_aug()
     from yolact_minimal_amd.utils.augmentations import sample_train_aug
-    out, n_none = {}, 0
+    out, n_none, n_u8 = {}, 0, 0
     cases = [(s, 96 + 8 * (s % 5), 128 - 6 * (s % 4), 1 + s % 4, 160 if s % 3 else 544) for s in range(40)]
+    cases[8:12] = [(40 + s, 104, 104, 1 + s % 3, 160) for s in range(4)]          # square images: the uint8-mask branch when no crop is drawn
     for k, (seed, h, w, n, size) in enumerate(cases):
         img, masks, boxes, labels = synth_sample(seed, h, w, n)
         random.seed(1000 + seed)
@@ -63,6 +65,7 @@ def main():
         assert np.array_equal(plan.boxes, r_boxes), (seed, plan.boxes, r_boxes)          # float64, bit for bit
         assert np.array_equal(np.asarray(plan.labels, dtype=np.float64), np.asarray(r_labels, dtype=np.float64)), seed
         o_img, o_masks = A.apply_plan(img, masks, plan)
+        n_u8 += int(masks.dtype == np.uint8 and plan.crop[2] == plan.crop[3])
         assert o_masks.shape == r_masks.shape, (seed, o_masks.shape, r_masks.shape)
         np.testing.assert_allclose(o_img, r_img.astype(np.float32), rtol=0, atol=2e-4, err_msg=str(seed))
         np.testing.assert_allclose(o_masks, r_masks.astype(np.float32), rtol=0, atol=1e-6, err_msg=str(seed))
@@ -76,6 +79,7 @@ def main():
                                           *(plan.final_pad or (-1, -1)), *(plan.final_crop or (-1, -1))])
             out[f'c{k}_img_digest'] = np.array([r_img.astype(np.float64).sum(), np.abs(r_img.astype(np.float64)).sum()])
             out[f'c{k}_mask_sum'] = r_masks.astype(np.float64).sum(axis=(1, 2))
+    assert n_u8 >= 1, 'no sample exercised the uint8 (already square) mask branch'
     np.savez_compressed(os.path.join(REPO, 'tests', 'golden', 'augment.npz'), **out)
     print(f'{len(cases)} seeded samples: decisions, boxes, labels and stage chain equal to the reference ({n_none} rejected by both); '
           f'wrote tests/golden/augment.npz')

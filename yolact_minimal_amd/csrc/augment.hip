@@ -117,9 +117,32 @@ __global__ __launch_bounds__(256) void k_train_aug_image(const T* __restrict__ i
     }
 }
 
+// cv2.resize on uint8 (INTER_LINEAR) is fixed point: taps of one axis as OpenCV computes them (imgproc/resize.cpp) — source index
+// from the half-pixel centre in double, weights saturate_cast<short>(w * 2048) (round half to even); along x the weights are forced
+// to (1, 0) at the borders, along y the row indices are clipped instead.
+__device__ __forceinline__ void u8_taps(int n_src, int n_dst, int d, bool clamp_weights, int& i0, int& i1, int& w0, int& w1) {
+    const float f = (float)(((double)d + 0.5) * ((double)n_src / (double)n_dst) - 0.5);
+    int i = (int)floorf(f);
+    float fr = f - (float)i;
+    if (clamp_weights) {
+        if (i < 0) { fr = 0.f; i = 0; }
+        if (i >= n_src - 1) { fr = 0.f; i = n_src - 1; }
+        i0 = i;
+        i1 = i + 1 < n_src ? i + 1 : n_src - 1;
+    } else {
+        i1 = i + 1 < 0 ? 0 : (i + 1 > n_src - 1 ? n_src - 1 : i + 1);
+        i0 = i < 0 ? 0 : (i > n_src - 1 ? n_src - 1 : i);
+    }
+    w0 = (int)__builtin_rintf((1.f - fr) * 2048.f);
+    w1 = (int)__builtin_rintf(fr * 2048.f);
+}
+
+// `fixed`: uint8 masks of an already-square crop — the reference resizes them as uint8 (pad_to_square :138-141 returns them
+// untouched, multi_scale_resize :180-181), i.e. through OpenCV's 8-bit fixed-point path, and a {0,1} mask stays {0,1}
+// (oracle/augment_ref.py resize_bilinear_u8); every other sample's masks went through the float32 pad buffer first.
 template <typename T>
 __global__ __launch_bounds__(256) void k_train_aug_masks(const T* __restrict__ masks, const int32_t* __restrict__ keep, int k,
-                                                         const ym_aug_plan p, float* __restrict__ out) {
+                                                         const ym_aug_plan p, float* __restrict__ out, int fixed) {
     const int S = p.S;
     const long long plane = (long long)S * S, total = plane * k;
     const float scale = (float)p.q / (float)p.r;
@@ -130,7 +153,21 @@ __global__ __launch_bounds__(256) void k_train_aug_masks(const T* __restrict__ m
         const T* m = masks + (size_t)keep[j] * p.H * p.W;
         float v = 0.f;
         int ry, rx;
-        if (to_resized(p, y, x, ry, rx)) {
+        if (fixed && to_resized(p, y, x, ry, rx)) {
+            int y0, y1, x0, x1, a0, a1, b0, b1;
+            u8_taps(p.q, p.r, rx, true, x0, x1, a0, a1);
+            u8_taps(p.q, p.r, ry, false, y0, y1, b0, b1);
+            int t[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    int Y, X;
+                    t[a][b] = to_source(p, a ? y1 : y0, b ? x1 : x0, Y, X) ? (int)m[(size_t)Y * p.W + X] : 0;
+                }
+            const int h0 = t[0][0] * a0 + t[0][1] * a1, h1 = t[1][0] * a0 + t[1][1] * a1;          // horizontal pass, scale 2048
+            v = (float)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+        } else if (to_resized(p, y, x, ry, rx)) {
             int y0, y1, x0, x1;
             float ly, lx;
             src_index(scale, ry, p.q, y0, y1, ly);
@@ -187,7 +224,8 @@ extern "C" int ym_train_aug_masks(const void* masks, int is_u8, const int32_t* k
     if (k == 0) return YM_OK;
     YM_REQUIRE(masks && keep && out, "train_aug_masks: null pointer");
     const int g = grid_for((long long)plan->S * plan->S * k);
-    if (is_u8) hipLaunchKernelGGL(k_train_aug_masks<uint8_t>, dim3(g), dim3(256), 0, (hipStream_t)s, (const uint8_t*)masks, keep, k, *plan, out);
-    else hipLaunchKernelGGL(k_train_aug_masks<float>, dim3(g), dim3(256), 0, (hipStream_t)s, (const float*)masks, keep, k, *plan, out);
+    const int fixed = (is_u8 && plan->cw == plan->ch) ? 1 : 0;          // already-square sample: the reference's masks stay uint8
+    if (is_u8) hipLaunchKernelGGL(k_train_aug_masks<uint8_t>, dim3(g), dim3(256), 0, (hipStream_t)s, (const uint8_t*)masks, keep, k, *plan, out, fixed);
+    else hipLaunchKernelGGL(k_train_aug_masks<float>, dim3(g), dim3(256), 0, (hipStream_t)s, (const float*)masks, keep, k, *plan, out, 0);
     return ym_check_launch("train_aug_masks");
 }
