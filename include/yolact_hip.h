@@ -357,6 +357,13 @@ int ym_class_box_loss(const float* class_p, const float* box_p, const float* off
                       float conf_alpha, float bbox_alpha, int neg_pos_ratio, float* dclass, float* dbox, int32_t* num_pos,
                       double* loss_c, double* loss_b, void* workspace, size_t workspace_bytes, ym_stream_t s);
 
+/* The positives the mask loss trains on (modules/yolact.py:255-267): conf [B][N] (> 0 = positive), num_pos [B] their counts (from
+ * ym_class_box_loss), keys [B][N] iid uniform [0,1) draws.  idx[b][0 .. min(count, cap)) = all positives of image b in anchor order
+ * when count <= cap, else the `cap` positives with the largest keys (a uniformly random subset, the reference's randperm[:cap]),
+ * in anchor order; equal keys by anchor index.  No host synchronisation. */
+int ym_select_positives(const int64_t* conf, const float* keys, int B, int N, int cap, const int32_t* num_pos, int64_t* idx,
+                        ym_stream_t s);
+
 /* semantic_seg_loss (modules/yolact.py:293-313) for ONE image: seg_nhwc [P][pitch] logits (channels >= num_classes are
  * padding), gt_masks_ds [g][P] in {0,1} (down-sampled + binarised gt masks), gt_cls[j*gt_cls_stride] the class of gt j.
  * loss_accum += coeff * sum BCE-with-logits(seg, target) with target[c][pix] = max over gts of class c; dseg [P][pitch] =

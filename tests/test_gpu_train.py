@@ -638,6 +638,40 @@ def test_mask_loss_subsamples_on_the_device_without_host_sync():
     assert abs(np.mean(losses) / float(full) - 1) < 0.15                 # the re-weighted subset estimates the full sum
 
 
+def test_select_positives_kernel_picks_the_largest_keys_in_anchor_order():
+    """ym_select_positives: <= cap positives -> all of them in anchor order; more -> the cap largest keys among the positives (equal
+    keys by anchor index), also in anchor order; the tail of a row is never written."""
+    from yolact_minimal_amd import hip
+    g = torch.Generator().manual_seed(11)
+    b, n, cap = 4, 18525, 100
+    conf = torch.zeros(b, n, dtype=torch.int64)
+    counts = [0, 37, 100, 3000]
+    for i, c in enumerate(counts):
+        conf[i, torch.randperm(n, generator=g)[:c]] = torch.randint(1, 81, (c,), generator=g)
+    conf[0, 5] = -1                                                       # neutral anchors are not positives
+    keys = torch.rand(b, n, generator=g)
+    pos3 = (conf[3] > 0).nonzero().flatten()
+    keys[3, pos3[:400]] = 0.9995                                          # a 400-way tie that straddles the threshold
+    num_pos = torch.tensor(counts + [sum(counts)], dtype=torch.int32)
+    idx = torch.full((b, cap), -7, dtype=torch.int64, device=DEV)
+    conf_d, keys_d, num_d = conf.to(DEV), keys.to(DEV), num_pos.to(DEV)           # (kept alive across the launch)
+    hip.check(hip.lib().ym_select_positives(hip.ptr(conf_d, torch.int64), hip.ptr(keys_d), b, n, cap, hip.ptr(num_d, torch.int32),
+                                            hip.ptr(idx, torch.int64), hip.stream_ptr()), 'sel')
+    idx = idx.cpu()
+    for i, c in enumerate(counts):
+        k = min(c, cap)
+        got = idx[i, :k]
+        assert bool((idx[i, k:] == -7).all())
+        pos = (conf[i] > 0).nonzero().flatten()
+        if c <= cap:
+            assert torch.equal(got, pos)
+        else:
+            kp = keys[i, pos]
+            order = sorted(range(len(pos)), key=lambda j: (-float(kp[j]), int(pos[j])))[:cap]      # largest key, then lowest anchor
+            want = torch.sort(pos[torch.tensor(order)]).values
+            assert torch.equal(got, want)
+
+
 def _loss_inputs(b, size, n_gt, seed):
     cfg = build_cfg('res50_coco', 'train', size)
     anchors = R.anchors_for(size, cfg.scales).float()

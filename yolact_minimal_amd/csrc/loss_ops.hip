@@ -257,6 +257,87 @@ __global__ __launch_bounds__(NT) void k_ohem_select(const float* __restrict__ ma
     }
 }
 
+// Positives of one image for the mask loss (modules/yolact.py:255-267): all of them in anchor order when there are at most `cap`
+// (masks_to_train), else a uniformly random subset of exactly `cap` — the `cap` largest of the caller's iid uniform keys among the
+// positives (radix select, equal keys by anchor index), written in anchor order.  Workgroup = image.  idx[b][0 .. min(P, cap)) are
+// valid; the rest is never read (the mask-loss kernel takes the counts from num_pos).  Replaces a masked_fill + topk chain of six
+// ATen launches per step.
+__global__ __launch_bounds__(NT) void k_select_positives(const int64_t* __restrict__ conf, const float* __restrict__ keys, int N,
+                                                         int cap, const int* __restrict__ num_pos, int64_t* __restrict__ idx) {
+    __shared__ uint32_t hist[256];
+    __shared__ int sh_digit, sh_rem, wave_tot[NT / 64], wave_eq[NT / 64], running, run_eq;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t* cf = conf + (size_t)b * N;
+    const float* ky = keys + (size_t)b * N;
+    int64_t* out = idx + (size_t)b * cap;
+    const int P = num_pos[b];
+    uint32_t T = 0u;
+    int r_eq = 0;
+    const bool all = P <= cap;
+    auto key = [&](int i) { return __float_as_uint(ky[i]); };               // keys are in [0, 1): the bit pattern orders them
+    if (!all) {
+        uint32_t prefix = 0u, mask = 0u;
+        int remaining = cap;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            for (int i = tid; i < 256; i += NT) hist[i] = 0u;
+            __syncthreads();
+            for (int i = tid; i < N; i += NT) {
+                if (cf[i] <= 0) continue;
+                const uint32_t k = key(i);
+                if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int acc = 0, d = 255;
+                for (; d > 0; --d) {
+                    const int h = (int)hist[d];
+                    if (acc + h >= remaining) break;
+                    acc += h;
+                }
+                sh_digit = d; sh_rem = remaining - acc;
+            }
+            __syncthreads();
+            prefix |= (uint32_t)sh_digit << shift;
+            mask |= 0xFFu << shift;
+            remaining = sh_rem;
+            __syncthreads();
+        }
+        T = prefix;
+        r_eq = remaining;                                                    // how many keys equal to T are taken (lowest anchors)
+    }
+    if (tid == 0) { running = 0; run_eq = 0; }
+    __syncthreads();
+    for (int base = 0; base < N; base += NT) {
+        const int i = base + tid;
+        const bool p = i < N && cf[i] > 0;
+        const uint32_t k = p ? key(i) : 0u;
+        const bool eq = p && !all && k == T;
+        const unsigned long long bal_eq = __ballot(eq);
+        if (lane == 0) wave_eq[wv] = __popcll(bal_eq);
+        __syncthreads();
+        int off_eq = run_eq;
+        for (int w = 0; w < wv; ++w) off_eq += wave_eq[w];
+        const bool take = p && (all || k > T || (eq && off_eq + __popcll(bal_eq & ((1ull << lane) - 1ull)) < r_eq));
+        const unsigned long long bal = __ballot(take);
+        if (lane == 0) wave_tot[wv] = __popcll(bal);
+        __syncthreads();
+        int off = running;
+        for (int w = 0; w < wv; ++w) off += wave_tot[w];
+        if (take) {
+            const int slot = off + __popcll(bal & ((1ull << lane) - 1ull));
+            if (slot < cap) out[slot] = i;
+        }
+        __syncthreads();                                                      // everyone has read running / run_eq and both count arrays
+        if (tid == 0) {
+            int t = 0, e = 0;
+            for (int w = 0; w < NT / 64; ++w) { t += wave_tot[w]; e += wave_eq[w]; }
+            running += t;
+            run_eq += e;
+        }
+        __syncthreads();
+    }
+}
+
 // cross entropy over the selected rows (sum) / total positives, and its gradient; one wave per row
 __global__ __launch_bounds__(256) void k_ce_loss(const float* __restrict__ cls, const int64_t* __restrict__ conf,
                                                   const uint8_t* __restrict__ sel, long long rows, int C, const int* __restrict__ num_pos,
@@ -391,6 +472,13 @@ extern "C" int ym_class_box_loss(const float* class_p, const float* box_p, const
     if (bgrid > 2048) bgrid = 2048;
     hipLaunchKernelGGL(k_box_loss, dim3(bgrid), dim3(256), 0, st, box_p, offsets, conf, rows, num_pos, B, bbox_alpha, dbox, loss_b);
     return ym_check_launch("class_box_loss");
+}
+
+extern "C" int ym_select_positives(const int64_t* conf, const float* keys, int B, int N, int cap, const int32_t* num_pos, int64_t* idx,
+                                   ym_stream_t s) {
+    YM_REQUIRE(conf && keys && num_pos && idx && B > 0 && N > 0 && cap > 0, "select_positives: bad args");
+    hipLaunchKernelGGL(k_select_positives, dim3(B), dim3(NT), 0, (hipStream_t)s, conf, keys, N, cap, num_pos, idx);
+    return ym_check_launch("select_positives");
 }
 
 extern "C" int ym_semantic_loss_batch(const float* seg_nhwc, int B, int P, int pitch, int num_classes,

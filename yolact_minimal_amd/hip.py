@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     'ym_mask_loss_workspace_bytes', 'ym_mask_loss_fwd_bwd', 'ym_mask_loss_batch_workspace_bytes', 'ym_mask_loss_batch',
     'ym_mask_iou_workspace_bytes', 'ym_mask_iou', 'ym_box_iou', 'ym_match_detections', 'ym_rle_encode', 'ym_ann_to_mask_workspace_bytes', 'ym_poly_to_mask', 'ym_runs_to_mask', 'ym_train_aug_image', 'ym_train_aug_masks',
     'ym_layernorm_bwd_workspace_bytes', 'ym_layernorm_bwd', 'ym_patch_merge_layernorm_bwd', 'ym_gelu_fwd', 'ym_gelu_bwd',
-    'ym_swin_window_attention_bwd', 'ym_adamw_step', 'ym_drop_path_add', 'ym_drop_path_bwd',
+    'ym_swin_window_attention_bwd', 'ym_adamw_step', 'ym_drop_path_add', 'ym_drop_path_bwd', 'ym_select_positives',
     'ym_match_anchors', 'ym_match_anchors_batch', 'ym_loss_workspace_bytes', 'ym_class_box_loss', 'ym_semantic_loss',
     'ym_semantic_loss_batch',
     'ym_bn_train_bwd_workspace_bytes', 'ym_bn_train_bwd', 'ym_bn_train_bwd_apply', 'ym_act_bias_bwd', 'ym_conv2d_fuses_bn_stats', 'ym_bn_train_fwd_stats', 'ym_maxpool3x3s2_bwd', 'ym_maxpool3x3s2_fwd_idx', 'ym_maxpool3x3s2_bwd_idx', 'ym_bilinear2x_bwd', 'ym_sgd_step',
@@ -174,6 +174,7 @@ def lib():
         L.ym_gelu_fwd.argtypes = [vp, vp, i64, vp]
         L.ym_gelu_bwd.argtypes = [vp, vp, vp, i64, vp]
         L.ym_swin_window_attention_bwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]
+        L.ym_select_positives.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
         L.ym_drop_path_add.argtypes = [vp, vp, vp, ctypes.c_float, vp, i32, i64, vp]
         L.ym_drop_path_bwd.argtypes = [vp, vp, ctypes.c_float, vp, i32, i64, vp]
         L.ym_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]

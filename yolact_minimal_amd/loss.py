@@ -143,7 +143,7 @@ def mask_generator(device):
 
 
 def lincomb_mask_loss(cfg, pos, anchor_gt, coef_p, proto_p, mask_gt, anchor_box, num_pos=None):
-    """`num_pos`: int32 device tensor [n_0..n_{B-1}, total] of positive counts (`ym_class_box_loss` produces it); computed here
+    """`pos`: [B,N] bool, or the matched labels conf_gt (int64, > 0 = positive).  `num_pos`: int32 device tensor [n_0..n_{B-1}, total] of positive counts (`ym_class_box_loss` produces it); computed here
     when absent.  Nothing is read back to the host: the kernel takes the counts from device memory, and the reference's
     `randperm` sub-sampling of > masks_to_train positives (:261-267, a CPU generator there) is a device-side random top-k —
     a uniformly random subset like the reference's, from the device generator instead of the host one."""
@@ -151,14 +151,19 @@ def lincomb_mask_loss(cfg, pos, anchor_gt, coef_p, proto_p, mask_gt, anchor_box,
     b, n = pos.shape
     dev = proto_p.device
     if num_pos is None:
-        per = pos.sum(1)
+        per = (pos > 0).sum(1)
         num_pos = torch.cat([per, per.sum(0, keepdim=True)]).to(torch.int32)
     if int(cfg.masks_to_train) > MAX_MASKS_PER_IMAGE:
         raise RuntimeError(f'cfg.masks_to_train = {cfg.masks_to_train}: the mask-loss kernel holds at most {MAX_MASKS_PER_IMAGE} '
                            f'positives per image (the reference default is 100)')
     cap = min(int(cfg.masks_to_train), n)
-    keys = torch.rand(b, n, device=dev, generator=mask_generator(dev)).masked_fill_(~pos, -1.0)
-    idx = keys.topk(cap, dim=1).indices.contiguous()          # the positives (random order) come first; the rest is never read
+    # positives in anchor order, or — over the cap — the `cap` largest of iid uniform keys among them (ym_select_positives): one
+    # launch, no host read; the draw comes from the dedicated generator
+    conf = pos if pos.dtype == torch.int64 else pos.to(torch.int64)
+    keys = torch.rand(b, n, device=dev, generator=mask_generator(dev))
+    idx = torch.empty(b, cap, dtype=torch.int64, device=dev)
+    hip.check(hip.lib().ym_select_positives(_vp(conf.contiguous()), _vp(keys), b, n, cap, _vp(num_pos.contiguous()), _vp(idx),
+                                            hip.stream_ptr()), 'ym_select_positives')
     ds_masks = []
     for i in range(b):
         g = mask_gt[i].shape[0]
@@ -220,6 +225,6 @@ def compute_loss(cfg, anchors, class_p, box_p, coef_p, proto_p, seg_p, box_class
     anchors = anchors.contiguous().float()
     match(cfg, [bc.contiguous().float() for bc in box_class], anchors, offsets, conf_gt, anchor_box, anchor_gt, ws)
     loss_c, loss_b = _ClassBoxLossFn.apply(class_p, box_p, offsets, conf_gt, num_pos, cfg.conf_alpha, cfg.bbox_alpha, 3)
-    loss_m = lincomb_mask_loss(cfg, conf_gt > 0, anchor_gt, coef_p, proto_p, mask_gt, anchor_box, num_pos)   # counts stay on the device
+    loss_m = lincomb_mask_loss(cfg, conf_gt, anchor_gt, coef_p, proto_p, mask_gt, anchor_box, num_pos)   # counts stay on the device
     loss_s = semantic_seg_loss(cfg, seg_p, mask_gt, box_class)
     return loss_c, loss_b, loss_m, loss_s
