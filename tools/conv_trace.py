@@ -17,8 +17,10 @@ ws = torch.empty(1 << 27, dtype=torch.uint8, device=dev)
 counters = torch.zeros(hip.TILE_COUNTERS, dtype=torch.int32, device=dev)
 import json  # noqa: E402
 tuned = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'yolact_minimal_amd', 'tuned_gfx950.json')))
-for spec in ((1, 34, 34, 256, 1024, 1, 1, 1), (1, 34, 34, 1024, 256, 1, 1, 0), (1, 34, 34, 256, 256, 3, 1, 0),
-             (1, 68, 68, 256, 256, 3, 1, 0), (8, 34, 34, 256, 256, 3, 1, 0), (8, 136, 136, 256, 256, 3, 1, 0)):
+SPECS = {'bs1': ((1, 34, 34, 256, 1024, 1, 1, 1), (1, 34, 34, 1024, 256, 1, 1, 0), (1, 34, 34, 256, 256, 3, 1, 0),
+                 (1, 68, 68, 256, 256, 3, 1, 0), (8, 34, 34, 256, 256, 3, 1, 0), (8, 136, 136, 256, 256, 3, 1, 0)),
+         'bs8': ((8, 34, 34, 256, 1024, 1, 1, 1), (8, 34, 34, 1024, 256, 1, 1, 0), (8, 34, 34, 256, 256, 3, 1, 0))}
+for spec in SPECS[sys.argv[1] if len(sys.argv) > 1 else 'bs1']:
     d, keep = make_desc(*spec, dev)
     sig = f'M{spec[0] * d.Ho * d.Wo}_N{spec[4]}_C{spec[3]}_k{spec[5]}_s{spec[6]}_seg1_r{spec[7]}'
     hit = tuned.get(sig, [0, 0, 0, 0, 0, 0, 0])
