@@ -17,7 +17,7 @@ import torch
 import torch.distributed as dist
 
 from . import hip
-from .train_engine import weights_changed
+from .train_engine import wgrad_stream_if_used, weights_changed
 
 
 def init_distributed(backend=None):
@@ -217,7 +217,18 @@ class FlatGradReducer:
         while self.next_bucket < len(self.buckets) and self.pending[self.next_bucket] == 0:
             a, e, _ = self.buckets[self.next_bucket]
             op = dist.ReduceOp.AVG if self.avg_op else dist.ReduceOp.SUM
-            self.works.append(dist.all_reduce(self.opt.grad[a:e], op=op, group=self.group, async_op=True))
+            # the collective orders itself after the CURRENT stream: weight gradients are written on train_engine's side stream,
+            # everything else (BN / bias gradients) on the main one -> issue it from the side stream after making that wait for
+            # the main stream; the main stream itself is not held up
+            flat = self.opt.grad
+            side = wgrad_stream_if_used(flat.device) if flat.is_cuda else None
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream(flat.device))
+                with torch.cuda.stream(side):
+                    work = dist.all_reduce(flat[a:e], op=op, group=self.group, async_op=True)
+            else:
+                work = dist.all_reduce(flat[a:e], op=op, group=self.group, async_op=True)
+            self.works.append(work)
             self.launch_log.append((self.next_bucket, self.grads_seen, self.in_finish))
             self.launches += 1
             self.next_bucket += 1
@@ -369,7 +380,9 @@ class Trainer:
             dist.all_reduce(all_loss)                 # 16-byte logging collective, train.py:121-122
         total = losses[0] + losses[1] + losses[2] + losses[3]
         from .loss import unit_loss_grads
-        with unit_loss_grads():                       # d(total)/d(loss_i) = 1: the loss kernels' stored gradients pass through unscaled
+        from .train_engine import wgrad_on_side_stream
+        # weight gradients run on a side stream next to the data-gradient chain; the main stream waits for them at the block's end
+        with unit_loss_grads(), wgrad_on_side_stream(self.device):   # d(total)/d(loss_i) = 1: stored loss gradients pass through unscaled
             total.backward()
         if self.reducer is not None:
             self.reducer.finish()
