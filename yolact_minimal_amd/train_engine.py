@@ -576,10 +576,27 @@ class ConvBias(torch.autograd.Function):
         if has_bias:
             dbias = _grad_slot(bias_param, (c,)) if (bias_param is not None and cout_pad == weight.shape[0]) else \
                 torch.empty(c, device=dy.device, dtype=torch.float32)
-        ws = scratch(dy.device, hip.lib().ym_bn_train_bwd_workspace_bytes(m, c) if has_bias else c * 16)   # partial-sum path
-        hip.check(hip.lib().ym_act_bias_bwd(hip.ptr(dy), hip.ptr(y) if y is not None else None, m, c, act,
-                                            hip.ptr(dz) if act != ACT_NONE else None, hip.ptr(dbias), ctypes.c_void_p(ws.data_ptr()),
-                                            ws.numel(), hip.stream_ptr()), 'ym_act_bias_bwd')
+        y_ptr = hip.ptr(y) if y is not None else None
+
+        def bias_grad():            # column sums of dy * act'(y) (the reduction re-derives act' itself: it does not need dz)
+            ws = scratch(dy.device, hip.lib().ym_bn_train_bwd_workspace_bytes(m, c))                  # partial-sum path
+            hip.check(hip.lib().ym_act_bias_bwd(hip.ptr(dy), y_ptr, m, c, act, None, hip.ptr(dbias), ctypes.c_void_p(ws.data_ptr()),
+                                                ws.numel(), hip.stream_ptr()), 'ym_act_bias_bwd')
+        in_slot = dbias is not None and bias_param is not None and cout_pad == weight.shape[0]
+        if has_bias and in_slot and _side_active[0] and dy.is_cuda:
+            # like the weight gradient, the bias gradient is off the critical path: side stream (it lands in the optimizer's slot)
+            side = wgrad_stream(dy.device)
+            side.wait_stream(torch.cuda.current_stream(dy.device))
+            with torch.cuda.stream(side):
+                bias_grad()
+            dy.record_stream(side)
+            if y is not None:
+                y.record_stream(side)
+        elif has_bias:
+            bias_grad()
+        if act != ACT_NONE:
+            hip.check(hip.lib().ym_act_bias_bwd(hip.ptr(dy), y_ptr, m, c, act, hip.ptr(dz), None, None, 0, hip.stream_ptr()),
+                      'ym_act_bias_bwd')
         dw = _conv_wgrad(x, dz, weight.shape, stride, pad, weight)          # (side stream: overlaps the data gradient below)
         dx = _conv_dgrad(dz, weight, cout_pad, x.shape, stride, pad) if ctx.needs_input_grad[0] else None
         if dbias is not None and cout_pad != weight.shape[0]:
