@@ -27,11 +27,24 @@ for (s0, e0, n0), (s1, e1, n1) in zip(rows, rows[1:]):
         gaps.append((g, n0.split('(')[0][-60:], n1.split('(')[0][-60:]))
     busy += e0 - s0
 gs = sorted(g for g, _, _ in gaps)
-tot_gap = sum(g for g in gs if g > 0)
-print(f'{len(rows)} kernels, busy {busy / 1e6:.2f} ms, gaps {tot_gap / 1e6:.2f} ms = {100 * tot_gap / (tot_gap + busy):.1f} % of busy+gap')
+# kernels of different streams may overlap (training: weight gradients on a side stream): device-busy time = UNION of the intervals
+union, cur_end = 0, None
+for s0, e0, _ in rows:
+    if cur_end is None or s0 >= cur_end:
+        union += e0 - s0
+        cur_end = e0
+    elif e0 > cur_end:
+        union += e0 - cur_end
+        cur_end = e0
+busy += rows[-1][1] - rows[-1][0] if rows else 0
+span_all = (rows[-1][1] - rows[0][0]) if rows else 0
+tot_gap = span_all - union if marker else sum(g for g in gs if g > 0)
+print(f'{len(rows)} kernels, kernel time {busy / 1e6:.2f} ms (sum over streams), device busy {union / 1e6:.2f} ms (union), '
+      f'idle {tot_gap / 1e6:.2f} ms = {100 * tot_gap / max(1, tot_gap + union):.1f} % of the span')
 if steps:
     span = rows[-1][1] - rows[0][0]
-    print(f'  steady state: {steps} steps, {span / steps / 1e6:.2f} ms/step wall, {busy / steps / 1e6:.2f} ms busy, '
+    print(f'  steady state: {steps} steps, {span / steps / 1e6:.2f} ms/step wall, {union / steps / 1e6:.2f} ms busy (union; '
+          f'{busy / steps / 1e6:.2f} ms of kernel time, {busy / max(1, union):.2f} kernels in flight on average), '
           f'{tot_gap / steps / 1e6:.2f} ms idle, {len(rows) / steps:.0f} kernels/step')
     for lim in (5, 20, 100, 1000):
         part = sum(g for g in gs if 0 < g <= lim * 1000)
