@@ -455,7 +455,7 @@ def main():
                 k2 = 40 if b == 1 else 10
                 t2 = timed(w2, k2, 5, lambda: None) / k2
                 f2 = Workload(n2, c2, b, args.img_size, device, with_post=False)
-                tf2 = timed(f2, k2, 5, lambda: None) / k2
+                tf2 = min(timed(f2, k2, 5, lambda: None), timed(f2, k2, 2, lambda: None)) / k2      # (best of two: a short region)
                 fl2 = f2.engine.total_flops
                 split[f'{name}_bs{b}_bf16x{mma}'] = dict(img_s=round(b / t2, 1), forward_only_img_s=round(b / tf2, 1),
                                                          tflops_f32_equiv=round(fl2 / tf2 / 1e12, 1),
