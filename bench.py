@@ -397,7 +397,10 @@ def main():
     if not args.no_train:
         net._engines.clear()
         torch.cuda.empty_cache()
-        train = train_bench(args.cfg, args.img_size, args.train_batch, args.train_steps, 2, world, local_rank, device, barrier)
+        try:
+            train = train_bench(args.cfg, args.img_size, args.train_batch, args.train_steps, 2, world, local_rank, device, barrier)
+        except Exception as e:        # the headline line must still be printed; the failure is reported under extra.train
+            train = dict(error=f'{type(e).__name__}: {e}'[:400])
 
     out = None
     if rank == 0:
@@ -493,7 +496,7 @@ def main():
             r50 = [cpu_baseline('res50_coco', args.img_size, threads=t, budget_s=4.0, max_img=4) for t in (8, 32)]
             cpu['res50_coco'] = max(r50, key=lambda r: r['value'])
         extra['train'] = train
-        primary_train = args.mode == 'train' and train is not None
+        primary_train = args.mode == 'train' and train is not None and 'error' not in train
         out = {
             'metric': (f'img/s {args.cfg} 544x544 DDP training (bs={args.train_batch}/GPU)' if primary_train else
                        f'img/s {args.cfg} 544x544 inference (bs={args.batch}/GPU)'),
