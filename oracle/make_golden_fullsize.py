@@ -9,7 +9,7 @@
   train_res101_coco_544_b16.npz     config 4's per-GPU training step (batch 16): 4 losses + fp32 gradient digests
 
 Every case also pins oracle/yolact_ref.py's restatement bit for bit against the reference.  TEST INFRASTRUCTURE ONLY.
-Run from the repo root:  python -m oracle.make_golden_fullsize [forward] [train256] [train544]
+Run from the repo root:  python -m oracle.make_golden_fullsize [forward] [train256] [train544] [train544res50] [train544b16]
 """
 import os
 import sys
@@ -133,7 +133,7 @@ def gen_train(ref_config, ref_yolact, name, size, batch, seed, damp=False, fp64=
 
 
 def main():
-    what = set(sys.argv[1:]) or {'forward', 'train256', 'train544', 'train544b16'}
+    what = set(sys.argv[1:]) or {'forward', 'train256', 'train544', 'train544res50', 'train544b16'}
     ref_config, ref_yolact, ref_out, ref_box = import_reference()
     torch.set_num_threads(8)
     if 'forward' in what:
@@ -142,6 +142,8 @@ def main():
         gen_train(ref_config, ref_yolact, 'res50_coco', 256, 4, 71, damp=True)
     if 'train544' in what:
         gen_train(ref_config, ref_yolact, 'res101_coco', 544, 8, 72)
+    if 'train544res50' in what:       # the second ResNet depth at the benchmarked size (bench: extra.res50_coco_bs8 / CPU baseline config 1)
+        gen_train(ref_config, ref_yolact, 'res50_coco', 544, 8, 74)
     if 'train544b16' in what:         # BASELINE config 4's per-GPU batch
         gen_train(ref_config, ref_yolact, 'res101_coco', 544, 16, 73, fp64=False)
 

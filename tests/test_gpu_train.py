@@ -402,7 +402,8 @@ def test_train_step_256_well_conditioned_golden(golden_dir):
     np.testing.assert_allclose(net.backbone.bn1.running_var.cpu().numpy(), g['run_var_stem'], rtol=1e-5, atol=1e-7)
 
 
-def test_train_step_res101_544_bs8_golden(golden_dir):
+@pytest.mark.parametrize('cfg_name', ['res101_coco', 'res50_coco'])
+def test_train_step_544_bs8_golden(golden_dir, cfg_name):
     """BASELINE.json config 3's per-GPU training step at FULL size (res101_coco, 544 px, batch 8) — the shape bench.py times, under
     the tuned training plan — against the REAL reference's losses and gradients (oracle/make_golden_fullsize.py train544, which
     also pins the oracle's restatement bit for bit at this size and evaluates the same step in fp64).
@@ -412,10 +413,11 @@ def test_train_step_res101_544_bs8_golden(golden_dir):
     batch-statistics BatchNorm amplifies rounding that much in backward.  The fp64 oracle is too slow to run live here, so the
     golden carries strided fp64 samples of every gradient and the reference run's own error per tensor: the HIP step is held,
     tensor by tensor, to 3x the fp32 reference's distance from fp64 (floor 1e-3 of max|g|), its robust norms (sum|g|, sum g^2) to
-    10 % / 20 % of the reference's, and its losses to 3e-4 of the fp64 values."""
-    g = np.load(os.path.join(golden_dir, 'train_res101_coco_544_b8.npz'))
+    10 % / 20 % of the reference's, and its losses to 3e-4 of the fp64 values.  The same for res50_coco (the other ResNet depth the
+    bench times at this size; oracle/make_golden_fullsize.py train544res50)."""
+    g = np.load(os.path.join(golden_dir, f'train_{cfg_name}_544_b8.npz'))
     seed, size, batch = int(g['seed']), 544, 8
-    cfg = build_cfg('res101_coco', 'train', size)
+    cfg = build_cfg(cfg_name, 'train', size)
     torch.manual_seed(seed)
     net = Yolact(cfg).train().to(DEV)
     img = torch.randn(batch, 3, size, size, generator=torch.Generator().manual_seed(seed + 300))
