@@ -401,6 +401,15 @@ def main():
             train = train_bench(args.cfg, args.img_size, args.train_batch, args.train_steps, 2, world, local_rank, device, barrier)
         except Exception as e:        # the headline line must still be printed; the failure is reported under extra.train
             train = dict(error=f'{type(e).__name__}: {e}'[:400])
+    train16 = None
+    config4 = world == 8 or os.environ.get('YM_BENCH_CONFIG4', '0') == '1'          # (the env switch lets a 1-GPU test walk this path)
+    if not args.no_train and config4 and args.train_batch != 16 and 'error' not in (train or {}):
+        # BASELINE config 4: bs=16 per GPU on the full node (every rank takes part: the step has collectives)
+        try:
+            torch.cuda.empty_cache()
+            train16 = train_bench(args.cfg, args.img_size, 16, 4, 2, world, local_rank, device, barrier)
+        except Exception as e:
+            train16 = dict(error=f'{type(e).__name__}: {e}'[:400])
 
     out = None
     if rank == 0:
@@ -496,6 +505,8 @@ def main():
             r50 = [cpu_baseline('res50_coco', args.img_size, threads=t, budget_s=4.0, max_img=4) for t in (8, 32)]
             cpu['res50_coco'] = max(r50, key=lambda r: r['value'])
         extra['train'] = train
+        if train16 is not None:
+            extra['train_bs16_per_gpu_ddp8'] = train16
         primary_train = args.mode == 'train' and train is not None and 'error' not in train
         out = {
             'metric': (f'img/s {args.cfg} 544x544 DDP training (bs={args.train_batch}/GPU)' if primary_train else

@@ -539,7 +539,7 @@ def test_bench_under_torchrun_with_rccl_single_rank(tmp_path):
     import subprocess
     import sys
     from tests.conftest import REPO
-    env = dict(os.environ, YM_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env = dict(os.environ, YM_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0', YM_BENCH_CONFIG4='1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
            '--master-port', '29533', os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--cfg',
            'res50_coco', '--no-extra', '--no-cpu-baseline', '--train-batch', '2', '--train-steps', '2']
@@ -549,6 +549,8 @@ def test_bench_under_torchrun_with_rccl_single_rank(tmp_path):
     d = json.loads(line)
     assert d['n_gpus'] == 1 and d['value'] > 0 and d['extra']['train']['finite'] and d['extra']['train']['img_s'] > 0
     assert 'ddp' in d['extra']['train']['parallelism']
+    c4 = d['extra']['train_bs16_per_gpu_ddp8']          # the full-node leg (BASELINE config 4), forced here by YM_BENCH_CONFIG4
+    assert c4['batch_per_gpu'] == 16 and c4['finite'] and c4['img_s'] > 0
 
 
 def test_mask_loss_kernel_matches_oracle_autograd():
