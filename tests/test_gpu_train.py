@@ -169,7 +169,8 @@ def test_bn_backward_sums_ride_on_the_consumers_dgrad():
 
 
 @pytest.mark.parametrize('cin,cout,k,stride,hw,b,msplit', [(128, 256, 1, 1, 34, 4, 7), (64, 128, 3, 1, 23, 3, 5), (128, 160, 3, 2, 30, 2, 3),
-                                                           (4, 96, 7, 2, 64, 2, 9), (256, 352, 3, 1, 9, 8, 2)])
+                                                           (4, 96, 7, 2, 64, 2, 9), (256, 352, 3, 1, 9, 8, 2), (256, 256, 3, 2, 10, 2, 4),
+                                                           (128, 192, 1, 1, 3, 1, 1)])
 def test_conv_wgrad_staging_variants_agree(cin, cout, k, stride, hw, b, msplit):
     """Weight gradient under every operand-staging variant (ym_wgrad_desc.lds_buffers: registers 2 / 1, DMA rings 22 / 23 / 24): the
     pixel reduction runs in the same order in all of them, so for one msplit the results are the SAME BITS; repeated launches of
