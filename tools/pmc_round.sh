@@ -16,4 +16,6 @@ one() {   # name, env, args...
 one infer_bs1_res101 "YM_X=0" $BENCH --steps 10 --warmup 3
 one infer_bs8_res101 "YM_X=0" $BENCH --batch 8 --steps 6 --warmup 2
 one infer_bs8_res101_bf16x3 "YM_CONV_MMA=3" $BENCH --batch 8 --steps 6 --warmup 2
-one train_bs8_res101 "YM_X=0" python $R/tools/train_profile.py --steps 4
+# (one stream: with the weight gradients on their side stream two kernels share the counters)
+one train_bs8_res101 "YM_WGRAD_STREAM=0" python $R/tools/train_profile.py --steps 4
+one train_bs8_swin "YM_WGRAD_STREAM=0" python $R/tools/train_profile.py --cfg swin_tiny_coco --steps 4
