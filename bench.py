@@ -363,9 +363,33 @@ def cpu_baseline(cfg_name, img_size, threads=None, budget_s=12.0, max_img=10):
                        f'{os.cpu_count()} host cpus ({nthr} torch threads)')
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-exec this command line under torch.distributed.run, one rank per GPU
+    (the environment tools/launch_8gpu.sh sets).  The ranks' stdout is inherited, so rank 0's ONE JSON line is this process's."""
+    import socket
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # the host driver only supports dmabuf IPC
+    env.setdefault('NCCL_MIN_NCHANNELS', '16')             # ring all-reduce over point-to-point xGMI is per-link bound
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
+    port = env.get('MASTER_PORT')
+    if not port:
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = str(s.getsockname()[1])
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', port, os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus != world:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch one rank per GPU, or run bare and let '
+                         f'bench.py spawn them)')
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', args.local_rank or 0))
     if not torch.cuda.is_available():

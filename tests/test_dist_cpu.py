@@ -129,3 +129,33 @@ def test_lr_schedule_matches_reference_formula():
         if step in C.lr_steps:
             lr = C.lr * 0.1 ** C.lr_steps.index(step)
         assert lr_at(C, step) == pytest.approx(lr), step
+
+
+def test_bench_spawns_one_rank_per_gpu_when_launched_bare(monkeypatch):
+    """`python bench.py --gpus N` without a launcher must become N ranks (the driver's scaling run may use either form):
+    the re-exec goes through torch.distributed.run on 127.0.0.1 with this command line's own arguments."""
+    import subprocess
+    import sys
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen['cmd'], seen['env'] = cmd, env
+        return 0
+    monkeypatch.setattr(subprocess, 'call', fake_call)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '7', '--warmup', '2'])
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.delenv('MASTER_PORT', raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen['cmd']
+    assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node=4' in cmd and '--nnodes=1' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and int(cmd[cmd.index('--master-port') + 1]) > 0
+    assert cmd[-6:] == ['--gpus', '4', '--steps', '7', '--warmup', '2'] and cmd[-7].endswith('bench.py')
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    # under a launcher (WORLD_SIZE set) a mismatching --gpus is an error, not a silent 1-rank run
+    monkeypatch.setenv('WORLD_SIZE', '2')
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert 'WORLD_SIZE=2' in str(e.value.code)

@@ -885,15 +885,17 @@ def test_gradient_buckets_are_reduced_while_backward_is_still_running():
 
 
 def test_bench_two_ranks_control_flow():
-    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one JSON line from rank 0, barrier + MAX over
-    ranks, whole-job img/s), with gloo so that both ranks can share this box's GPU: inference replicas + the 2-rank training leg."""
+    """Bare `python bench.py --gpus 2` (no launcher: bench.py spawns the two ranks itself; one JSON line from rank 0, barrier +
+    MAX over ranks, whole-job img/s), with gloo so that both ranks can share this box's GPU: inference replicas + the 2-rank
+    training leg.  The launcher form (`torch.distributed.run ... bench.py --gpus N`) is covered by the single-rank RCCL test."""
     import json
     import subprocess
     import sys
     from tests.conftest import REPO
     env = dict(os.environ, YM_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29547', os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--cfg',
+    # BARE command: bench.py itself re-execs under torch.distributed.run with one rank per GPU when WORLD_SIZE is unset
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
+    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--cfg',
            'res50_coco', '--img_size', '256', '--train-batch', '2', '--train-steps', '2']
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
