@@ -107,6 +107,9 @@ class WindowAttentionFn(torch.autograd.Function):
         qkv = qkv.contiguous()
         b, h, w, c3 = qkv.shape
         c = c3 // 3
+        # qkv.bias gets a second gradient from this node (the Linear's ConvBias is the other producer): autograd sums the two on
+        # the main stream, so neither may be written from train_engine's side stream (`_side_ok`)
+        qkv_bias._ym_multi_producer = True
         out = torch.empty(b, h, w, c, device=qkv.device, dtype=torch.float32)
         hip.swin_window_attention(qkv, qkv_bias.detach(), table.detach(), b, h, w, c, heads, window, shift, out)
         ctx.save_for_backward(qkv, qkv_bias, table)
@@ -137,6 +140,7 @@ def _w4(lin):
         w._ym_grad_slot = slot.view(lin.out_features, lin.in_features, 1, 1)
         w._ym_slot_free = True
         lin.weight._ym_slot_free = False
+    w._ym_owner = lin.weight                 # (side-stream bookkeeping lands on the parameter, not on this temporary view)
     return w
 
 

@@ -430,12 +430,30 @@ def _conv_dgrad(dz, weight, cout_pad, x_shape, stride, pad, add=None, out=None, 
 
 def _grad_slot(param, shape):
     """Gradient destination: the parameter's slice of the optimizer's flat gradient buffer when the trainer installed
-    one (`FlatSGD` sets `param._ym_grad_slot`), so autograd adopts the view and no gather copy is needed; else fresh."""
+    one (`FlatSGD` sets `param._ym_grad_slot`), so autograd adopts the view and no gather copy is needed; else fresh.
+    The slot view is tagged `_ym_is_slot`: only such a destination may be written from the side stream (nothing reads it before
+    the optimizer / the bucket all-reduce, which order themselves after that stream).  A fresh tensor is summed / cloned by
+    autograd on the main stream, so it is always produced there — and when it is a SECOND gradient of a parameter whose slot was
+    already handed out in this backward, the main stream first waits for the side stream (autograd is about to add the two)."""
     slot = getattr(param, '_ym_grad_slot', None) if param is not None else None
     if slot is not None and getattr(param, '_ym_slot_free', False):
         param._ym_slot_free = False           # a second use in the same step must accumulate into a fresh tensor
-        return slot.view_as(slot)             # a FRESH view: AccumulateGrad only adopts (instead of cloning) an unshared tensor
+        v = slot.view_as(slot)                # a FRESH view: AccumulateGrad only adopts (instead of cloning) an unshared tensor
+        v._ym_is_slot = True
+        return v
+    if slot is not None and getattr(getattr(param, '_ym_owner', param), '_ym_side_written', False):
+        join_wgrad_stream(param.device)
+        getattr(param, '_ym_owner', param)._ym_side_written = False
     return torch.empty(shape, device=param.device if param is not None else None, dtype=torch.float32)
+
+
+def _side_ok(param, *dsts):
+    """May a gradient of `param` be written into `dsts` from the side stream?  Only when every destination is the optimizer's
+    slot (see `_grad_slot`) and this autograd node is the parameter's only gradient producer (`_ym_multi_producer`: e.g. Swin's
+    qkv.bias also receives a gradient from the window-attention node — autograd sums the two on the main stream)."""
+    if not _side_active[0] or param is None or getattr(param, '_ym_multi_producer', False):
+        return False
+    return all(d is not None and d.is_cuda and getattr(d, '_ym_is_slot', False) for d in dsts)
 
 
 # ---- weight gradients on a side stream ---------------------------------------------------------------------------------------
@@ -514,7 +532,8 @@ def join_wgrad_stream(device):
         torch.cuda.current_stream(_dev_key(device)).wait_stream(e)
 
 
-def _conv_wgrad(x, dz, weight_shape, stride, pad, weight_param=None, dw=None, accumulate=False, segments=None):
+def _conv_wgrad(x, dz, weight_shape, stride, pad, weight_param=None, dw=None, accumulate=False, segments=None, owners=None):
+    """`owners`: the parameters a caller-owned `dw` (+ `segments` destinations) belong to (default: `weight_param`)."""
     if not _side_active[0] or not x.is_cuda:
         return _conv_wgrad_now(x, dz, weight_shape, stride, pad, weight_param, dw, accumulate, segments)
     cout, cin, kh, kw = weight_shape
@@ -522,12 +541,20 @@ def _conv_wgrad(x, dz, weight_shape, stride, pad, weight_param=None, dw=None, ac
     if dw is None:                                   # (allocated / adopted on the main stream, written on the side stream)
         dw = _grad_slot(weight_param, (cout, cin, kh, kw)) if weight_param is not None else \
             torch.empty(cout, cin, kh, kw, device=x.device, dtype=torch.float32)
+    owners = owners if owners is not None else (weight_param,)
+    dsts = (dw,) if segments is None else (dw, segments[2], segments[3])
+    if len(owners) != len(dsts) or not all(_side_ok(o, d) for o, d in zip(owners, dsts)):
+        # a fresh tensor (second use of a parameter in this step, a non-leaf weight, no flat optimizer): autograd reads it on the
+        # main stream right after this node returns -> produce it there
+        return _conv_wgrad_now(x, dz, weight_shape, stride, pad, weight_param, dw, accumulate, segments)
     side = wgrad_stream(x.device, ordered=shared_dst)
     side.wait_stream(torch.cuda.current_stream(x.device))          # x, dz (and earlier accumulations into dw) are ready
     with torch.cuda.stream(side):
         _conv_wgrad_now(x, dz, weight_shape, stride, pad, weight_param, dw, accumulate, segments)
     x.record_stream(side)                                          # the allocator must not recycle them under the side stream
     dz.record_stream(side)
+    for o in owners:
+        getattr(o, '_ym_owner', o)._ym_side_written = True
     return dw
 
 
@@ -603,8 +630,7 @@ class ConvBias(torch.autograd.Function):
             ws = scratch(dy.device, hip.lib().ym_bn_train_bwd_workspace_bytes(m, c))                  # partial-sum path
             hip.check(hip.lib().ym_act_bias_bwd(hip.ptr(dy), y_ptr, m, c, act, None, hip.ptr(dbias), ctypes.c_void_p(ws.data_ptr()),
                                                 ws.numel(), hip.stream_ptr()), 'ym_act_bias_bwd')
-        in_slot = dbias is not None and bias_param is not None and cout_pad == weight.shape[0]
-        if has_bias and in_slot and _side_active[0] and dy.is_cuda:
+        if has_bias and cout_pad == weight.shape[0] and _side_ok(bias_param, dbias):
             # like the weight gradient, the bias gradient is off the critical path: side stream (it lands in the optimizer's slot)
             side = wgrad_stream(dy.device)
             side.wait_stream(torch.cuda.current_stream(dy.device))
@@ -613,6 +639,7 @@ class ConvBias(torch.autograd.Function):
             dy.record_stream(side)
             if y is not None:
                 y.record_stream(side)
+            bias_param._ym_side_written = True
         elif has_bias:
             bias_grad()
         if act != ACT_NONE:
@@ -741,7 +768,8 @@ class PredictionHead(torch.autograd.Function):
             dz = dz_all[row_off[l]:row_off[l + 1]].view(bsz, h, w, pad)
             xh = xh_all[row_off[l]:row_off[l + 1]].view(bsz, h, w, 256)
             _conv_dgrad(dz, hw_.w, pad, (bsz, h, w, 256), 1, 1, out=dxh_all[row_off[l]:row_off[l + 1]].view(bsz, h, w, 256))
-            _conv_wgrad(xh, dz, tuple(hw_.w.shape), 1, 1, dw=dw[0], accumulate=l > 0, segments=(c_conf, c_conf + c_box, dw[1], dw[2]))
+            _conv_wgrad(xh, dz, tuple(hw_.w.shape), 1, 1, dw=dw[0], accumulate=l > 0, segments=(c_conf, c_conf + c_box, dw[1], dw[2]),
+                        owners=(w_conf, w_box, w_coef))
         # upfeature: ReLU backward + bias column sums for all levels at once, then per-level data / weight gradients
         dzu_all = torch.empty_like(dxh_all)
         db_up = _grad_slot(b_up, (256,))
@@ -754,7 +782,7 @@ class PredictionHead(torch.autograd.Function):
             h, w = shapes[l]
             dzu = dzu_all[row_off[l]:row_off[l + 1]].view(bsz, h, w, 256)
             dlevels.append(_conv_dgrad(dzu, w_up, 256, lv.shape, 1, 1) if ctx.needs_input_grad[12 + l] else None)
-            _conv_wgrad(lv, dzu, tuple(w_up.shape), 1, 1, dw=dw_up, accumulate=l > 0)
+            _conv_wgrad(lv, dzu, tuple(w_up.shape), 1, 1, dw=dw_up, accumulate=l > 0, owners=(w_up,))
         return (dw_up, db_up, dw[0], db[0], dw[1], db[1], dw[2], db[2], None, None, None, None, *dlevels)
 
 

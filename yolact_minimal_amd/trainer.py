@@ -102,6 +102,7 @@ class FlatSGD:
             p.grad = None
             p._ym_slot_free = True
             p._ym_in_slot = False
+            p._ym_side_written = False
 
     @staticmethod
     def gather(p):
@@ -112,6 +113,11 @@ class FlatSGD:
         if g is None:
             p._ym_grad_slot.zero_()
         elif g.data_ptr() != p._ym_grad_slot.data_ptr():
+            if getattr(p, '_ym_side_written', False):
+                # the slot was written from the side stream on the promise that autograd ADOPTS it unread; a sum / clone made on the
+                # main stream raced with that write (train_engine._grad_slot joins the streams for every case it knows about)
+                raise RuntimeError('a gradient written on the side stream was copied or summed by autograd on the main stream '
+                                   '(AccumulateGrad did not adopt the slot view): run with YM_WGRAD_STREAM=0')
             p._ym_grad_slot.copy_(g)
         p._ym_in_slot = True
 
