@@ -990,4 +990,6 @@ def test_side_stream_gradients_equal_single_stream(cfg_name, fused_head, monkeyp
             # (fp64 atomics of the BN statistics are order-dependent in the last bits: "equal" = to fp32 rounding, far below a
             # dropped or stale contribution, which is O(1) of the tensor)
             assert float((x - y).abs().max()) <= 1e-4 * scale + 1e-9, (step, tuple(p.shape), float((x - y).abs().max()), scale)
-    torch.testing.assert_close(ref.opt.flat, tst.opt.flat, rtol=1e-4, atol=1e-6)
+    # (AdamW normalises every element's update by its own running |g|: where |g| ~ 1e-9 the fp64-atomics noise of the statistics
+    # decides the update's size, a few 1e-6 after two steps; SGD's update is linear in g)
+    torch.testing.assert_close(ref.opt.flat, tst.opt.flat, rtol=1e-4, atol=2e-5 if cfg_name.startswith('swin') else 1e-6)

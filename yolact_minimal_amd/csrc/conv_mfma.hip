@@ -31,7 +31,9 @@ constexpr int PITCH = 36;  // floats
 
 // Phase stamps for tools/conv_trace.py (only in the -DYM_TRACE debug build: `make -C yolact_minimal_amd/csrc trace`).
 #ifdef YM_TRACE
-#define YM_STAMP(i) do { if ((i) == 3) __builtin_amdgcn_s_waitcnt(0); if (p.trace && threadIdx.x == 0) p.trace[(size_t)blockIdx.x * 4 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+// stamp 0 carries the XCC id (HW_REG_XCC_ID[3:0]) in bits 60..63: every XCD has its own counter base, and in a chain of launches
+// block b is NOT always on XCD b % 8
+#define YM_STAMP(i) do { if ((i) == 3) __builtin_amdgcn_s_waitcnt(0); if (p.trace && threadIdx.x == 0) p.trace[(size_t)blockIdx.x * 4 + (i)] = (long long)__builtin_amdgcn_s_memtime() | ((i) == 0 ? (long long)(__builtin_amdgcn_s_getreg(0x1814) & 15) << 60 : 0ll); } while (0)
 #else
 #define YM_STAMP(i) do { } while (0)
 #endif
@@ -597,7 +599,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
                 if (s_last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
             }
             __syncthreads();
-            if (!s_last) return;
+            if (!s_last) { YM_STAMP(3); return; }
         }
         if (n < p.Cout) {
             f32x4 sc = pre_sc, sh = pre_sh;

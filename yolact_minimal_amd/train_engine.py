@@ -530,6 +530,27 @@ def join_wgrad_stream(device):
         torch.cuda.current_stream(_dev_key(device)).wait_stream(s)
     for e in _extra_streams.get(_dev_key(device), ()):
         torch.cuda.current_stream(_dev_key(device)).wait_stream(e)
+    _side_keep.pop(_dev_key(device), None)         # everything the side streams read is ordered before the main stream from here on
+
+
+# Operands of a side-stream launch (x, dz, y) are OWNED by the main stream's autograd pass, which may
+#   (a) free them as soon as the node returns -> the caching allocator would hand the block to the next main-stream kernel, and
+#   (b) ACCUMULATE IN PLACE into a tensor it holds the only reference to (InputBuffer: `old += new` when use_count == 1) -- e.g. the
+#       `dz` a residual conv returns as the gradient of its residual input, which autograd then sums with the other branch's;
+# both while a lagging side stream has not read them yet.  Holding a reference until the side stream has passed the launch covers
+# both (a block in use is not recycled; use_count > 1 forces the out-of-place sum) without `record_stream`, whose deferred frees
+# had inflated the allocator's reservation from 8 to 30 GiB.  Entries are dropped as soon as their event has completed.
+_side_keep = {}
+
+
+def _keep_for_side(device, side, *tensors):
+    import collections
+    q = _side_keep.setdefault(_dev_key(device), collections.deque())
+    ev = torch.cuda.Event()
+    ev.record(side)
+    q.append((ev, tensors))
+    while len(q) > 1 and q[0][0].query():
+        q.popleft()
 
 
 def _conv_wgrad(x, dz, weight_shape, stride, pad, weight_param=None, dw=None, accumulate=False, segments=None, owners=None):
@@ -551,8 +572,7 @@ def _conv_wgrad(x, dz, weight_shape, stride, pad, weight_param=None, dw=None, ac
     side.wait_stream(torch.cuda.current_stream(x.device))          # x, dz (and earlier accumulations into dw) are ready
     with torch.cuda.stream(side):
         _conv_wgrad_now(x, dz, weight_shape, stride, pad, weight_param, dw, accumulate, segments)
-    x.record_stream(side)                                          # the allocator must not recycle them under the side stream
-    dz.record_stream(side)
+    _keep_for_side(x.device, side, x, dz)                          # neither recycled nor summed into in place until the side stream is past
     for o in owners:
         getattr(o, '_ym_owner', o)._ym_side_written = True
     return dw
@@ -636,9 +656,7 @@ class ConvBias(torch.autograd.Function):
             side.wait_stream(torch.cuda.current_stream(dy.device))
             with torch.cuda.stream(side):
                 bias_grad()
-            dy.record_stream(side)
-            if y is not None:
-                y.record_stream(side)
+            _keep_for_side(dy.device, side, dy, y)
             bias_param._ym_side_written = True
         elif has_bias:
             bias_grad()
