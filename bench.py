@@ -10,6 +10,14 @@ Image size is 544 (the reference cannot run at 550: SURVEY.md §0.1).  Weights: 
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--cfg res101_coco] [--batch 1]
 
+`--inflight S` (default 2 at bs=1): S independent bs=1 requests are in flight on S HIP streams (S engines with their own activations,
+split-K scratch and hipGraphs).  A bs=1 forward is a chain of ~190 dependent launches, each ~9 us of launch boundary + address
+set-up + epilogue around ~7 us of MFMA work, so ONE chain keeps the matrix pipe ~35 % busy; the second request's kernels run in
+those holes (348 -> 490 img/s forward-only on one MI355X).  Every step is still one image through forward + nms + after_nms with
+one host read of its detection count (read when the slot is reused, i.e. S steps later, so the host never waits on the request it
+just enqueued).  `--inflight 1` is the single-request latency mode of rounds 1-2; its numbers stay in the line under
+`roofline.single_request`.
+
 N > 1 (launched by torch.distributed.run, one rank per GPU): inference does not shard — images are
 independent — so every rank runs an independent replica on its own batch ("replicas only", no data-path
 collective); the timed region is bracketed by barrier + synchronize and the MAX over ranks is reported.
@@ -39,6 +47,7 @@ def parse():
     ap.add_argument('--cfg', default='res101_coco')
     ap.add_argument('--batch', type=int, default=1, help='images per GPU per step')
     ap.add_argument('--img_size', type=int, default=544)
+    ap.add_argument('--inflight', type=int, default=0, help='bs=1 requests in flight on separate streams (0 = 2 at --batch 1, else 1)')
     ap.add_argument('--no-post', action='store_true', help='time the network forward only')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the bs=8 side measurements')
@@ -61,10 +70,12 @@ def build_net(cfg_name, img_size, device, seed=0):
 
 
 class Workload:
-    """forward(batch) + per-image post-processing, everything resident on the device."""
+    """forward(batch) + per-image post-processing, everything resident on the device.  `inflight` > 1 (batch 1 only): that many
+    requests overlap, each on its own stream with its own engine; see the module docstring."""
 
-    def __init__(self, net, cfg, batch, img_size, device, with_post=True, seed=0):
+    def __init__(self, net, cfg, batch, img_size, device, with_post=True, seed=0, inflight=1):
         from yolact_minimal_amd.utils.synthetic import synth_head_outputs
+        from yolact_minimal_amd.engine import InferEngine
         self.net, self.cfg, self.batch, self.device = net, cfg, batch, device
         g = torch.Generator().manual_seed(seed)
         self.img = torch.randn(batch, 3, img_size, img_size, generator=g).to(device)
@@ -77,9 +88,48 @@ class Workload:
         self.head_b = [t.expand(batch, *t.shape[1:]).contiguous() for t in self.head] if batch > 1 else None
         self.anchors = torch.tensor(net.anchors, dtype=torch.float32).reshape(-1, 4).to(device)
         self.engine = net._engine(self.img)
+        self.inflight = inflight if batch == 1 else 1
+        if self.inflight > 1:
+            self.engines = [self.engine] + [InferEngine(net, batch, img_size, img_size, device) for _ in range(self.inflight - 1)]
+            self.streams = [torch.cuda.Stream(device=device) for _ in range(self.inflight)]
+            self.pending = [None] * self.inflight
+            self.i = 0
+            self.detections = 0
+            torch.cuda.synchronize()
+            for e, st in zip(self.engines, self.streams):          # graph capture / first run outside the timed region
+                with torch.cuda.stream(st):
+                    e.run(self.img)
+            torch.cuda.synchronize()
+
+    def _finish(self, slot):
+        """The ONE host read of a request (its detection count, as `after_nms` needs it to size what it returns); the request was
+        enqueued `inflight` steps ago, so this rarely waits."""
+        pend = self.pending[slot]
+        if pend is None:
+            return
+        self.pending[slot] = None
+        ids, scores, box_px, masks, counts = pend
+        with torch.cuda.stream(self.streams[slot]):
+            n = int(counts.tolist()[0])
+        self.detections += n
+        return ids[0, :n], scores[0, :n], box_px[0, :n], masks[0, :n]
+
+    def flush(self):
+        if self.inflight > 1:
+            for slot in range(self.inflight):
+                self._finish(slot)
 
     def step(self):
         from yolact_minimal_amd.utils.output_utils import nms, after_nms, nms_batch, after_nms_batch
+        if self.inflight > 1:
+            slot = self.i % self.inflight
+            self.i += 1
+            self._finish(slot)
+            with torch.cuda.stream(self.streams[slot]):
+                self.engines[slot].run(self.img)
+                if self.with_post:
+                    self.pending[slot] = after_nms_batch(nms_batch(*self.head, self.anchors, self.cfg), 480, 640, self.cfg, sync=False)
+            return
         self.engine.run(self.img)
         if self.with_post:
             if self.batch > 1:
@@ -93,11 +143,13 @@ class Workload:
 def timed(workload, steps, warmup, barrier):
     for _ in range(warmup):
         workload.step()
+    workload.flush()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         workload.step()
+    workload.flush()                 # (requests in flight: the host reads of the last ones)
     torch.cuda.synchronize()
     barrier()
     return time.perf_counter() - t0
@@ -408,7 +460,10 @@ def main():
             dist.barrier()
 
     net, cfg = build_net(args.cfg, args.img_size, device)
-    wl = Workload(net, cfg, args.batch, args.img_size, device, with_post=not args.no_post)
+    inflight = args.inflight if args.inflight > 0 else (2 if args.batch == 1 else 1)
+    if args.batch != 1:
+        inflight = 1
+    wl = Workload(net, cfg, args.batch, args.img_size, device, with_post=not args.no_post, inflight=inflight)
     elapsed = timed(wl, args.steps, args.warmup, barrier)
     if dist is not None:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -439,7 +494,15 @@ def main():
     if rank == 0:
         # forward-only rate on the same engine, and the live conv roofline
         fw = Workload(net, cfg, args.batch, args.img_size, device, with_post=False)
-        t_fwd = timed(fw, args.steps, 2, lambda: None) / args.steps
+        t_fwd = timed(fw, args.steps, 2, lambda: None) / args.steps           # ONE request at a time (graph replay)
+        t_fwd_multi, single = t_fwd, None
+        if inflight > 1:
+            fwm = Workload(net, cfg, args.batch, args.img_size, device, with_post=False, inflight=inflight)
+            t_fwd_multi = timed(fwm, 4 * args.steps, 4, lambda: None) / (4 * args.steps)      # seconds per image, requests overlapped
+            del fwm
+            one = Workload(net, cfg, args.batch, args.img_size, device, with_post=not args.no_post, inflight=1)
+            t_one = timed(one, args.steps, 5, lambda: None) / args.steps
+            del one
         flops, conv_secs, launches, layers = conv_roofline(fw.engine, fw.img)
         achieved = flops / conv_secs / 1e12
         traffic, traffic_src = None, None
@@ -453,15 +516,27 @@ def main():
         # kernels — layout, max-pool, 3 upsamples, softmax: ~2 % — are left in the denominator, so this is a lower bound that agrees
         # with the rocprofv3 kernel trace under profiles/).  The eager per-launch HIP-event figure is kept beside it.
         achieved_graph = flops / t_fwd / 1e12
-        roofline = dict(bound='mfma', achieved=round(achieved_graph, 2), peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-                        frac=round(achieved_graph / F32_MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
-                        kernel='conv_igemm_f32 (all instantiations)', launches_per_step=launches,
-                        flops_per_launch=round(flops / launches), avg_launch_us=round(t_fwd / launches * 1e6, 2),
-                        forward_graph_ms=round(t_fwd * 1e3, 3), eager_event_conv_ms=round(conv_secs * 1e3, 3),
-                        eager_event_frac=round(achieved / F32_MFMA_PEAK_TFLOPS, 4))
-        extra = dict(forward_only_ms=round(t_fwd * 1e3, 3),
-                     forward_only_img_s=round(args.batch / t_fwd, 1),
-                     forward_tflops=round(flops / t_fwd / 1e12, 2),
+        single = dict(achieved=round(achieved_graph, 2), frac=round(achieved_graph / F32_MFMA_PEAK_TFLOPS, 4),
+                      avg_launch_us=round(t_fwd / launches * 1e6, 2), forward_graph_ms=round(t_fwd * 1e3, 3),
+                      eager_event_conv_ms=round(conv_secs * 1e3, 3), eager_event_frac=round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+                      note='one request at a time: the per-launch figure (algorithmic flops of a conv launch / its duration in the dependent chain)')
+        if inflight > 1:
+            single['img_s_with_post'] = round(args.batch / t_one, 2)
+        # with `inflight` requests overlapped the conv launches of different requests share the chip, so a launch's own duration no
+        # longer measures anything; `achieved` is then the conv kernels' algorithmic flops of the timed forwards / their wall time
+        achieved_multi = flops / t_fwd_multi / 1e12
+        roofline = dict(bound='mfma', achieved=round(achieved_multi, 2), peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+                        frac=round(achieved_multi / F32_MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
+                        kernel='conv_igemm_f32 / conv_igemm_pers (all instantiations)', launches_per_step=launches,
+                        flops_per_launch=round(flops / launches), avg_launch_us=round(t_fwd_multi / launches * 1e6, 2),
+                        forward_graph_ms=round(t_fwd_multi * 1e3, 3), requests_in_flight=inflight,
+                        definition=('algorithmic conv flops per forward / wall time per forward with requests_in_flight forwards '
+                                    'overlapped on as many streams' if inflight > 1 else
+                                    'algorithmic conv flops per forward / graph-replay forward time'),
+                        single_request=single)
+        extra = dict(forward_only_ms=round(t_fwd_multi * 1e3, 3),
+                     forward_only_img_s=round(args.batch / t_fwd_multi, 1),
+                     forward_tflops=round(flops / t_fwd_multi / 1e12, 2),
                      gflop_per_img=round(flops / args.batch / 1e9, 1))
         slow = sorted(layers, key=lambda l: -l['ms'])[:5]
         extra['slowest_convs'] = [dict(name=l['name'], ms=round(l['ms'], 4), tflops=round(l['gflop'] / l['ms'], 1)) for l in slow]
@@ -542,10 +617,12 @@ def main():
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'{args.cfg} 544x544 (the reference\'s "550-class" size) bs={args.batch} inference: '
                                    f'forward + nms + after_nms(480x640) per image'
+                                   + (f', {inflight} independent bs=1 requests in flight on {inflight} HIP streams' if inflight > 1 else '')
                                    if not args.no_post else
                                    f'{args.cfg} 544x544 bs={args.batch} forward only',
                        'global_batch': args.batch * world, 'parallelism': f'replicas x{world} (inference does not shard)',
-                       'weights': 'seeded random init', 'post_inputs': 'synthetic dense head outputs (17.8k candidates)'},
+                       'weights': 'seeded random init', 'post_inputs': 'synthetic dense head outputs (17.8k candidates)',
+                       'requests_in_flight': inflight},
             'roofline': roofline, 'cpu_baseline': cpu, 'extra': extra,
         }
     barrier()

@@ -83,7 +83,10 @@ typedef struct {
                                 `weight` comes from ym_pack_conv_weight_dgrad.  Autograd counterpart of every
                                 nn.Conv2d on the path (loss_total.backward(), reference train.py:126). */
     int32_t stages;          /* workgroup kernel operand staging: 0/2 = registers, double buffer; 3 = registers, loads two K tiles
-                                ahead (64-wide tiles); 22/23/24 = direct global->LDS DMA, ring of 2/3/4 (24: 64x64 tile only) */
+                                ahead (64-wide tiles); 22/23/24 = direct global->LDS DMA, ring of 2/3/4 (24: 64x64 tile only);
+                                42/43/44/46/48 = PERSISTENT direct-to-LDS kernel, ring of 2/3/4/6/8 (64x64 tile, plain NHWC
+                                output, ReLU or no activation; anything else falls back to 22/23/24): grid_wgs workgroups walk
+                                the (tile, K slice) items and the operand stream runs on across item boundaries */
     double* bn_sum;          /* optional [Cout] fp64 accumulators (zeroed by the caller): the epilogue adds the */
     double* bn_sumsq;        /* per-channel sum / sum of squares of the conv OUTPUT (train-mode BN statistics).  */
                              /* Only when ym_conv2d_fuses_bn_stats(desc) == 1 (plain NHWC output).               */
@@ -114,6 +117,8 @@ typedef struct {
     const float* bnb_gamma;  /* bnb_out = its saved output, or (bnb_out == NULL) xhat * gamma + beta > 0 re-derived exactly as the     */
     const float* bnb_beta;   /* forward pass computed it.  Same sums as the first pass of ym_bn_train_bwd, which                       */
                              /* ym_bn_train_bwd_apply then skips.  Needs ym_conv2d_fuses_bn_stats(desc) == 1.                          */
+    int32_t grid_wgs;        /* persistent kernel (stages 4x): workgroups to launch; 0 = as many as the CUs hold (LDS-limited, at most  */
+                             /* 4 per CU), never more than there are work items                                                          */
 } ym_conv_desc;
 
 /* y = act(conv(x, w) * scale + shift + residual), one launch (plus a reduce launch if K is split).

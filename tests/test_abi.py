@@ -35,7 +35,7 @@ def test_struct_layout_matches_c():
     """ctypes mirrors of ym_conv_desc / ym_conv_seg / ym_nms_cfg have the C sizes (x86-64 SysV)."""
     from yolact_minimal_amd import hip
     assert ctypes.sizeof(hip.ConvSeg) == 32
-    assert ctypes.sizeof(hip.ConvDesc) == 40 + 13 * 4 + 4 + 3 * 32 + 6 * 4 + 16 + 8 + 44 + 8 + 4 + 4 + 4 + 6 * 8   # (... mma, bnb_relu, padding, 6 bnb_* pointers)
+    assert ctypes.sizeof(hip.ConvDesc) == 40 + 13 * 4 + 4 + 3 * 32 + 6 * 4 + 16 + 8 + 44 + 8 + 4 + 4 + 4 + 6 * 8 + 8   # (... mma, bnb_relu, padding, 6 bnb_* pointers, grid_wgs + padding)
     assert hip.lib().ym_sizeof_conv_desc() == ctypes.sizeof(hip.ConvDesc)
     assert ctypes.sizeof(hip.WgradDesc) == 24 + 14 * 4 + 4 + 8 + 4 + 16 + 8   # + accumulate, row_end[2], padding, dw_seg[2], lds_buffers (+pad)
     assert ctypes.sizeof(hip.NmsCfg) == 32

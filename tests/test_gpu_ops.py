@@ -13,7 +13,7 @@ def _dev():
 
 
 def run_conv(x_nchw, w, scale=None, shift=None, residual=None, stride=1, pad=0, act=0, tile=(0, 0), ksplit=0, kwaves=0, stages=0,
-             counters=None, repeat=1, tail=(0, 0)):
+             counters=None, repeat=1, tail=(0, 0), grid_wgs=0):
     """Runs ym_conv2d_fwd on NHWC data; returns NCHW cpu tensor."""
     from yolact_minimal_amd import hip
     dev = _dev()
@@ -50,6 +50,7 @@ def run_conv(x_nchw, w, scale=None, shift=None, residual=None, stride=1, pad=0, 
     if counters is not None:
         d.tile_counters = counters.data_ptr()
     d.tail_tiles, d.tail_ksplit = tail
+    d.grid_wgs = grid_wgs
     nbytes = hip.conv_workspace_bytes(d)
     ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
     for _ in range(repeat):
@@ -222,6 +223,46 @@ def test_conv_direct_to_lds_parity(case):
     torch.testing.assert_close(base, ref_conv(x, wt, scale, shift, res, stride, pad, act), rtol=1e-4, atol=1e-5)
 
 
+PERS_CASES = [
+    # b, cin, h, w, cout, k, stride, pad, act, residual, ksplit, tail, grid_wgs (0 = library choice)
+    (1, 256, 34, 34, 1024, 1, 1, 0, 1, True, 1, (48, 2), 0),      # layer3 conv3 at bs=1 as tuned: tail split, ~1 item per workgroup
+    (1, 1024, 34, 34, 256, 1, 1, 0, 1, False, 3, (0, 0), 0),      # layer3 conv1 at bs=1: K split 3, fused finish
+    (1, 256, 34, 34, 256, 3, 1, 1, 1, False, 6, (0, 0), 64),      # 3x3 (padding taps, tap changes inside an item), 7 items per workgroup
+    (2, 256, 34, 34, 1024, 1, 1, 0, 1, True, 1, (0, 0), 40),      # 592 tiles on 40 workgroups: the operand stream crosses 14 item boundaries
+    (2, 128, 19, 19, 128, 3, 2, 1, 0, False, 1, (0, 0), 8),       # stride 2, no activation, ragged M (last tile 41 rows)
+    (1, 256, 9, 9, 96, 3, 1, 1, 1, False, 2, (0, 0), 8),          # ragged N (96 = 64 + 32), K split, 1 K tile items inside a ring of 8
+    (1, 64, 12, 12, 64, 1, 1, 0, 1, True, 2, (0, 0), 8),          # items of ONE K tile: the loader runs several items ahead of the MFMAs
+    (3, 512, 17, 17, 2048, 1, 1, 0, 1, True, 1, (30, 4), 0),      # layer4 conv3, tail of 30 tiles x 4 slices
+]
+
+
+@pytest.mark.parametrize('case', PERS_CASES)
+def test_conv_persistent_kernel_parity(case):
+    """stages 42 / 43 / 44 / 46 / 48 (csrc/conv_persist.hip): `grid_wgs` persistent workgroups walk the (tile, K slice) items with
+    ONE direct-to-LDS ring whose loader runs on across item boundaries.  Same work items, same MFMA order, same slice-sum order
+    and the same epilogue arithmetic as the per-item kernel (stages 22) -> BIT-IDENTICAL output for every ring depth and every
+    grid size (1 ... many items per workgroup), and within 1e-4 of an fp64 convolution."""
+    from yolact_minimal_amd import hip
+    b, cin, h, w, cout, k, stride, pad, act, use_res, ksplit, tail, grid = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    res = torch.randn(b, cout, ho, wo, generator=g) if use_res else None
+    counters = torch.zeros(hip.TILE_COUNTERS, device=_dev(), dtype=torch.int32)
+    base = run_conv(x, wt, scale, shift, res, stride, pad, act, (64, 64), ksplit, 0, 22, counters=counters, tail=tail)
+    for stages in (42, 43, 44, 46, 48):
+        for gw in sorted({grid, 8 if grid else 0}):
+            got = run_conv(x, wt, scale, shift, res, stride, pad, act, (64, 64), ksplit, 0, stages, counters=counters, tail=tail,
+                           grid_wgs=gw, repeat=2)
+            assert not torch.isnan(got).any(), (stages, gw)
+            assert torch.equal(got, base), (stages, gw, float((got - base).abs().max()))
+    assert int(counters.abs().sum()) == 0
+    torch.testing.assert_close(base, ref_conv(x, wt, scale, shift, res, stride, pad, act), rtol=1e-4, atol=1e-5)
+
+
 WAVE_CASES = [
     # b, cin, h, w, cout, k, stride, pad, act, residual, wave tile, kwaves
     (1, 64, 17, 17, 64, 1, 1, 0, 1, False, (32, 32), 1),
@@ -367,7 +408,9 @@ def test_val_aug_preprocess(h, w, dtype):
 
 @pytest.mark.parametrize('tile,ksplit,stages,tail', [((64, 64), 1, 22, (50, 2)), ((64, 64), 1, 22, (0, 0)), ((64, 64), 4, 22, (0, 0)),
                                                      ((64, 64), 3, 0, (0, 0)), ((128, 64), 1, 23, (37, 3)), ((64, 64), 1, 34, (0, 0)),
-                                                     ((128, 128), 1, 103, (0, 0)), ((64, 64), 1, 103, (50, 2)), ((64, 64), 3, 103, (0, 0)), ((128, 64), 1, 106, (0, 0))])
+                                                     ((128, 128), 1, 103, (0, 0)), ((64, 64), 1, 103, (50, 2)), ((64, 64), 3, 103, (0, 0)), ((128, 64), 1, 106, (0, 0)),
+                                                     # the persistent kernel (conv_persist.hip): ring of 3 / 4 / 8, ~3.4 items per workgroup, K-slice exchange, tail
+                                                     ((64, 64), 1, 43, (0, 0)), ((64, 64), 1, 44, (50, 2)), ((64, 64), 3, 43, (0, 0)), ((64, 64), 1, 48, (0, 0)), ((64, 64), 2, 42, (0, 0))])
 def test_conv_launches_are_race_free(tile, ksplit, stages, tail):
     """400 back-to-back launches of a chip-filling shape (2610 tiles: the Swin-T bs=8 qkv conv, M9248_N1152_C384) must all be
     bit-identical, and equal to the plain launch of the same tile up to the association of the K sum.  Regression test for two
@@ -399,6 +442,8 @@ def test_conv_launches_are_race_free(tile, ksplit, stages, tail):
     if stages >= 100:                               # 103 / 106: split-bf16 x3 / x6 (register staging)
         d.mma, d.stages = stages - 100, 0
     d.tail_tiles, d.tail_ksplit = tail
+    if 42 <= stages <= 48:
+        d.grid_wgs = 768                            # 2610+ items on 768 persistent workgroups
     assert hip.conv_workspace_bytes(d) <= ws.numel()
     hip.conv2d_fwd(d, ws)
     first = out.clone()

@@ -126,3 +126,39 @@ def test_train_aug_matches_oracle_chain(seed, h, w, n, size):
             np.testing.assert_allclose(got[1].cpu().numpy(), want_masks, rtol=0, atol=1e-5)
     if seed == 43:
         assert _U8_SQUARE_SEEN, 'no parametrised case exercised the uint8 / square-crop branch'
+
+
+def test_requests_in_flight_give_the_single_request_results():
+    """bench.py's bs=1 serving mode (`--inflight 2`): two independent requests overlap on two HIP streams, each with its own
+    engine (activations, split-K scratch, arrival counters, hipGraph) and its own post-processing scratch.  Every request must
+    return exactly what the one-at-a-time path returns: the forward outputs bit for bit, and ids / scores / pixel boxes / masks
+    of `nms` + `after_nms`."""
+    import bench
+    from yolact_minimal_amd.utils.output_utils import nms, after_nms
+    dev = torch.device(DEV)
+    net, cfg = bench.build_net('res50_coco', 256, dev)
+    one = bench.Workload(net, cfg, 1, 256, dev, with_post=True, inflight=1)
+    one.engine.run(one.img)
+    torch.cuda.synchronize()
+    want_fwd = [t.clone() for t in one.engine.outputs()]
+    cls, box, coef, proto = one.head
+    r = nms(cls, box, coef, proto, one.anchors, cfg)
+    want = after_nms(r[0], r[1], r[2].clone(), r[3], r[4], 480, 640, cfg)
+    two = bench.Workload(net, cfg, 1, 256, dev, with_post=True, inflight=2)
+    for it in range(7):
+        slot = two.i % 2
+        got = two._finish(slot) if two.pending[slot] is not None else None
+        two.step()                   # (finishes the slot itself when something is pending: call _finish first to keep the result)
+        if got is not None:
+            for a, b in zip(got, want):
+                assert torch.equal(a, b), it
+    for slot in range(2):
+        got = two._finish(slot)
+        assert got is not None
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+    torch.cuda.synchronize()
+    for e in two.engines:
+        for a, b in zip(e.outputs(), want_fwd):
+            assert torch.equal(a, b)
+    assert two.detections == 7 * int(want[0].shape[0])          # 7 requests were issued, each read back once

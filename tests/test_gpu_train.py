@@ -107,12 +107,20 @@ def test_conv_bn_fn_grads(cin, cout, k, stride, hw, relu, res):
         torch.testing.assert_close(_nchw(rg.grad).cpu(), rc.grad, rtol=1e-4, atol=1e-5)
 
 
-def test_bn_backward_sums_ride_on_the_consumers_dgrad():
-    """Two identity Bottlenecks (modules/resnet.py:20-40) in train mode: with BnGradLink the backward sums of bn1, bn2 and of the
+@pytest.mark.parametrize('force_stages,force_grid', [(None, None), ('43', '8'), ('46', '0')])
+def test_bn_backward_sums_ride_on_the_consumers_dgrad(force_stages, force_grid, monkeypatch):
+    """(Parametrised over the conv kernel: the tuned per-item kernels, and the persistent kernel of conv_persist.hip forced for
+    every conv -- its STATS instantiation carries the forward BatchNorm sums and the backward sums of the data gradient -- with 8
+    workgroups walking all items / the library's grid.)
+    Two identity Bottlenecks (modules/resnet.py:20-40) in train mode: with BnGradLink the backward sums of bn1, bn2 and of the
     first block's bn3 are accumulated by the epilogue of the data-gradient conv that writes their `dout`; the gradients must be
     those of the two-pass BN backward (same terms, fp64 sums in a different order) and of torch's CPU autograd."""
     import torch.nn as nn
     from yolact_minimal_amd import train_engine as T
+    if force_stages:
+        monkeypatch.setenv('YM_FORCE_STAGES', force_stages)
+        monkeypatch.setenv('YM_FORCE_GRID', force_grid)
+    T.tuned_table_changed()
 
     class Block(nn.Module):
         def __init__(self, c, p):
@@ -166,6 +174,8 @@ def test_bn_backward_sums_ride_on_the_consumers_dgrad():
         assert float((results[True][0][n] - ref[n]).norm() / ref[n].norm()) < 2e-4, n        # torch CPU autograd, per tensor
     torch.testing.assert_close(results[True][1], results[False][1], rtol=2e-5, atol=2e-6)
     assert float((results[True][1] - ref_dx).norm() / ref_dx.norm()) < 2e-4
+    monkeypatch.undo()
+    T.tuned_table_changed()
 
 
 @pytest.mark.parametrize('cin,cout,k,stride,hw,b,msplit', [(128, 256, 1, 1, 34, 4, 7), (64, 128, 3, 1, 23, 3, 5), (128, 160, 3, 2, 30, 2, 3),
@@ -827,18 +837,25 @@ def test_conv_dgrad_staging_variants_agree(cin, cout, k, stride, hw, b):
     outs = {}
     try:
         for name, cfg_ in (('reg2', [64, 64, 1, 0, 2, 0, 0]), ('reg3', [64, 64, 1, 0, 3, 0, 0]), ('dl2', [64, 64, 1, 0, 22, 0, 0]),
-                           ('dl3', [64, 64, 1, 0, 23, 0, 0]), ('dl2_128', [128, 128, 1, 0, 22, 0, 0]), ('dl2_ks3', [64, 64, 3, 0, 22, 0, 0])):
+                           ('dl3', [64, 64, 1, 0, 23, 0, 0]), ('dl2_128', [128, 128, 1, 0, 22, 0, 0]), ('dl2_ks3', [64, 64, 3, 0, 22, 0, 0]),
+                           # the persistent kernel (conv_persist.hip, MODE 2): ring of 3 / 4 / 8; 8 workgroups walk all the items
+                           ('pers3', [64, 64, 1, 0, 43, 0, 0, 8]), ('pers4', [64, 64, 1, 0, 44, 0, 0, 0]), ('pers8', [64, 64, 1, 0, 48, 0, 0, 16]),
+                           ('pers3_ks3', [64, 64, 3, 0, 43, 0, 0, 8])):
             table[key] = cfg_
+            T.tuned_table_changed()          # (launch descriptors are cached per shape with the table entry of their first use)
             outs[name] = T._conv_dgrad(dz.to(DEV), w.to(DEV), cout_pad, (b, hw, hw, cin), stride, pad).cpu()
     finally:
         if saved is None:
             table.pop(key, None)
         else:
             table[key] = saved
+        T.tuned_table_changed()
     want = xr.grad.permute(0, 2, 3, 1)
     for name, o in outs.items():
         torch.testing.assert_close(o.double(), want, rtol=1e-4, atol=1e-5, msg=lambda m, name=name: f'{name}: {m}')
     assert torch.equal(outs['reg2'], outs['dl2']) and torch.equal(outs['reg2'], outs['reg3']) and torch.equal(outs['reg2'], outs['dl3'])
+    assert torch.equal(outs['reg2'], outs['pers3']) and torch.equal(outs['reg2'], outs['pers4']) and torch.equal(outs['reg2'], outs['pers8'])
+    assert torch.equal(outs['dl2_ks3'], outs['pers3_ks3'])
 
 
 @pytest.mark.parametrize('cfg_name', ['res50_coco', 'swin_tiny_coco'])

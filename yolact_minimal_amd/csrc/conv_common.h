@@ -20,6 +20,23 @@ struct FastDiv {
     __device__ __forceinline__ void divmod(unsigned x, unsigned& q, unsigned& r) const { q = div(x); r = x - q * d; }
 };
 
+// Branch-free operand fetch: raw buffer loads return 0 for offsets beyond the descriptor's range, so padding taps,
+// rows past M / Cout and the K tail need no control flow (and hipcc can keep COUNTED vmcnt waits across the K loop —
+// with `if (ok) load` it drained vmcnt(0) before every LDS write, defeating any prefetch depth > 1).
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0xFFFFFFF0u;
+__device__ __forceinline__ f32x4 buf_ld16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+// agent-scope (sc1) accesses: coherent across the 8 XCD L2s without cache maintenance (aux bit 4 = sc1 on gfx94x/gfx950)
+constexpr int AUX_SC1 = 16;
+__device__ __forceinline__ f32x4 buf_ld16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, AUX_SC1));
+}
+__device__ __forceinline__ void buf_st16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), r, (int)byte_off, 0, AUX_SC1);
+}
+
 struct SegDev {
     float* out;
     long long bstride;
@@ -54,6 +71,7 @@ struct ConvP {
     FastDiv fd_tiles_m;
     long long* trace;  // debug builds (-DYM_TRACE, tools/conv_trace.py): per-workgroup s_memtime stamps [grid][4]
     unsigned in_bytes, w_bytes, ws_bytes;   // sizes of `in` / `w` for the raw-buffer descriptors (out-of-range reads return 0)
+    int total_items;   // persistent kernel (conv_persist.hip): (tile, K slice) work items = main_blocks + tail tiles * tail_split
     int nseg;
     int vec;   // 1: single segment, plain NHWC [M][Cout], Cout % 4 == 0, 16-byte aligned -> vectorised epilogue
     SegDev seg[3];
@@ -95,3 +113,7 @@ __device__ __forceinline__ void epilogue_store(const ConvP& p, int m, int n, flo
 
 // conv_wave.hip: wave-private kernel; returns YM_OK / YM_EINVAL (unsupported variant)
 int ym_launch_conv_wave(const ymk::ConvP& p, int tm, int tn, int kwaves, hipStream_t st);
+// conv_persist.hip: persistent direct-to-LDS kernel (ring of `ns` K tiles, `grid` workgroups walk p.total_items work items);
+// mode 0 = convolution, 2 = data gradient; stats = the launch fuses BatchNorm sums (bn_sum / bnb_*).  YM_EINVAL: no such variant.
+int ym_launch_conv_pers(const ymk::ConvP& p, int bm, int bn, int mode, int ns, bool stats, int grid, hipStream_t st);
+size_t ym_conv_pers_lds_bytes(int bm, int bn, int ns);

@@ -38,23 +38,6 @@ constexpr int PITCH = 36;  // floats
 #define YM_STAMP(i) do { } while (0)
 #endif
 
-// Branch-free operand fetch: raw buffer loads return 0 for offsets beyond the descriptor's range, so padding taps,
-// rows past M / Cout and the K tail need no control flow (and hipcc can keep COUNTED vmcnt waits across the K loop —
-// with `if (ok) load` it drained vmcnt(0) before every LDS write, defeating any prefetch depth > 1).
-typedef int i32x4_t __attribute__((ext_vector_type(4)));
-constexpr unsigned OOB = 0xFFFFFFF0u;
-__device__ __forceinline__ f32x4 buf_ld16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
-}
-// agent-scope (sc1) accesses: coherent across the 8 XCD L2s without cache maintenance (aux bit 4 = sc1 on gfx94x/gfx950)
-constexpr int AUX_SC1 = 16;
-__device__ __forceinline__ f32x4 buf_ld16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, AUX_SC1));
-}
-__device__ __forceinline__ void buf_st16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), r, (int)byte_off, 0, AUX_SC1);
-}
-
 // MODE 0: Cin % 32 == 0 (every K tile lies inside one filter tap).  MODE 1: Cin == 4 (stem; one tap per float4).
 // MODE 2: data gradient (transposed conv): output pixel (ih,iw) gathers dY[(ih+pad-kh)/s][(iw+pad-kw)/s] where divisible.
 // NS: LDS ring depth.  2 = load(t+1) overlaps compute(t).  3 = loads run TWO tiles ahead (small tiles with one workgroup per
@@ -1020,20 +1003,46 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
     hipStream_t st = (hipStream_t)s;
     if (d->kwaves > 0) return ym_launch_conv_wave(p, pl.bm, pl.bn, d->kwaves, st);
     const int grid = pl.grid();
+    p.total_items = grid;
+    int stages = d->stages;
+    if (stages >= 42 && stages <= 48) {
+        // persistent direct-to-LDS kernel (conv_persist.hip); what it does not cover runs on the non-persistent ring of the same depth
+        const int ns = stages - 40;
+        const int act = d->seg[0].act;
+        const bool ok = p.vec && pl.bm == 64 && pl.bn == 64 && d->Cin % 32 == 0 && d->nlevels == 0 && d->mma == 0 &&
+                        (act == YM_ACT_NONE || act == YM_ACT_RELU) && (pl.slots() == 1 || p.counters) &&
+                        (ns == 2 || ns == 3 || ns == 4 || ns == 6 || ns == 8);
+        if (ok) {
+            static int cus = 0;
+            if (cus == 0) {
+                int dev = 0, n = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+                cus = n;
+            }
+            int per_cu = (int)((160u << 10) / ym_conv_pers_lds_bytes(64, 64, ns));
+            if (per_cu > 4) per_cu = 4;                       // 128 VGPRs: four waves per SIMD
+            if (per_cu < 1) per_cu = 1;
+            int g = d->grid_wgs > 0 ? d->grid_wgs : cus * per_cu;
+            if (g > grid) g = grid;
+            if (g >= 8 && g < grid) g &= ~7;                  // a workgroup's items then all lie in its own XCD's chunk of the tile space
+            return ym_launch_conv_pers(p, 64, 64, d->transposed ? 2 : 0, ns, d->bn_sum != nullptr, g, st);
+        }
+        stages = ns >= 4 && pl.bm == 64 && pl.bn == 64 && !d->transposed ? 24 : (ns == 2 ? 22 : 23);
+    }
     // stages: 0/2 register-staged double buffer, 3 register-staged ring of 3 (64-wide tiles), 22/23/24 direct-to-LDS ring of 2/3/4,
     // 33/34 direct-to-LDS ring of 3/4 with software-pipelined fragments (64x64 forward tile)
 #define YM_TILE_CASE(BM_, BN_, MODE_, HAS3_)                                                          \
     do {                                                                                              \
-        if (d->stages == 23) launch<BM_, BN_, MODE_, 3, true>(p, grid, st);                           \
-        else if (d->stages == 22) launch<BM_, BN_, MODE_, 2, true>(p, grid, st);                      \
-        else if (d->stages == 3 && HAS3_) launch<BM_, BN_, MODE_, HAS3_ ? 3 : 2>(p, grid, st);        \
+        if (stages == 23) launch<BM_, BN_, MODE_, 3, true>(p, grid, st);                           \
+        else if (stages == 22) launch<BM_, BN_, MODE_, 2, true>(p, grid, st);                      \
+        else if (stages == 3 && HAS3_) launch<BM_, BN_, MODE_, HAS3_ ? 3 : 2>(p, grid, st);        \
         else launch<BM_, BN_, MODE_, 2>(p, grid, st);                                                 \
     } while (0)
     if (d->mma != 0) {                                  // split-bf16 products (see SPL above); tensors stay fp32
         YM_REQUIRE(d->mma == 3 || d->mma == 6, "conv: mma must be 0 (f32 MFMA), 3 (bf16x3) or 6 (bf16x6), got %d", d->mma);
         YM_REQUIRE(d->nlevels == 0 && d->Cin % 32 == 0, "conv: split-bf16 mode needs Cin %% 32 == 0 and a single-size input");
-        if (d->transposed) { if (d->mma == 3) launch_split<2, 2>(p, pl.bm, pl.bn, d->stages, grid, st); else launch_split<2, 3>(p, pl.bm, pl.bn, d->stages, grid, st); }
-        else { if (d->mma == 3) launch_split<0, 2>(p, pl.bm, pl.bn, d->stages, grid, st); else launch_split<0, 3>(p, pl.bm, pl.bn, d->stages, grid, st); }
+        if (d->transposed) { if (d->mma == 3) launch_split<2, 2>(p, pl.bm, pl.bn, stages, grid, st); else launch_split<2, 3>(p, pl.bm, pl.bn, stages, grid, st); }
+        else { if (d->mma == 3) launch_split<0, 2>(p, pl.bm, pl.bn, stages, grid, st); else launch_split<0, 3>(p, pl.bm, pl.bn, stages, grid, st); }
     } else if (d->nlevels > 0) {                        // pyramid input: register-staged double buffer
         if (pl.bm == 128 && pl.bn == 128) launch<128, 128, 0, 2, false, false, true>(p, grid, st);
         else if (pl.bm == 128 && pl.bn == 64) launch<128, 64, 0, 2, false, false, true>(p, grid, st);
@@ -1048,9 +1057,9 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
     else if (pl.bm == 128 && pl.bn == 128) YM_TILE_CASE(128, 128, 0, false);
     else if (pl.bm == 128 && pl.bn == 64) YM_TILE_CASE(128, 64, 0, true);
     else if (pl.bm == 64 && pl.bn == 128) YM_TILE_CASE(64, 128, 0, true);
-    else if (d->stages == 24) launch<64, 64, 0, 4, true>(p, grid, st);
-    else if (d->stages == 33) launch<64, 64, 0, 3, true, true>(p, grid, st);
-    else if (d->stages == 34) launch<64, 64, 0, 4, true, true>(p, grid, st);
+    else if (stages == 24) launch<64, 64, 0, 4, true>(p, grid, st);
+    else if (stages == 33) launch<64, 64, 0, 3, true, true>(p, grid, st);
+    else if (stages == 34) launch<64, 64, 0, 4, true, true>(p, grid, st);
     else YM_TILE_CASE(64, 64, 0, true);
 #undef YM_TILE_CASE
     rc = ym_check_launch("conv_igemm_f32");

@@ -151,6 +151,7 @@ class _Conv:
             self.tail = (hit[5], hit[6]) if len(hit) > 6 else (0, 0)
             d.tile_m, d.tile_n, d.ksplit, d.kwaves, d.stages = hit[0], hit[1], hit[2], self.kwaves, self.stages
             d.tail_tiles, d.tail_ksplit = self.tail
+            d.grid_wgs = hit[7] if len(hit) > 7 else 0          # persistent kernel (stages 4x): workgroups launched
         self.apply_mma(conv_mma())
         return ho, wo
 
@@ -173,6 +174,7 @@ class _Conv:
             self.tail = (hit[5], hit[6]) if len(hit) > 6 else (0, 0)
             d.tile_m, d.tile_n, d.ksplit, d.kwaves = self.tile[0], self.tile[1], self.ksplit, self.kwaves
             d.tail_tiles, d.tail_ksplit = self.tail
+            d.grid_wgs = hit[7] if len(hit) > 7 else 0
             if self.kwaves:                                         # the tuner may prefer the f32 wave kernel for a tiny layer
                 self.mma = 0
                 d.mma = 0

@@ -54,7 +54,7 @@ class ConvDesc(ctypes.Structure):
                 ('level_w', ctypes.c_int32 * 5), ('tail_tiles', ctypes.c_int32), ('tail_ksplit', ctypes.c_int32), ('mma', ctypes.c_int32),
                 ('bnb_relu', ctypes.c_int32), ('bnb_y', ctypes.c_void_p), ('bnb_out', ctypes.c_void_p),
                 ('bnb_mean', ctypes.c_void_p), ('bnb_invstd', ctypes.c_void_p), ('bnb_gamma', ctypes.c_void_p),
-                ('bnb_beta', ctypes.c_void_p)]
+                ('bnb_beta', ctypes.c_void_p), ('grid_wgs', ctypes.c_int32)]
 
 
 class WgradDesc(ctypes.Structure):

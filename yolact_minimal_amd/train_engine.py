@@ -36,6 +36,12 @@ def _table():
     return tuned_table()
 
 
+def tuned_table_changed():
+    """The cached launch descriptors keep the tile / split / staging choice of their first use: call this after editing the tuned
+    table (tests, tuning tools) so that the next launch of every shape reads its entry again."""
+    _desc_cache.clear()
+
+
 def _time_launch(fn, iters=5):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     fn(); fn()
@@ -94,6 +100,12 @@ def _configure_conv(d, key):
         d.kwaves = hit[3] if len(hit) > 3 else 0
         d.stages = hit[4] if len(hit) > 4 else 0
         d.tail_tiles, d.tail_ksplit = (hit[5], hit[6]) if len(hit) > 6 else (0, 0)
+        d.grid_wgs = hit[7] if len(hit) > 7 else 0              # persistent kernel (stages 4x): workgroups launched
+    force = os.environ.get('YM_FORCE_STAGES')        # experiments / tests: e.g. 43 = every conv the persistent kernel covers runs on it
+    if force:
+        d.tile_m, d.tile_n, d.kwaves, d.stages, d.grid_wgs = 64, 64, 0, int(force), int(os.environ.get('YM_FORCE_GRID', '0'))
+        if d.tail_tiles and d.ksplit > 1:
+            d.tail_tiles = d.tail_ksplit = 0
     mma = train_mma()
     if mma and d.Cin % 32 == 0 and d.nlevels == 0:
         # opt-in FAST training mode (YM_TRAIN_MMA=3): forward and data-gradient convs on the bf16 MFMA (split-bf16 products, see

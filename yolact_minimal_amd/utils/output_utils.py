@@ -40,7 +40,8 @@ def _anchors_on(anchors, device):
 
 
 def _nms_buffers(device, ncfg):
-    key = (str(device), ncfg.num_anchors, ncfg.num_classes, ncfg.coef_dim, ncfg.max_det)
+    # (scratch is per STREAM: requests in flight on different streams must not share it)
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream, ncfg.num_anchors, ncfg.num_classes, ncfg.coef_dim, ncfg.max_det)
     b = _ws_cache.get(key)
     if b is None:
         nbytes = hip.lib().ym_nms_workspace_bytes(ctypes.byref(ncfg))
@@ -130,9 +131,10 @@ _scratch_bufs = {}
 
 
 def _scratch(device, nbytes):
-    b = _scratch_bufs.get(str(device))
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    b = _scratch_bufs.get(key)
     if b is None or b.numel() < nbytes:
-        b = _scratch_bufs[str(device)] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        b = _scratch_bufs[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
     return b
 
 
@@ -174,7 +176,7 @@ def nms_batch(class_pred, box_pred, coef_pred, proto_out, anchors, cfg):
     nbytes = L.ym_nms_batch_workspace_bytes(ctypes.byref(ncfg), batch)
     if nbytes == 0:
         raise RuntimeError('ym_nms_batch_workspace_bytes: ' + L.ym_last_error().decode())
-    key = ('batch', str(device), batch, n_anchors, n_classes)
+    key = ('batch', str(device), torch.cuda.current_stream(device).cuda_stream, batch, n_anchors, n_classes)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = _ws_cache[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
