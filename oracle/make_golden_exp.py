@@ -65,5 +65,45 @@ def main():
     print('wrote tests/golden/exp_torch_cpu.npz')
 
 
+def post_cases():
+    """The inputs of tests/golden/post_*.npz (oracle/make_golden.py gen_post), regenerated from their seeds."""
+    from oracle import yolact_ref as R
+    a544 = R.anchors_for(544, [24, 48, 96, 192, 384])
+    a128 = R.anchors_for(128, [int(128 / 544 * s) for s in (24, 48, 96, 192, 384)])
+    yield ('dense544',) + tuple(R.synth_head_outputs(18525, seed=1)) + (a544,)
+    yield ('sparse544',) + tuple(R.synth_head_outputs(18525, seed=2, bg_bias=9.0)) + (a544,)
+    yield ('small128',) + tuple(R.synth_head_outputs(1023, proto_hw=32, seed=3, bg_bias=5.0)) + (a128,)
+    cls, box, coef, proto = R.synth_head_outputs(1023, proto_hw=32, seed=5, bg_bias=7.5)
+    box[0, ::3, 0] = -40.0
+    box[0, ::3, 2] = -8.0
+    yield 'degenerate128', cls, box, coef, proto, a128
+    cls, box, coef, proto = R.synth_head_outputs(1023, proto_hw=32, seed=6, bg_bias=5.0)
+    cls[0, 1::2] = cls[0, 0::2][: cls[0, 1::2].shape[0]]
+    yield 'ties128', cls, box, coef, proto, a128
+
+
+def freeze_decode_exp():
+    """For every post-processing golden: the outputs of THIS host's `torch.exp` (the reference's call, utils/output_utils.py:150)
+    on exactly the arguments the decode feeds it -- `box_p[keep, 2:] * 0.2` for every candidate over the score threshold.  With
+    them the reference's boxes can be re-derived without MKL (tests/test_oracle_expf.py: decode with the frozen values == the
+    frozen reference boxes bit for bit; the kernel's boxes differ exactly where the frozen value is not the correctly rounded
+    exp)."""
+    out = {}
+    for tag, cls, box, coef, proto, anchors in post_cases():
+        keep = cls[0].t()[1:].max(dim=0)[0] > 0.05
+        x = box[0][keep][:, 2:] * 0.2
+        out[f'{tag}_y'] = torch.exp(x).numpy()
+        out[f'{tag}_n'] = np.array(int(keep.sum()))
+        print(tag, int(keep.sum()), 'candidates')
+    np.savez_compressed(os.path.join(HERE, '..', 'tests', 'golden', 'exp_decode_frozen.npz'), **out)
+    print('wrote tests/golden/exp_decode_frozen.npz')
+
+
 if __name__ == '__main__':
-    main()
+    import sys
+    sys.path.insert(0, os.path.join(HERE, '..'))
+    if 'decode' in sys.argv[1:]:
+        freeze_decode_exp()
+    else:
+        main()
+        freeze_decode_exp()

@@ -177,7 +177,12 @@ def decode(box_p, anchors, exp='torch'):
     value in ~1.1 % of inputs).  exp='cr': the correctly rounded exp of oracle/expf_cr.c — the host-independent anchor the
     HIP kernel is held to bit for bit."""
     cxcy = anchors[:, :2] + box_p[:, :2] * 0.1 * anchors[:, 2:]
-    wh = anchors[:, 2:] * (expf_cr(box_p[:, 2:] * 0.2) if exp == 'cr' else torch.exp(box_p[:, 2:] * 0.2))
+    if torch.is_tensor(exp):      # FROZEN outputs of the reference's own torch.exp for exactly these inputs (tests/golden/exp_decode_frozen.npz)
+        assert exp.shape == box_p[:, 2:].shape and exp.dtype == torch.float32
+        e = exp
+    else:
+        e = expf_cr(box_p[:, 2:] * 0.2) if exp == 'cr' else torch.exp(box_p[:, 2:] * 0.2)
+    wh = anchors[:, 2:] * e
     x1y1 = cxcy - wh / 2
     x2y2 = wh + x1y1
     return torch.clip(torch.cat((x1y1, x2y2), 1), min=0., max=1.)
@@ -325,6 +330,39 @@ def after_nms(ids, scores, boxes, coefs, proto, img_h, img_w, visual_thre=0.0, d
 # synthetic inputs shared by goldens, tests and bench
 # ------------------------------------------------------------------------------------------------
 from yolact_minimal_amd.utils.synthetic import synth_head_outputs, synth_targets  # noqa: E402,F401  (input generators)
+
+
+def detections_match(a, b, tol=1e-4, cut_margin=None):
+    """Do two `nms` results (ids, scores, boxes, ...) describe the same detections up to `tol`?  Detections are ordered by score,
+    and scores that differ by less than the arithmetic noise of two implementations may swap places or fall on different sides
+    of the top-`max_det` cut, so the comparison is on SETS: every detection of one result whose score is safely above the other
+    result's cut (by `cut_margin`, default 2 tol) must have a partner of the same class with score and box within `tol`; partners
+    are used once.  Returns (ok, message, pairs) with pairs = [(index in a, index in b)]."""
+    cut_margin = 2 * tol if cut_margin is None else cut_margin
+    ia, sa, ba = a[0], a[1], a[2]
+    ib, sb, bb = b[0], b[1], b[2]
+    if ia is None or ib is None:
+        return (ia is None and ib is None), 'one result is empty', []
+    used, pairs = set(), []
+    cut_a, cut_b = float(sa.min()), float(sb.min())
+    for i in range(ia.numel()):
+        best = None
+        for j in range(ib.numel()):
+            if j in used or int(ia[i]) != int(ib[j]):
+                continue
+            if abs(float(sa[i]) - float(sb[j])) <= tol and float((ba[i] - bb[j]).abs().max()) <= tol:
+                best = j
+                break
+        if best is None:
+            if float(sa[i]) > cut_b + cut_margin:
+                return False, f'detection {i} of a (class {int(ia[i])}, score {float(sa[i]):.6f}) has no partner in b', pairs
+        else:
+            used.add(best)
+            pairs.append((i, best))
+    for j in range(ib.numel()):
+        if j not in used and float(sb[j]) > cut_a + cut_margin:
+            return False, f'detection {j} of b (class {int(ib[j])}, score {float(sb[j]):.6f}) has no partner in a', pairs
+    return True, '', pairs
 
 
 def randomize_bn_(sd, seed=7):

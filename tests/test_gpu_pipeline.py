@@ -162,3 +162,58 @@ def test_requests_in_flight_give_the_single_request_results():
         for a, b in zip(e.outputs(), want_fwd):
             assert torch.equal(a, b)
     assert two.detections == 7 * int(want[0].shape[0])          # 7 requests were issued, each read back once
+
+
+def test_chained_forward_nms_after_nms_matches_the_reference(golden_dir):
+    """eval.py:45-52 as ONE chain at the benchmarked size: res101_coco 544 px, `nms` / `after_nms` consume the HIP forward's OWN
+    outputs (every other post-processing test feeds synthetic head outputs).  Golden from the REAL reference
+    (oracle/make_golden_chained.py): seeded weights with the conf layer re-centred so that ~400 anchors of 6 classes pass the score
+    threshold; the generator checked that the detection set is unchanged under 2e-6 noise on the network outputs.
+    Bars: network outputs 1e-4; detections as SETS (oracle.yolact_ref.detections_match: equal class, score and box within 1e-4 --
+    neighbouring anchors of a random-init net score 1e-7 apart, so their order is not a property of the network); masks of
+    matched detections differ in <= 1e-4 of the pixels; and the HIP post-processing equals the oracle's applied to the HIP
+    forward's outputs exactly (ids, scores, boxes, pixel boxes)."""
+    from yolact_minimal_amd.utils.output_utils import nms, after_nms
+    gold = np.load(f'{golden_dir}/chained_res101_coco_544.npz')
+    seed = int(gold['seed'])
+    cfg = build_cfg('res101_coco', 'val', 544)
+    torch.manual_seed(seed)
+    net = Yolact(cfg).eval()
+    sd = net.state_dict()
+    R.randomize_bn_(sd, seed + 100)
+    R.randomize_bias_(sd, seed + 200)
+    sd['prediction_layers.conf_layer.weight'].mul_(float(gold['conf_gain']))
+    sd['prediction_layers.conf_layer.bias'].copy_(torch.from_numpy(gold['conf_bias']))
+    net.load_state_dict(sd)
+    net = net.to(DEV)
+    img = torch.randn(1, 3, 544, 544, generator=torch.Generator().manual_seed(seed + 300))
+    with torch.no_grad():
+        out = net(img.to(DEV))
+    for t, key in zip(out, ('class_digest', 'box_digest', 'coef_digest', 'proto_digest')):
+        d = t.detach().double()
+        got = np.array([d.sum().item(), d.abs().sum().item(), (d * d).sum().item()])
+        np.testing.assert_allclose(got, gold[key], rtol=1e-4, err_msg=key)
+    # the HIP post-processing on the HIP forward's outputs == the oracle on the same tensors
+    r = nms(out[0], out[1], out[2], out[3], net.anchors, cfg)
+    anchors = torch.tensor(net.anchors, dtype=torch.float32).reshape(-1, 4)
+    o = R.nms(out[0].cpu(), out[1].cpu(), out[2].cpu(), out[3].cpu(), anchors, stable=True, exp='cr')
+    assert torch.equal(r[0].cpu(), o[0]) and torch.equal(r[1].cpu(), o[1]) and torch.equal(r[2].cpu(), o[2])
+    res = after_nms(r[0], r[1], r[2].clone(), r[3], r[4], 480, 640, cfg)
+    o_after = R.after_nms(o[0], o[1], o[2], o[3], o[4], 480, 640)
+    assert torch.equal(res[2].cpu(), o_after[2])
+    assert float((res[3].cpu() != o_after[3]).float().mean()) < 1e-5
+    # ... and == the reference's own chain, as a set of detections
+    ref = (torch.from_numpy(gold['ids']), torch.from_numpy(gold['scores']), torch.from_numpy(gold['boxes']))
+    ok, msg, pairs = R.detections_match(ref, (r[0].cpu(), r[1].cpu(), r[2].cpu()))
+    assert ok, msg
+    n = int(gold['n'])
+    assert len(pairs) >= n - 3, (len(pairs), n)
+    ref_masks = np.unpackbits(gold['masks_packed'])[:n * 480 * 640].reshape(n, 480, 640)
+    ref_px = gold['px_boxes']
+    masks, px = res[3].cpu().numpy().astype(np.uint8), res[2].cpu().numpy()
+    bad_px = 0
+    for i, j in pairs:
+        assert np.abs(px[j] - ref_px[i]).max() <= 1, (i, j, px[j], ref_px[i])
+        bad_px += int((px[j] != ref_px[i]).any())
+        assert float((masks[j] != ref_masks[i]).mean()) <= 1e-4, (i, j)
+    assert bad_px <= max(1, len(pairs) // 50)

@@ -148,9 +148,13 @@ def main():
             total_new += t_old
     print(f'sum over shapes: tuned {total_old:.1f} us -> with persistent winners {total_new:.1f} us')
     if write:
-        with open(TUNED, 'w') as f:
-            json.dump(tuned, f, indent=0, sort_keys=True)
-        print('tuned table updated')
+        # (on a gpurun box only gpurun_out/ travels back: the table is written there as well)
+        outs = [TUNED] + ([os.path.join(os.path.dirname(os.path.dirname(TUNED)), 'gpurun_out', 'tuned_gfx950.json')]
+                          if os.path.isdir(os.path.join(os.path.dirname(os.path.dirname(TUNED)), 'gpurun_out')) else [])
+        for path in outs:
+            with open(path, 'w') as f:
+                json.dump(tuned, f, indent=0, sort_keys=True)
+        print('tuned table updated:', outs)
 
 
 if __name__ == '__main__':
