@@ -10,12 +10,14 @@ Image size is 544 (the reference cannot run at 550: SURVEY.md §0.1).  Weights: 
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--cfg res101_coco] [--batch 1]
 
-`--inflight S` (default 2 at bs=1): S independent bs=1 requests are in flight on S HIP streams (S engines with their own activations,
-split-K scratch and hipGraphs).  A bs=1 forward is a chain of ~190 dependent launches, each ~9 us of launch boundary + address
-set-up + epilogue around ~7 us of MFMA work, so ONE chain keeps the matrix pipe ~35 % busy; the second request's kernels run in
-those holes (348 -> 490 img/s forward-only on one MI355X).  Every step is still one image through forward + nms + after_nms with
-one host read of its detection count (read when the slot is reused, i.e. S steps later, so the host never waits on the request it
-just enqueued).  `--inflight 1` is the single-request latency mode of rounds 1-2; its numbers stay in the line under
+`--inflight S` (default 4 at bs=1): S independent bs=1 requests are in flight on S HIP streams (S engines with their own activations,
+split-K scratch, arrival counters and hipGraphs; GPU_MAX_HW_QUEUES=8 so that every stream has a hardware queue of its own).  A
+bs=1 forward is a chain of ~190 dependent launches, each ~9 us of launch boundary + address set-up + epilogue around ~7 us of MFMA
+work, so ONE chain keeps the matrix pipe ~35 % busy; the other requests' kernels run in those holes.  Measured on one MI355X,
+forward + nms + after_nms: 1 request 325 img/s, 2: 468, 3: 545, 4: 594, 5: 495, 6: 532, 8: 479 (the part runs four compute pipes).
+Every step is still ONE image through forward + nms + after_nms with ONE host read of its detection count (taken when the slot is
+reused, S steps later: the count is copied to pinned memory behind the request, so the host never waits on what it just
+enqueued).  `--inflight 1` is the single-request latency mode of rounds 1-2; its numbers stay in the line under
 `roofline.single_request`.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): inference does not shard — images are
@@ -29,7 +31,11 @@ import os
 import sys
 import time
 
-import torch
+# requests in flight (--inflight) run on separate HIP streams; ROCm multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues
+# (default 4) and two streams that share a queue do not overlap -> ask for 8 before the runtime starts
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
+import torch  # noqa: E402
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
@@ -47,7 +53,7 @@ def parse():
     ap.add_argument('--cfg', default='res101_coco')
     ap.add_argument('--batch', type=int, default=1, help='images per GPU per step')
     ap.add_argument('--img_size', type=int, default=544)
-    ap.add_argument('--inflight', type=int, default=0, help='bs=1 requests in flight on separate streams (0 = 2 at --batch 1, else 1)')
+    ap.add_argument('--inflight', type=int, default=0, help='bs=1 requests in flight on separate streams (0 = 4 at --batch 1, else 1)')
     ap.add_argument('--no-post', action='store_true', help='time the network forward only')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the bs=8 side measurements')
@@ -67,6 +73,9 @@ def build_net(cfg_name, img_size, device, seed=0):
     torch.manual_seed(seed)
     net = Yolact(cfg).eval().to(device)
     return net, cfg
+
+
+_STREAMS = []
 
 
 class Workload:
@@ -91,8 +100,12 @@ class Workload:
         self.inflight = inflight if batch == 1 else 1
         if self.inflight > 1:
             self.engines = [self.engine] + [InferEngine(net, batch, img_size, img_size, device) for _ in range(self.inflight - 1)]
-            self.streams = [torch.cuda.Stream(device=device) for _ in range(self.inflight)]
+            while len(_STREAMS) < self.inflight:           # one process-wide set: every Workload overlaps on the SAME streams (= the same
+                _STREAMS.append(torch.cuda.Stream(device=device))      # hardware queues), whatever was created in between
+            self.streams = _STREAMS[:self.inflight]
             self.pending = [None] * self.inflight
+            self.counts_host = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(self.inflight)]
+            self.events = [torch.cuda.Event() for _ in range(self.inflight)]
             self.i = 0
             self.detections = 0
             torch.cuda.synchronize()
@@ -108,9 +121,9 @@ class Workload:
         if pend is None:
             return
         self.pending[slot] = None
-        ids, scores, box_px, masks, counts = pend
-        with torch.cuda.stream(self.streams[slot]):
-            n = int(counts.tolist()[0])
+        ids, scores, box_px, masks, counts, ev = pend
+        ev.synchronize()                              # (waits for THIS request only: its count was copied to pinned memory behind it)
+        n = int(self.counts_host[slot][0])
         self.detections += n
         return ids[0, :n], scores[0, :n], box_px[0, :n], masks[0, :n]
 
@@ -128,7 +141,11 @@ class Workload:
             with torch.cuda.stream(self.streams[slot]):
                 self.engines[slot].run(self.img)
                 if self.with_post:
-                    self.pending[slot] = after_nms_batch(nms_batch(*self.head, self.anchors, self.cfg), 480, 640, self.cfg, sync=False)
+                    r = after_nms_batch(nms_batch(*self.head, self.anchors, self.cfg), 480, 640, self.cfg, sync=False)
+                    self.counts_host[slot].copy_(r[4], non_blocking=True)
+                    ev = self.events[slot]
+                    ev.record()
+                    self.pending[slot] = r + (ev,)
             return
         self.engine.run(self.img)
         if self.with_post:
@@ -460,7 +477,7 @@ def main():
             dist.barrier()
 
     net, cfg = build_net(args.cfg, args.img_size, device)
-    inflight = args.inflight if args.inflight > 0 else (2 if args.batch == 1 else 1)
+    inflight = args.inflight if args.inflight > 0 else (4 if args.batch == 1 else 1)
     if args.batch != 1:
         inflight = 1
     wl = Workload(net, cfg, args.batch, args.img_size, device, with_post=not args.no_post, inflight=inflight)

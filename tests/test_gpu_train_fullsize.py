@@ -200,7 +200,7 @@ def test_bn_pool_upsample_backward_at_full_size(b, h, c):
             # reproduces -- torch's own device kernel may pick another one, so this reference runs on the host)
             r = xq.cpu().permute(0, 3, 1, 2).contiguous().requires_grad_()
             F.max_pool2d(r, 3, 2, 1).backward(gq.cpu().permute(0, 3, 1, 2).contiguous())
-            r.grad = r.grad.to(DEV).double()
+            want = r.grad.to(DEV).double()
         else:                                                     # FPN top-down x2 (align_corners=False, modules/yolact.py:70-71)
             a = xq.clone().requires_grad_()
             y = T.Bilinear2x.apply(a, False)
@@ -208,5 +208,6 @@ def test_bn_pool_upsample_backward_at_full_size(b, h, c):
             y.backward(gq)
             r = xq.double().permute(0, 3, 1, 2).requires_grad_()
             F.interpolate(r, scale_factor=2, mode='bilinear', align_corners=False).backward(gq.double().permute(0, 3, 1, 2))
-        err = float((a.grad.double() - r.grad.permute(0, 2, 3, 1)).abs().max() / r.grad.abs().max())
+            want = r.grad
+        err = float((a.grad.double() - want.permute(0, 2, 3, 1)).abs().max() / want.abs().max())
         assert err <= 1e-4, ('pool / upsample', err)

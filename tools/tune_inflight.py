@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Experiment / tuner: per-layer kernel choices for bs=1 serving with TWO requests in flight (bench.py --inflight 2).
+Measures the 2-in-flight forward throughput with the table as it is, re-tunes every conv shape of the bs=1 plan under
+`InferEngine.autotune(concurrent=True)` (two copies of a launch side by side), measures again, and writes the choices as
+`<signature>_c2` entries to gpurun_out/tuned_c2.json."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from yolact_minimal_amd.engine import tuned_table  # noqa: E402
+
+dev = torch.device('cuda:0')
+name = sys.argv[1] if len(sys.argv) > 1 else 'res101_coco'
+net, cfg = bench.build_net(name, 544, dev)
+
+
+def throughput(inflight):
+    net._engines.clear()
+    w = bench.Workload(net, cfg, 1, 544, dev, with_post=False, inflight=inflight)
+    t = min(bench.timed(w, 200, 20, lambda: None), bench.timed(w, 200, 5, lambda: None)) / 200
+    return 1.0 / t
+
+
+before = {s: throughput(s) for s in (1, 2)}
+print('as tuned (per-launch latency):', {k: round(v, 1) for k, v in before.items()}, flush=True)
+net._engines.clear()
+eng = net._engine(torch.randn(1, 3, 544, 544, device=dev))
+res = eng.autotune(10, verbose=True, concurrent=True)
+saved = {k: tuned_table().get(k) for k in res}
+tuned_table().update({k: v[:7] for k, v in res.items()})
+after = {s: throughput(s) for s in (1, 2)}
+print('tuned with two copies side by side:', {k: round(v, 1) for k, v in after.items()}, flush=True)
+os.makedirs('gpurun_out', exist_ok=True)
+json.dump({k + '_c2': v[:7] for k, v in res.items() if v[:7] != (saved.get(k) or [])[:7]}, open('gpurun_out/tuned_c2.json', 'w'), indent=0, sort_keys=True)
+json.dump(dict(before=before, after=after, detail=res), open('gpurun_out/tuned_c2_detail.json', 'w'), indent=0, sort_keys=True)

@@ -507,12 +507,27 @@ class InferEngine:
             c.apply_mma(mma)
         self.retune()
 
-    def autotune(self, iters=10, verbose=False, mma=0):
+    def autotune(self, iters=10, verbose=False, mma=0, concurrent=False):
         """Time every (tile, ksplit) candidate of every distinct conv shape on this GPU; keep the fastest.
-        Returns {signature: [tile_m, tile_n, ksplit, best_us, default_us]}."""
+        Returns {signature: [tile_m, tile_n, ksplit, best_us, default_us]}.
+        `concurrent`: tune for THROUGHPUT with requests in flight (bench.py --inflight 2) instead of for the latency of a launch
+        that has the chip to itself: every candidate is timed as two copies of the launch running side by side on two streams
+        (own split-K scratch and arrival counters each); the figure is the wall time per PAIR, so a choice that wins by spreading
+        thin over all CUs (many K slices + an exchange) loses to one that does the same work with fewer resources."""
         results = {}
         big_ws = torch.empty(1 << 28, device=self.device, dtype=torch.uint8)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if concurrent:
+            side = torch.cuda.Stream(device=self.device)
+            big_ws2 = torch.empty(1 << 28, device=self.device, dtype=torch.uint8)
+            counters2 = torch.zeros(hip.TILE_COUNTERS, device=self.device, dtype=torch.int32)
+            main = torch.cuda.current_stream(self.device)
+
+        def launch(d, d2):
+            hip.conv2d_fwd(d, big_ws)
+            if concurrent:                       # (same inputs and outputs: both copies write the same values; scratch + counters differ)
+                with torch.cuda.stream(side):
+                    hip.conv2d_fwd(d2, big_ws2)
 
         def time_cfg(c, tile, ks, kwv=0, stg=0, tail=(0, 0)):
             d = c.desc
@@ -522,16 +537,24 @@ class InferEngine:
             need = hip.conv_workspace_bytes(d)
             if need > big_ws.numel():
                 return None
+            d2 = None
+            if concurrent:
+                d2 = type(d).from_buffer_copy(d)
+                if d.tile_counters:
+                    d2.tile_counters = counters2.data_ptr()
             try:
                 for _ in range(2):
-                    hip.conv2d_fwd(d, big_ws)
+                    launch(d, d2)
             except RuntimeError:
                 return None
             best = 1e30
             for _ in range(3):
+                torch.cuda.synchronize()
                 ev0.record()
                 for _ in range(iters):
-                    hip.conv2d_fwd(d, big_ws)
+                    launch(d, d2)
+                if concurrent:
+                    main.wait_stream(side)
                 ev1.record()
                 torch.cuda.synchronize()
                 best = min(best, ev0.elapsed_time(ev1) / iters * 1e3)
@@ -572,6 +595,9 @@ class InferEngine:
                         if (tm, tn) == (64, 64) and nkt // ks >= 2:    # + software-pipelined fragments
                             cands.append(((tm, tn), ks, 0, 33, (0, 0)))
                             cands.append(((tm, tn), ks, 0, 34, (0, 0)))
+                        if (tm, tn) == (64, 64) and d.nseg == 1 and d.tile_counters and c.act in (ACT_NONE, ACT_RELU):
+                            cands.append(((tm, tn), ks, 0, 43, (0, 0)))    # persistent kernel (conv_persist.hip), ring of 3 / 6
+                            cands.append(((tm, tn), ks, 0, 46, (0, 0)))
                 # workgroup-quantisation fix: split the tiles of the last partial round (over 256 CUs x 1 or 2 workgroups)
                 if not c.stem and d.nseg == 1 and d.tile_counters and 256 < wgs <= hip.TILE_COUNTERS:
                     for r in sorted({wgs % 256, wgs % 512} - {0}):
