@@ -75,16 +75,14 @@ def build_net(cfg_name, img_size, device, seed=0):
     return net, cfg
 
 
-_STREAMS = []
-
-
 class Workload:
     """forward(batch) + per-image post-processing, everything resident on the device.  `inflight` > 1 (batch 1 only): that many
-    requests overlap, each on its own stream with its own engine; see the module docstring."""
+    requests overlap (yolact_minimal_amd.pipeline.RequestPipeline: one engine + one stream per slot); see the module docstring.
+    `chained`: post-process the forward's OWN outputs (eval.py:45-52) instead of the dense synthetic head outputs."""
 
-    def __init__(self, net, cfg, batch, img_size, device, with_post=True, seed=0, inflight=1):
+    def __init__(self, net, cfg, batch, img_size, device, with_post=True, seed=0, inflight=1, chained=False):
         from yolact_minimal_amd.utils.synthetic import synth_head_outputs
-        from yolact_minimal_amd.engine import InferEngine
+        from yolact_minimal_amd.pipeline import RequestPipeline
         self.net, self.cfg, self.batch, self.device = net, cfg, batch, device
         g = torch.Generator().manual_seed(seed)
         self.img = torch.randn(batch, 3, img_size, img_size, generator=g).to(device)
@@ -92,67 +90,36 @@ class Workload:
         n_anchors = len(net.anchors) // 4
         cls, box, coef, proto = synth_head_outputs(n_anchors, num_classes=cfg.num_classes, proto_hw=img_size // 4,
                                                    seed=1)
-        self.head = [t.to(device) for t in (cls, box, coef, proto)]
+        self.head = None if chained else [t.to(device) for t in (cls, box, coef, proto)]
         # batch > 1: the batched launch set (one image per grid row, one host read per batch) on B copies of the dense case
-        self.head_b = [t.expand(batch, *t.shape[1:]).contiguous() for t in self.head] if batch > 1 else None
+        self.head_b = [t.expand(batch, *t.shape[1:]).contiguous() for t in self.head] if batch > 1 and not chained else None
         self.anchors = torch.tensor(net.anchors, dtype=torch.float32).reshape(-1, 4).to(device)
-        self.engine = net._engine(self.img)
-        self.inflight = inflight if batch == 1 else 1
+        self.inflight = inflight
+        self.pipe = None
         if self.inflight > 1:
-            self.engines = [self.engine] + [InferEngine(net, batch, img_size, img_size, device) for _ in range(self.inflight - 1)]
-            while len(_STREAMS) < self.inflight:           # one process-wide set: every Workload overlaps on the SAME streams (= the same
-                _STREAMS.append(torch.cuda.Stream(device=device))      # hardware queues), whatever was created in between
-            self.streams = _STREAMS[:self.inflight]
-            self.pending = [None] * self.inflight
-            self.counts_host = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(self.inflight)]
-            self.events = [torch.cuda.Event() for _ in range(self.inflight)]
-            self.i = 0
-            self.detections = 0
-            torch.cuda.synchronize()
-            for e, st in zip(self.engines, self.streams):          # graph capture / first run outside the timed region
-                with torch.cuda.stream(st):
-                    e.run(self.img)
-            torch.cuda.synchronize()
-
-    def _finish(self, slot):
-        """The ONE host read of a request (its detection count, as `after_nms` needs it to size what it returns); the request was
-        enqueued `inflight` steps ago, so this rarely waits."""
-        pend = self.pending[slot]
-        if pend is None:
-            return
-        self.pending[slot] = None
-        ids, scores, box_px, masks, counts, ev = pend
-        ev.synchronize()                              # (waits for THIS request only: its count was copied to pinned memory behind it)
-        n = int(self.counts_host[slot][0])
-        self.detections += n
-        return ids[0, :n], scores[0, :n], box_px[0, :n], masks[0, :n]
+            self.pipe = RequestPipeline(net, cfg, img_size, img_size, device, depth=self.inflight, out_hw=(480, 640), with_post=with_post,
+                                        batch=batch)
+            self.pipe.warm_up(self.img)
+            self.engine = self.pipe.engines[0]
+        else:
+            self.engine = net._engine(self.img)
 
     def flush(self):
-        if self.inflight > 1:
-            for slot in range(self.inflight):
-                self._finish(slot)
+        if self.pipe is not None:
+            self.pipe.drain()
 
     def step(self):
         from yolact_minimal_amd.utils.output_utils import nms, after_nms, nms_batch, after_nms_batch
-        if self.inflight > 1:
-            slot = self.i % self.inflight
-            self.i += 1
-            self._finish(slot)
-            with torch.cuda.stream(self.streams[slot]):
-                self.engines[slot].run(self.img)
-                if self.with_post:
-                    r = after_nms_batch(nms_batch(*self.head, self.anchors, self.cfg), 480, 640, self.cfg, sync=False)
-                    self.counts_host[slot].copy_(r[4], non_blocking=True)
-                    ev = self.events[slot]
-                    ev.record()
-                    self.pending[slot] = r + (ev,)
+        if self.pipe is not None:
+            self.pipe.submit(self.img, self.head if self.batch == 1 else self.head_b)
             return
         self.engine.run(self.img)
         if self.with_post:
             if self.batch > 1:
-                after_nms_batch(nms_batch(*self.head_b, self.anchors, self.cfg), 480, 640, self.cfg)
+                hb = self.head_b if self.head_b is not None else self.engine.outputs()
+                after_nms_batch(nms_batch(*hb, self.anchors, self.cfg), 480, 640, self.cfg)
             else:
-                cls, box, coef, proto = self.head
+                cls, box, coef, proto = self.head if self.head is not None else self.engine.outputs()
                 r = nms(cls, box, coef, proto, self.anchors, self.cfg)
                 after_nms(r[0], r[1], r[2], r[3], r[4], 480, 640, self.cfg)
 
@@ -238,6 +205,48 @@ def post_bench(net, cfg, device, img_size, iters=30):
         t_nms, t_after = t_nms / iters * 1e-3, t_after / iters * 1e-3
         out[f'bs{b}'] = dict(detections=n_det, nms_us=round(t_nms * 1e6, 1), after_nms_us=round(t_after * 1e6, 1),
                              after_nms_gbs=round(nbytes / t_after / 1e9, 1), after_nms_frac_hbm_peak=round(nbytes / t_after / 1e9 / HBM_PEAK_GBS, 4))
+    return out
+
+
+def chained_bench(cfg_name, img_size, device, inflight, steps=100):
+    """eval.py:45-52 as ONE chain: `nms` / `after_nms` consume the forward's OWN outputs.  A random-init network gives degenerate
+    detections, so the shared conf layer is reshaped like oracle/make_golden_chained.py does (weight x 10, bias = minus the spatial
+    mean of every (anchor, class) logit + N(0, 1) + a background offset found by bisection for ~400 candidates over the score
+    threshold); the golden test of that recipe is tests/test_gpu_pipeline.py::test_chained_forward_nms_after_nms_matches_the_reference."""
+    net, cfg = build_net(cfg_name, img_size, device, seed=71)
+    conv = net.prediction_layers.conf_layer
+    with torch.no_grad():
+        conv.weight.mul_(10.0)
+        conv.bias.zero_()
+    net.mark_weights_changed()
+    img = torch.randn(1, 3, img_size, img_size, generator=torch.Generator().manual_seed(371)).to(device)
+    eng = net._engine(img)
+    eng.run(img)
+    torch.cuda.synchronize()
+    la = eng.class_logits[0].reshape(-1, 3, cfg.num_classes).double()
+    nb = torch.randn(3, cfg.num_classes, generator=torch.Generator().manual_seed(571)).to(device).double() - la.mean(dim=0)
+    lo, hi = 0.0, 40.0
+    for _ in range(30):
+        mid = 0.5 * (lo + hi)
+        bb = nb.clone()
+        bb[:, 0] += mid
+        n_c = int((torch.softmax((la + bb).reshape(-1, cfg.num_classes), -1)[:, 1:].max(dim=1)[0] > 0.05).sum())
+        lo, hi = (mid, hi) if n_c > 400 else (lo, mid)
+    nb[:, 0] += hi
+    with torch.no_grad():
+        conv.bias.copy_(nb.reshape(-1).float())
+    net.mark_weights_changed()
+    net._engines.clear()
+    out = {}
+    for s_ in sorted({1, inflight}):
+        w = Workload(net, cfg, 1, img_size, device, with_post=True, inflight=s_, chained=True)
+        t = timed(w, steps, 10, lambda: None) / steps
+        out[f'img_s_inflight{s_}'] = round(1.0 / t, 1)
+        if w.pipe is not None:
+            out['detections_per_image'] = round(w.pipe.detections / max(1, w.pipe.submitted), 1)
+        del w
+    out['workload'] = 'forward + nms + after_nms(480x640) on the forward\'s own outputs (~400 candidates over the score threshold)'
+    net._engines.clear()
     return out
 
 
@@ -477,9 +486,7 @@ def main():
             dist.barrier()
 
     net, cfg = build_net(args.cfg, args.img_size, device)
-    inflight = args.inflight if args.inflight > 0 else (4 if args.batch == 1 else 1)
-    if args.batch != 1:
-        inflight = 1
+    inflight = args.inflight if args.inflight > 0 else (4 if args.batch == 1 else 2)
     wl = Workload(net, cfg, args.batch, args.img_size, device, with_post=not args.no_post, inflight=inflight)
     elapsed = timed(wl, args.steps, args.warmup, barrier)
     if dist is not None:
@@ -559,19 +566,31 @@ def main():
         extra['slowest_convs'] = [dict(name=l['name'], ms=round(l['ms'], 4), tflops=round(l['gflop'] / l['ms'], 1)) for l in slow]
         if not args.no_extra and world == 1:
             for name, b in ((args.cfg, 8), ('res50_coco', 8), ('swin_tiny_coco', 8)):
+                # bs=8 (BASELINE config 2 / 5): one batch at a time, and with 2 batches in flight (the same RequestPipeline)
                 n2, c2 = (net, cfg) if name == args.cfg else build_net(name, args.img_size, device)
                 w2 = Workload(n2, c2, b, args.img_size, device, with_post=not args.no_post)
                 t2 = timed(w2, 8, 2, lambda: None)
                 f2 = Workload(n2, c2, b, args.img_size, device, with_post=False)
                 tf2 = timed(f2, 8, 2, lambda: None) / 8
                 fl2 = f2.engine.total_flops
+                del w2, f2
+                w3 = Workload(n2, c2, b, args.img_size, device, with_post=not args.no_post, inflight=2)
+                t3 = timed(w3, 16, 4, lambda: None) / 16
+                del w3
+                f3 = Workload(n2, c2, b, args.img_size, device, with_post=False, inflight=2)
+                tf3 = timed(f3, 16, 4, lambda: None) / 16
+                del f3
                 if name.startswith('swin'):
                     fl2 += 1.8e9 * b          # attention matmuls (QK^T, PV), not run by the conv kernel
-                extra[f'{name}_bs{b}'] = dict(img_s=round(b * 8 / t2, 1), forward_only_img_s=round(b / tf2, 1),
-                                              forward_tflops=round(fl2 / tf2 / 1e12, 2),
-                                              frac_f32_mfma_peak=round(fl2 / tf2 / 1e12 / F32_MFMA_PEAK_TFLOPS, 4))
+                extra[f'{name}_bs{b}'] = dict(img_s=round(b / t3, 1), forward_only_img_s=round(b / tf3, 1),
+                                              forward_tflops=round(fl2 / tf3 / 1e12, 2),
+                                              frac_f32_mfma_peak=round(fl2 / tf3 / 1e12 / F32_MFMA_PEAK_TFLOPS, 4), batches_in_flight=2,
+                                              one_batch_at_a_time=dict(img_s=round(b * 8 / t2, 1), forward_only_img_s=round(b / tf2, 1),
+                                                                       frac_f32_mfma_peak=round(fl2 / tf2 / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)))
         if not args.no_extra and world == 1:
             extra['post'] = post_bench(net, cfg, device, args.img_size)
+            if args.batch == 1 and not args.no_post:
+                extra['chained'] = chained_bench(args.cfg, args.img_size, device, inflight)
             # split-bf16 fast modes (ym_conv_desc.mma): same plan, same fp32 tensors, products on the bf16 MFMA.  bf16x3 holds the
             # reference's 544 px goldens inside the 1e-4 bar (tests/test_gpu_forward.py::test_forward_544_bs8_split_bf16_modes_...);
             # `value` above stays the f32 parity mode.  Roofline here: 3 (6) bf16 MFMA flops per algorithmic flop vs 2.5 PF dense.
@@ -634,7 +653,7 @@ def main():
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'{args.cfg} 544x544 (the reference\'s "550-class" size) bs={args.batch} inference: '
                                    f'forward + nms + after_nms(480x640) per image'
-                                   + (f', {inflight} independent bs=1 requests in flight on {inflight} HIP streams' if inflight > 1 else '')
+                                   + (f', {inflight} independent bs={args.batch} requests in flight on {inflight} HIP streams' if inflight > 1 else '')
                                    if not args.no_post else
                                    f'{args.cfg} 544x544 bs={args.batch} forward only',
                        'global_batch': args.batch * world, 'parallelism': f'replicas x{world} (inference does not shard)',

@@ -129,11 +129,12 @@ def test_train_aug_matches_oracle_chain(seed, h, w, n, size):
 
 
 def test_requests_in_flight_give_the_single_request_results():
-    """bench.py's bs=1 serving mode (`--inflight 2`): two independent requests overlap on two HIP streams, each with its own
-    engine (activations, split-K scratch, arrival counters, hipGraph) and its own post-processing scratch.  Every request must
-    return exactly what the one-at-a-time path returns: the forward outputs bit for bit, and ids / scores / pixel boxes / masks
-    of `nms` + `after_nms`."""
+    """`RequestPipeline` (bench.py's bs=1 serving mode, `--inflight 4`): independent requests overlap on separate HIP streams,
+    each with its own engine (activations, split-K scratch, arrival counters, hipGraph) and its own post-processing scratch.
+    Every request must return exactly what the one-at-a-time path returns: the forward outputs bit for bit, and ids / scores /
+    pixel boxes / masks of `nms` + `after_nms` -- on synthetic head outputs and on the forward's own outputs."""
     import bench
+    from yolact_minimal_amd.pipeline import RequestPipeline
     from yolact_minimal_amd.utils.output_utils import nms, after_nms
     dev = torch.device(DEV)
     net, cfg = bench.build_net('res50_coco', 256, dev)
@@ -144,24 +145,31 @@ def test_requests_in_flight_give_the_single_request_results():
     cls, box, coef, proto = one.head
     r = nms(cls, box, coef, proto, one.anchors, cfg)
     want = after_nms(r[0], r[1], r[2].clone(), r[3], r[4], 480, 640, cfg)
-    two = bench.Workload(net, cfg, 1, 256, dev, with_post=True, inflight=2)
-    for it in range(7):
-        slot = two.i % 2
-        got = two._finish(slot) if two.pending[slot] is not None else None
-        two.step()                   # (finishes the slot itself when something is pending: call _finish first to keep the result)
-        if got is not None:
-            for a, b in zip(got, want):
-                assert torch.equal(a, b), it
-    for slot in range(2):
-        got = two._finish(slot)
-        assert got is not None
+    pipe = RequestPipeline(net, cfg, 256, 256, dev, depth=3, out_hw=(480, 640))
+    pipe.warm_up(one.img)
+    results = []
+    for it in range(8):
+        done = pipe.submit(one.img, one.head)
+        assert (done is None) == (it < 3)
+        if done is not None:
+            results.append(done)
+    results += pipe.drain()
+    assert len(results) == 8 and pipe.detections == 8 * int(want[0].shape[0])
+    for got in results:
         for a, b in zip(got, want):
             assert torch.equal(a, b)
     torch.cuda.synchronize()
-    for e in two.engines:
+    for e in pipe.engines:
         for a, b in zip(e.outputs(), want_fwd):
             assert torch.equal(a, b)
-    assert two.detections == 7 * int(want[0].shape[0])          # 7 requests were issued, each read back once
+    # post-processing of the forward's own outputs (a random-init net: whatever passes the threshold, possibly nothing)
+    r2 = nms(*want_fwd, one.anchors, cfg)
+    want2 = after_nms(r2[0], r2[1], r2[2].clone() if r2[2] is not None else None, r2[3], r2[4], 480, 640, cfg)
+    for it in range(4):
+        pipe.submit(one.img)
+    for got in pipe.drain():
+        for a, b in zip(got, want2):
+            assert (a is None and b is None) or torch.equal(a, b)
 
 
 def test_chained_forward_nms_after_nms_matches_the_reference(golden_dir):

@@ -1,0 +1,105 @@
+"""Serving with several independent requests in flight on one MI355X (batch 1: 325 -> 594 img/s; batch 8: 673 -> 739 forward-only).
+
+The reference evaluates one image at a time (`eval.py:36-69`: forward -> nms -> after_nms, a device synchronisation around each).
+On this part a bs=1 forward is a chain of ~190 dependent launches of 0.6-1.4 GFLOP each: every launch pays a kernel boundary, an
+address set-up + cold-L2 round trip and an epilogue (~9 us) around ~7 us of MFMA work, so ONE chain keeps the matrix pipe ~35 %
+busy whatever the kernels do.  Requests are independent, so the way to fill the chip at batch size 1 is to have several of them in
+flight: `RequestPipeline` owns `depth` complete engines (activations, split-K scratch, arrival counters, hipGraph: nothing shared
+but the read-only weights) and `depth` HIP streams, and runs request i on slot i % depth.  Each request is still ONE image through
+`Yolact.forward` -> `nms` -> `after_nms` with ONE host read (its detection count, which `after_nms` needs to size what it returns);
+the count is copied to pinned host memory behind the request and read when the slot comes up again, so the host never waits on
+the request it has just enqueued.
+
+Measured (res101_coco 544 px, MI355X, forward + nms + after_nms(480x640)): depth 1: 325 img/s, 2: 468, 3: 545, 4: 594, 5: 495,
+8: 479 -- the part schedules four compute pipes; GPU_MAX_HW_QUEUES must be >= depth + 1 (ROCm multiplexes HIP streams onto 4
+hardware queues by default and two streams that share a queue do not overlap): set it to 8 before the first HIP call.
+"""
+import torch
+
+from .engine import InferEngine
+from .utils.output_utils import nms_batch, after_nms_batch
+
+_streams = {}
+
+
+def _stream_set(device, n):
+    """One process-wide set of streams per device: every pipeline overlaps on the SAME streams (= the same hardware queues)."""
+    key = torch.device(device)
+    lst = _streams.setdefault(key, [])
+    while len(lst) < n:
+        lst.append(torch.cuda.Stream(device=device))
+    return lst[:n]
+
+
+class RequestPipeline:
+    def __init__(self, net, cfg, height, width, device, depth=4, out_hw=(480, 640), with_post=True, batch=1):
+        self.net, self.cfg, self.device, self.depth, self.batch = net, cfg, torch.device(device), depth, batch
+        self.out_hw, self.with_post = out_hw, with_post
+        self.engines = [InferEngine(net, batch, height, width, device) for _ in range(depth)]
+        self.streams = _stream_set(device, depth)
+        self.counts_host = [torch.zeros(batch, dtype=torch.int32).pin_memory() for _ in range(depth)]
+        self.events = [torch.cuda.Event() for _ in range(depth)]
+        self.pending = [None] * depth
+        self.anchors = torch.tensor(net.anchors, dtype=torch.float32).reshape(-1, 4).to(device) \
+            if not torch.is_tensor(net.anchors) else net.anchors.to(device)
+        self.submitted = 0
+        self.detections = 0
+
+    def warm_up(self, img):
+        """Capture every slot's hipGraph (first run of an engine) outside any timed region."""
+        torch.cuda.synchronize(self.device)
+        for e, st in zip(self.engines, self.streams):
+            with torch.cuda.stream(st):
+                e.run(img)
+        torch.cuda.synchronize(self.device)
+
+    def finish(self, slot):
+        """Result of the request that last used `slot`: (ids, scores, boxes_px, masks) like `after_nms` (None x 4 without
+        detections; a list of such tuples, one per image, when batch > 1), or None if the slot is idle.  Without post-processing:
+        the slot's four network outputs."""
+        pend = self.pending[slot]
+        if pend is None:
+            return None
+        self.pending[slot] = None
+        if not self.with_post:
+            pend.synchronize()
+            return self.engines[slot].outputs()
+        ids, scores, box_px, masks, counts, ev = pend
+        ev.synchronize()                                  # THIS request only
+        out = []
+        for b, n in enumerate(self.counts_host[slot].tolist()):
+            self.detections += n
+            out.append((ids[b, :n], scores[b, :n], box_px[b, :n], masks[b, :n]) if n else (None, None, None, None))
+        return out[0] if self.batch == 1 else out
+
+    def submit(self, img, head_outputs=None):
+        """Enqueue one request ([batch,3,H,W] images, device resident) on the next slot and return the finished result of the request
+        that used this slot before (None the first `depth` times).  `head_outputs`: post-process these (class, box, coef, proto)
+        tensors instead of the forward's own outputs (bench.py: a random-init network yields degenerate detections)."""
+        slot = self.submitted % self.depth
+        self.submitted += 1
+        done = self.finish(slot)
+        ev = self.events[slot]
+        with torch.cuda.stream(self.streams[slot]):
+            eng = self.engines[slot]
+            eng.run(img)
+            if self.with_post:
+                cls, box, coef, proto = head_outputs if head_outputs is not None else eng.outputs()
+                r = after_nms_batch(nms_batch(cls, box, coef, proto, self.anchors, self.cfg), self.out_hw[0], self.out_hw[1], self.cfg,
+                                    sync=False)
+                self.counts_host[slot].copy_(r[4], non_blocking=True)
+                ev.record()
+                self.pending[slot] = r + (ev,)
+            else:
+                ev.record()
+                self.pending[slot] = ev
+        return done
+
+    def drain(self):
+        """Finish everything in flight, oldest first."""
+        out = []
+        for k in range(self.depth):
+            r = self.finish((self.submitted + k) % self.depth)
+            if r is not None:
+                out.append(r)
+        return out
