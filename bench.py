@@ -530,12 +530,12 @@ def main():
         flops, conv_secs, launches, layers = conv_roofline(fw.engine, fw.img)
         achieved = flops / conv_secs / 1e12
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(REPO, 'profiles', 'r02_pmc_hbm_infer_bs1_res101.json')
+        pmc_path = os.path.join(REPO, 'profiles', 'r03_pmc_hbm_infer_bs1_res101.json')
         if args.cfg == 'res101_coco' and args.batch == 1 and os.path.exists(pmc_path):
             # HBM-side bytes per conv launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2
             # gfx950 correction + WRITE_SIZE); not re-measured live (bench.py cannot wrap itself in rocprofv3)
             traffic = round(json.load(open(pmc_path))['conv_kernels']['traffic_bytes_per_launch'])
-            traffic_src = 'profiles/r02_pmc_hbm_infer_bs1_res101.json'
+            traffic_src = 'profiles/r03_pmc_hbm_infer_bs1_res101.json'
         # `achieved`: the conv kernels' algorithmic flops over the GRAPH-REPLAY forward (the path `value` times; its few non-conv
         # kernels — layout, max-pool, 3 upsamples, softmax: ~2 % — are left in the denominator, so this is a lower bound that agrees
         # with the rocprofv3 kernel trace under profiles/).  The eager per-launch HIP-event figure is kept beside it.

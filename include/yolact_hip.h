@@ -85,7 +85,7 @@ typedef struct {
     int32_t stages;          /* workgroup kernel operand staging: 0/2 = registers, double buffer; 3 = registers, loads two K tiles
                                 ahead (64-wide tiles); 22/23/24 = direct global->LDS DMA, ring of 2/3/4 (24: 64x64 tile only);
                                 42/43/44/46/48 = PERSISTENT direct-to-LDS kernel, ring of 2/3/4/6/8 (64x64 tile, plain NHWC
-                                output, ReLU or no activation; anything else falls back to 22/23/24): grid_wgs workgroups walk
+                                output, ReLU or no activation, no bn_sum; anything else falls back to 22/23/24): grid_wgs workgroups walk
                                 the (tile, K slice) items and the operand stream runs on across item boundaries */
     double* bn_sum;          /* optional [Cout] fp64 accumulators (zeroed by the caller): the epilogue adds the */
     double* bn_sumsq;        /* per-channel sum / sum of squares of the conv OUTPUT (train-mode BN statistics).  */

@@ -114,6 +114,6 @@ __device__ __forceinline__ void epilogue_store(const ConvP& p, int m, int n, flo
 // conv_wave.hip: wave-private kernel; returns YM_OK / YM_EINVAL (unsupported variant)
 int ym_launch_conv_wave(const ymk::ConvP& p, int tm, int tn, int kwaves, hipStream_t st);
 // conv_persist.hip: persistent direct-to-LDS kernel (ring of `ns` K tiles, `grid` workgroups walk p.total_items work items);
-// mode 0 = convolution, 2 = data gradient; stats = the launch fuses BatchNorm sums (bn_sum / bnb_*).  YM_EINVAL: no such variant.
-int ym_launch_conv_pers(const ymk::ConvP& p, int bm, int bn, int mode, int ns, bool stats, int grid, hipStream_t st);
+// mode 0 = convolution, 2 = data gradient; launches with fused BatchNorm sums are not covered.  YM_EINVAL: no such variant.
+int ym_launch_conv_pers(const ymk::ConvP& p, int bm, int bn, int mode, int ns, int grid, hipStream_t st);
 size_t ym_conv_pers_lds_bytes(int bm, int bn, int ns);

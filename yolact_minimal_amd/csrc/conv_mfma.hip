@@ -1010,7 +1010,7 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
         const int ns = stages - 40;
         const int act = d->seg[0].act;
         const bool ok = p.vec && pl.bm == 64 && pl.bn == 64 && d->Cin % 32 == 0 && d->nlevels == 0 && d->mma == 0 &&
-                        (act == YM_ACT_NONE || act == YM_ACT_RELU) && (pl.slots() == 1 || p.counters) &&
+                        (act == YM_ACT_NONE || act == YM_ACT_RELU) && (pl.slots() == 1 || p.counters) && d->bn_sum == nullptr &&
                         (ns == 2 || ns == 3 || ns == 4 || ns == 6 || ns == 8);
         if (ok) {
             static int cus = 0;
@@ -1025,7 +1025,7 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
             int g = d->grid_wgs > 0 ? d->grid_wgs : cus * per_cu;
             if (g > grid) g = grid;
             if (g >= 8 && g < grid) g &= ~7;                  // a workgroup's items then all lie in its own XCD's chunk of the tile space
-            return ym_launch_conv_pers(p, 64, 64, d->transposed ? 2 : 0, ns, d->bn_sum != nullptr, g, st);
+            return ym_launch_conv_pers(p, 64, 64, d->transposed ? 2 : 0, ns, g, st);
         }
         stages = ns >= 4 && pl.bm == 64 && pl.bn == 64 && !d->transposed ? 24 : (ns == 2 ? 22 : 23);
     }

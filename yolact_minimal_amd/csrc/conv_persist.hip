@@ -14,9 +14,12 @@
 //     targets until the next item's first iteration): 64x64 fp32 = exactly one 16 KB stage, so the ring depth is the whole LDS
 //     bill -- NS = 3 -> 48 KB = 3 workgroups per CU, NS = 8 -> 128 KB for the batch-1 regime, where a launch has about one item
 //     per CU, every access misses the (per-launch cold) L2 and a lone wave per SIMD must have ~2 us of operands in flight.
-//   * Lean code: ReLU / identity only, BatchNorm statistics only in the STATS instantiation (conv_igemm_f32<64,64,...> is 36 KB
-//     of code, mostly tanh / erf / fp64 paths it does not execute; a bs=1 launch runs its prologue and epilogue instruction-cache
-//     cold).
+//   * Lean code (10 KB against 36 KB for conv_igemm_f32<64,64,...>): ReLU / identity only and NO fused BatchNorm statistics.  A
+//     launch that carries them (ym_conv_desc.bn_sum: the training forward and most data gradients) stays on the per-item kernel:
+//     an instantiation with the statistics epilogue was built and measured 3x SLOWER than that kernel (150 vs 50 us for the
+//     layer3 data gradients, MFMA-busy 0.27): the column sums re-read dout / y / out from L2 and add fp64 atomics per item, and
+//     a persistent workgroup sits through that latency itself (3 resident workgroups per CU, phases correlated), where the
+//     per-item kernel has a fourth workgroup and freshly dispatched ones to cover it.
 //
 // Work decomposition, K-slice exchange (agent-scope `sc1` stores + arrival counter, last arriver sums in slice order), tail split
 // and XCD-aware tile order are those of conv_mfma.hip: item b here is blockIdx.x == b there.  With grid % 8 == 0 a workgroup's
@@ -40,7 +43,7 @@ __device__ __forceinline__ void wg_sync_lds() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int BM, int BN, int MODE, int NS, bool STATS>
+template <int BM, int BN, int MODE, int NS>
 __global__ __launch_bounds__(256) void conv_igemm_pers(const ConvP p) {
     static_assert(BM == 64 && BN == 64, "the accumulator staging aliases one ring stage: (BM + BN) * 128 B == BM * BN * 4 B");
     static_assert(MODE == 0 || MODE == 2, "Cin % 32 == 0 convolution / data gradient");
@@ -325,7 +328,6 @@ __global__ __launch_bounds__(256) void conv_igemm_pers(const ConvP p) {
             wg_sync_lds();
             finish = *s_flag != 0;
         }
-        double bsum[4] = {0.0, 0.0, 0.0, 0.0}, bsq[4] = {0.0, 0.0, 0.0, 0.0};
         if (finish && n < p.Cout) {
             f32x4 sc = pre_sc, sh = pre_sh;
             if (!direct) {
@@ -333,7 +335,6 @@ __global__ __launch_bounds__(256) void conv_igemm_pers(const ConvP p) {
                 if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
             }
             float* outb = p.seg[0].out + n;
-            const bool fwd_stats = STATS && p.bn_sum != nullptr && p.bnb_y == nullptr;
 #pragma unroll
             for (int rk = 0; rk < ENR; ++rk) {
                 const int row = row0 + rk * RPP;
@@ -361,64 +362,7 @@ __global__ __launch_bounds__(256) void conv_igemm_pers(const ConvP p) {
                         for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];   // NaN stays NaN, like torch.relu
                     }
                     *reinterpret_cast<f32x4*>(outb + (size_t)m * p.Cout) = v;
-                    if (fwd_stats) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { const double dv = v[e]; bsum[e] += dv; bsq[e] += dv * dv; }
-                    }
                 }
-            }
-            if (STATS && p.bnb_y) {
-                // BN-BACKWARD sums of the layer whose output gradient this item just wrote (ym_conv_desc.bnb_*): a rolled loop that
-                // re-reads this lane's own float4s of dout (L2 hits) together with y (and out for the ReLU mask)
-                const f32x4 b_mu = *reinterpret_cast<const f32x4*>(p.bnb_mean + n), b_is = *reinterpret_cast<const f32x4*>(p.bnb_invstd + n);
-                f32x4 b_g = {1.f, 1.f, 1.f, 1.f}, b_bt = {0.f, 0.f, 0.f, 0.f};
-                const bool remask = p.bnb_relu && !p.bnb_out;
-                if (remask) { b_g = *reinterpret_cast<const f32x4*>(p.bnb_gamma + n); b_bt = *reinterpret_cast<const f32x4*>(p.bnb_beta + n); }
-                constexpr int UR = 2;
-#pragma unroll 1
-                for (int rk0 = 0; rk0 < ENR; rk0 += UR) {
-                    f32x4 dv[UR], yy[UR], o[UR];
-#pragma unroll
-                    for (int u = 0; u < UR; ++u) {
-                        const int m = m0 + row0 + (rk0 + u) * RPP;
-                        const size_t off = (size_t)(m < p.M ? m : p.M - 1) * p.Cout + n;       // (rows past the end: a valid address, value unused)
-                        dv[u] = *reinterpret_cast<const f32x4*>(p.seg[0].out + off);
-                        yy[u] = *reinterpret_cast<const f32x4*>(p.bnb_y + off);
-                        if (p.bnb_out) o[u] = *reinterpret_cast<const f32x4*>(p.bnb_out + off);
-                    }
-#pragma unroll
-                    for (int u = 0; u < UR; ++u) {
-                        if (m0 + row0 + (rk0 + u) * RPP >= p.M) continue;
-                        if (!p.bnb_out) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[u][e] = remask ? bn_affine(yy[u][e], b_mu[e], b_is[e], b_g[e], b_bt[e]) : 1.f;
-                        }
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const double dd = o[u][e] > 0.f ? dv[u][e] : 0.f;
-                            bsum[e] += dd;
-                            bsq[e] += dd * (double)((yy[u][e] - b_mu[e]) * b_is[e]);
-                        }
-                    }
-                }
-            }
-        }
-        if (STATS && p.bn_sum && finish) {
-            // fused BatchNorm statistics: per-workgroup column sums of the tile (fp64), then one fp64 atomic per channel
-            wg_sync_lds();                         // every lane is done reading the staged tile
-            double* R = reinterpret_cast<double*>(C);      // [RPP][BN][2] doubles = 16 KB = the same stage
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                R[((row0 * BN) + col4 * 4 + e) * 2 + 0] = bsum[e];
-                R[((row0 * BN) + col4 * 4 + e) * 2 + 1] = bsq[e];
-            }
-            wg_sync_lds();
-            if (tid < BN && n0 + tid < p.Cout) {
-                double S = 0.0, Q = 0.0;
-#pragma unroll
-                for (int r = 0; r < RPP; ++r) { S += R[(r * BN + tid) * 2]; Q += R[(r * BN + tid) * 2 + 1]; }
-                atomicAdd(p.bn_sum + n0 + tid, S);
-                atomicAdd(p.bn_sumsq + n0 + tid, Q);
             }
         }
         wg_sync_lds();                             // stage `nb` is free again: the next item's first dma_next re-stages it
@@ -426,27 +370,27 @@ __global__ __launch_bounds__(256) void conv_igemm_pers(const ConvP p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the run-ahead loads of "no work left" still target this workgroup's LDS
 }
 
-template <int BM, int BN, int MODE, int NS, bool STATS>
+template <int BM, int BN, int MODE, int NS>
 int launch_pers(const ConvP& p, int grid, hipStream_t st) {
     const size_t lds = ym_conv_pers_lds_bytes(BM, BN, NS);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_pers<BM, BN, MODE, NS, STATS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_pers<BM, BN, MODE, NS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_pers<BM, BN, MODE, NS, STATS>), dim3(grid), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv_igemm_pers<BM, BN, MODE, NS>), dim3(grid), dim3(256), lds, st, p);
     return ym_check_launch("conv_igemm_pers");
 }
 
-template <int MODE, bool STATS>
+template <int MODE>
 int launch_pers_ns(const ConvP& p, int ns, int grid, hipStream_t st) {
     switch (ns) {
-        case 2: return launch_pers<64, 64, MODE, 2, STATS>(p, grid, st);
-        case 3: return launch_pers<64, 64, MODE, 3, STATS>(p, grid, st);
-        case 4: return launch_pers<64, 64, MODE, 4, STATS>(p, grid, st);
-        case 6: return launch_pers<64, 64, MODE, 6, STATS>(p, grid, st);
-        case 8: return launch_pers<64, 64, MODE, 8, STATS>(p, grid, st);
+        case 2: return launch_pers<64, 64, MODE, 2>(p, grid, st);
+        case 3: return launch_pers<64, 64, MODE, 3>(p, grid, st);
+        case 4: return launch_pers<64, 64, MODE, 4>(p, grid, st);
+        case 6: return launch_pers<64, 64, MODE, 6>(p, grid, st);
+        case 8: return launch_pers<64, 64, MODE, 8>(p, grid, st);
         default: ym_set_error("conv(persistent): ring depth %d not built (2, 3, 4, 6, 8)", ns); return YM_EINVAL;
     }
 }
@@ -455,11 +399,10 @@ int launch_pers_ns(const ConvP& p, int ns, int grid, hipStream_t st) {
 
 size_t ym_conv_pers_lds_bytes(int bm, int bn, int ns) { return (size_t)ns * (bm + bn) * 32 * sizeof(float) + 16; }
 
-int ym_launch_conv_pers(const ConvP& p, int bm, int bn, int mode, int ns, bool stats, int grid, hipStream_t st) {
+int ym_launch_conv_pers(const ConvP& p, int bm, int bn, int mode, int ns, int grid, hipStream_t st) {
     if (bm != 64 || bn != 64 || (mode != 0 && mode != 2)) {
         ym_set_error("conv(persistent): 64x64 tile, convolution or data gradient only (got %dx%d mode %d)", bm, bn, mode);
         return YM_EINVAL;
     }
-    if (mode == 0) return stats ? launch_pers_ns<0, true>(p, ns, grid, st) : launch_pers_ns<0, false>(p, ns, grid, st);
-    return stats ? launch_pers_ns<2, true>(p, ns, grid, st) : launch_pers_ns<2, false>(p, ns, grid, st);
+    return mode == 0 ? launch_pers_ns<0>(p, ns, grid, st) : launch_pers_ns<2>(p, ns, grid, st);
 }

@@ -56,9 +56,11 @@ def _time_launch(fn, iters=5):
     return best
 
 
-def _configure_conv(d, key):
-    """Set tile/ksplit/kwaves of a ConvDesc from the tuned table (or sweep it when YM_TUNE_TRAIN=1)."""
-    hit = _table().get(key)
+def _configure_conv(d, key, stats=False):
+    """Set tile/ksplit/kwaves of a ConvDesc from the tuned table (or sweep it when YM_TUNE_TRAIN=1).  `stats`: the launch carries
+    fused BatchNorm sums, which the persistent kernel does not do: `<key>_st` holds the per-item choice measured for such launches
+    where the plain entry (shared with inference) selects the persistent kernel."""
+    hit = (_table().get(key + '_st') if stats else None) or _table().get(key)
     if hit is None and _TUNING:
         M, nkt = d.B * d.Ho * d.Wo, d.k_pad // 32
         big = scratch(torch.device('cuda', torch.cuda.current_device()), 1 << 28)
@@ -372,7 +374,7 @@ def _conv_forward(x, wp, k_pad, cout_pad, kh, kw, stride, pad, shift, act, resid
             for i, sg in enumerate(segs):
                 d.seg[i].out = sg[2]
         if cin != 4:
-            _configure_conv(d, f'M{b * ho * wo}_N{cout_pad}_C{cin}_k{kh}_s{stride}_seg{d.nseg}_r{int(residual is not None)}')
+            _configure_conv(d, f'M{b * ho * wo}_N{cout_pad}_C{cin}_k{kh}_s{stride}_seg{d.nseg}_r{int(residual is not None)}', stats=bn_stats is not None)
         d.tile_counters = _tile_counters(x.device)
         fuses = bn_stats is not None and hip.lib().ym_conv2d_fuses_bn_stats(ctypes.byref(d)) == 1
         ent = _desc_cache[key] = (d, fuses, hip.conv_workspace_bytes(d))
