@@ -7,14 +7,17 @@ import json
 import os
 import sys
 
-import torch
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+import torch  # noqa: E402
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from yolact_minimal_amd.engine import tuned_table  # noqa: E402
 
 dev = torch.device('cuda:0')
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 name = sys.argv[1] if len(sys.argv) > 1 else 'res101_coco'
+COPIES = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 net, cfg = bench.build_net(name, 544, dev)
 
 
@@ -25,15 +28,15 @@ def throughput(inflight):
     return 1.0 / t
 
 
-before = {s: throughput(s) for s in (1, 2)}
+before = {s: throughput(s) for s in (1, COPIES)}
 print('as tuned (per-launch latency):', {k: round(v, 1) for k, v in before.items()}, flush=True)
 net._engines.clear()
 eng = net._engine(torch.randn(1, 3, 544, 544, device=dev))
-res = eng.autotune(10, verbose=True, concurrent=True)
+res = eng.autotune(10, verbose=True, concurrent=COPIES)
 saved = {k: tuned_table().get(k) for k in res}
 tuned_table().update({k: v[:7] for k, v in res.items()})
-after = {s: throughput(s) for s in (1, 2)}
+after = {s: throughput(s) for s in (1, COPIES)}
 print('tuned with two copies side by side:', {k: round(v, 1) for k, v in after.items()}, flush=True)
 os.makedirs('gpurun_out', exist_ok=True)
-json.dump({k + '_c2': v[:7] for k, v in res.items() if v[:7] != (saved.get(k) or [])[:7]}, open('gpurun_out/tuned_c2.json', 'w'), indent=0, sort_keys=True)
-json.dump(dict(before=before, after=after, detail=res), open('gpurun_out/tuned_c2_detail.json', 'w'), indent=0, sort_keys=True)
+json.dump({k + f'_c{COPIES}': v[:7] for k, v in res.items() if v[:7] != (saved.get(k) or [])[:7]}, open(f'gpurun_out/tuned_c{COPIES}.json', 'w'), indent=0, sort_keys=True)
+json.dump(dict(before=before, after=after, detail=res), open(f'gpurun_out/tuned_c{COPIES}_detail.json', 'w'), indent=0, sort_keys=True)

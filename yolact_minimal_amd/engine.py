@@ -517,17 +517,22 @@ class InferEngine:
         results = {}
         big_ws = torch.empty(1 << 28, device=self.device, dtype=torch.uint8)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ncopy = int(concurrent) if concurrent else 1        # True = 2 copies
+        if ncopy == 1 and concurrent:
+            ncopy = 2
         if concurrent:
-            side = torch.cuda.Stream(device=self.device)
-            big_ws2 = torch.empty(1 << 28, device=self.device, dtype=torch.uint8)
-            counters2 = torch.zeros(hip.TILE_COUNTERS, device=self.device, dtype=torch.int32)
+            from .pipeline import _stream_set
+            sides = _stream_set(self.device, ncopy - 1)
+            big_ws2 = [torch.empty(1 << 27, device=self.device, dtype=torch.uint8) for _ in sides]
+            counters2 = [torch.zeros(hip.TILE_COUNTERS, device=self.device, dtype=torch.int32) for _ in sides]
             main = torch.cuda.current_stream(self.device)
 
         def launch(d, d2):
             hip.conv2d_fwd(d, big_ws)
-            if concurrent:                       # (same inputs and outputs: both copies write the same values; scratch + counters differ)
-                with torch.cuda.stream(side):
-                    hip.conv2d_fwd(d2, big_ws2)
+            if concurrent:                       # (same inputs and outputs: all copies write the same values; scratch + counters differ)
+                for i, side in enumerate(sides):
+                    with torch.cuda.stream(side):
+                        hip.conv2d_fwd(d2[i], big_ws2[i])
 
         def time_cfg(c, tile, ks, kwv=0, stg=0, tail=(0, 0)):
             d = c.desc
@@ -539,9 +544,12 @@ class InferEngine:
                 return None
             d2 = None
             if concurrent:
-                d2 = type(d).from_buffer_copy(d)
-                if d.tile_counters:
-                    d2.tile_counters = counters2.data_ptr()
+                if need > big_ws2[0].numel():
+                    return None
+                d2 = [type(d).from_buffer_copy(d) for _ in sides]
+                for i, dd in enumerate(d2):
+                    if d.tile_counters:
+                        dd.tile_counters = counters2[i].data_ptr()
             try:
                 for _ in range(2):
                     launch(d, d2)
@@ -554,7 +562,8 @@ class InferEngine:
                 for _ in range(iters):
                     launch(d, d2)
                 if concurrent:
-                    main.wait_stream(side)
+                    for side in sides:
+                        main.wait_stream(side)
                 ev1.record()
                 torch.cuda.synchronize()
                 best = min(best, ev0.elapsed_time(ev1) / iters * 1e3)

@@ -12,6 +12,7 @@ head outputs (matching, OHEM ranking, cross-entropy, smooth-L1, mask BCE) is `yo
 """
 import ctypes
 import os
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -269,8 +270,12 @@ class _PackCache:
 
     def refresh(self):
         """Re-pack every live image in one launch."""
-        for hook in list(_pre_refresh_hooks):                # derived weights (the concatenated head filter) follow their sources first
-            hook()
+        for ref in list(_pre_refresh_hooks):                 # derived weights (the concatenated head filter) follow their sources first
+            obj = ref()
+            if obj is None:                                  # its module is gone: drop the hook
+                _pre_refresh_hooks.remove(ref)
+            else:
+                obj.sync()
         dead = [k for k, e in self.entries.items() if e['ref']() is None]
         for k in dead:
             del self.entries[k]
@@ -299,7 +304,7 @@ class _PackCache:
             e['stamp'] = (owner._version, _EPOCH[0])
 
 
-_pre_refresh_hooks = []     # callables run before a batched re-pack (see _HeadWeights)
+_pre_refresh_hooks = []     # weak references to objects whose .sync() runs before a batched re-pack (see _HeadWeights)
 _pack_caches = {}          # one cache (and one device-side table) per device
 
 
@@ -689,7 +694,7 @@ class _HeadWeights:
     Their OIHW weights / biases are kept concatenated in persistent buffers that follow the parameters: three contiguous
     device-to-device copies per optimizer step (before the batched re-pack of the weight images) instead of a `torch.cat` with
     its autograd node, allocation and backward split every forward."""
-    _by_module = {}
+    _by_module = weakref.WeakKeyDictionary()      # PredictionModule -> its _HeadWeights: a rebuilt / collected net leaves nothing behind
 
     def __init__(self, hd, pad):
         convs = (hd.conf_layer, hd.bbox_layer, hd.coef_layer[0])
@@ -701,14 +706,13 @@ class _HeadWeights:
         self.b = torch.zeros(pad, device=w0.device, dtype=torch.float32)
         self.w._ym_grad_slot = self.w           # marks the buffer as "refreshed only by its owner" for the pack cache
         self.stamp = None
-        _pre_refresh_hooks.append(self.sync)
+        _pre_refresh_hooks.append(weakref.ref(self))
 
     @classmethod
     def of(cls, hd, pad):
-        key = id(hd)
-        e = cls._by_module.get(key)
+        e = cls._by_module.get(hd)
         if e is None or e.convs[0].weight.device != e.w.device or e.convs[0] is not hd.conf_layer:
-            e = cls._by_module[key] = cls(hd, pad)
+            e = cls._by_module[hd] = cls(hd, pad)
         return e
 
     def sync(self):
