@@ -18,10 +18,15 @@ from .box_utils import box_iou, mask_iou
 
 
 class APDataObject:
-    """Stores all the information necessary to calculate the AP for one IoU and one class (common_utils.py:107-169)."""
+    """Accumulator of one (IoU type, IoU threshold, class) cell of the mAP table: the (score, hit?) pairs of every prediction and
+    the number of ground-truth instances.  Same public surface as the reference's bookkeeping class (`utils/common_utils.py:107-171`:
+    `push`, `add_gt_positives`, `is_empty`, `get_ap`, `data_points`, `num_gt_positives`); `get_ap` is evaluated on arrays and returns
+    the reference's value bit for bit (pinned by tests/golden/metrics.npz: the divisions are the same IEEE operations and the
+    101 samples are added in the same order)."""
+    RECALL_GRID = np.arange(101) / 100                      # COCO's 101 recall thresholds 0.00 ... 1.00
 
     def __init__(self):
-        self.data_points = []
+        self.data_points = []                               # [(score, is_true_positive)]
         self.num_gt_positives = 0
 
     def push(self, score, is_true):
@@ -31,31 +36,25 @@ class APDataObject:
         self.num_gt_positives += num_positives
 
     def is_empty(self):
-        return len(self.data_points) == 0 and self.num_gt_positives == 0
+        return not self.data_points and self.num_gt_positives == 0
 
     def get_ap(self):
+        """Area under the monotone precision envelope sampled at the 101 recall thresholds (a threshold beyond the reached recall
+        contributes 0)."""
         if self.num_gt_positives == 0:
             return 0
-        self.data_points.sort(key=lambda x: -x[0])
-        precisions, recalls = [], []
-        num_true = num_false = 0
-        for datum in self.data_points:
-            if datum[1]:
-                num_true += 1
-            else:
-                num_false += 1
-            precisions.append(num_true / (num_true + num_false))
-            recalls.append(num_true / self.num_gt_positives)
-        for i in range(len(precisions) - 1, 0, -1):          # monotone envelope, like COCOeval
-            if precisions[i] > precisions[i - 1]:
-                precisions[i - 1] = precisions[i]
-        y_range = [0] * 101                                   # 101-point Riemann sum over recall 0.00 .. 1.00
-        x_range = np.array([x / 100 for x in range(101)])
-        indices = np.searchsorted(np.array(recalls), x_range, side='left')
-        for bar_idx, precision_idx in enumerate(indices):
-            if precision_idx < len(precisions):
-                y_range[bar_idx] = precisions[precision_idx]
-        return sum(y_range) / len(y_range)
+        self.data_points.sort(key=lambda p: -p[0])          # (kept in place and stable, like the reference: callers look at it)
+        n = len(self.data_points)
+        if n == 0:
+            return 0.0
+        hits = np.fromiter((bool(p[1]) for p in self.data_points), dtype=np.int64, count=n)
+        tp = np.cumsum(hits)
+        precision = tp / np.arange(1, n + 1)                # tp / (tp + fp) after each prediction
+        recall = tp / self.num_gt_positives
+        envelope = np.maximum.accumulate(precision[::-1])[::-1]
+        first = np.searchsorted(recall, self.RECALL_GRID, side='left')      # first prediction that reaches each threshold
+        samples = np.where(first < n, envelope[np.minimum(first, n - 1)], 0.0)
+        return sum(samples.tolist()) / 101                  # left-to-right sum of python floats: the reference's rounding
 
 
 def match_detections(iou_box, iou_mask, ids_p, gt_classes, iou_thres, num_classes):
