@@ -110,7 +110,7 @@ def main():
         for ks in ksplits:
             items0 = tiles * ks
             for ns in (2, 3, 4, 6, 8):
-                lds = ns * 16384 + 16
+                lds = ns * 16384 + 16384 + 16          # ring + the deferred epilogue tile
                 for per_cu in (1, 2, 3, 4):
                     if per_cu * lds > 160 * 1024:
                         continue

@@ -115,5 +115,6 @@ __device__ __forceinline__ void epilogue_store(const ConvP& p, int m, int n, flo
 int ym_launch_conv_wave(const ymk::ConvP& p, int tm, int tn, int kwaves, hipStream_t st);
 // conv_persist.hip: persistent direct-to-LDS kernel (ring of `ns` K tiles, `grid` workgroups walk p.total_items work items);
 // mode 0 = convolution, 2 = data gradient; launches with fused BatchNorm sums are not covered.  YM_EINVAL: no such variant.
-int ym_launch_conv_pers(const ymk::ConvP& p, int bm, int bn, int mode, int ns, int grid, hipStream_t st);
-size_t ym_conv_pers_lds_bytes(int bm, int bn, int ns);
+// defer: the un-split item's stores are issued under the next item's MFMAs (costs a dedicated 16 KB accumulator tile in LDS).
+int ym_launch_conv_pers(const ymk::ConvP& p, int bm, int bn, int mode, int ns, bool defer, int grid, hipStream_t st);
+size_t ym_conv_pers_lds_bytes(int bm, int bn, int ns, bool defer);

@@ -975,6 +975,7 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
     p.trace = nullptr;
 #ifdef YM_TRACE
     if (const char* e = getenv("YM_TRACE_PTR")) p.trace = (long long*)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("YM_PERS_ABL")) { if (!d->bn_sum) p.bnb_relu = atoi(e); }      // conv_persist.hip ablations (trace build only)
 #endif
     p.counters = (p.vec && pl.slots() > 1 && d->kwaves == 0 && need < 0xFFFFFFF0ull) ? d->tile_counters : nullptr;
     YM_REQUIRE(pl.tail_tiles == 0 || p.counters, "conv: tail_tiles needs a plain NHWC output (vector epilogue) and a workspace < 4 GiB");
@@ -1019,13 +1020,15 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
                 if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
                 cus = n;
             }
-            int per_cu = (int)((160u << 10) / ym_conv_pers_lds_bytes(64, 64, ns));
+            static int defer = -1;                            // YM_PERS_DEFER=0: the synchronous epilogue (A/B experiments)
+            if (defer < 0) { const char* e = getenv("YM_PERS_DEFER"); defer = e ? atoi(e) : 1; }
+            int per_cu = (int)((160u << 10) / ym_conv_pers_lds_bytes(64, 64, ns, defer != 0));
             if (per_cu > 4) per_cu = 4;                       // 128 VGPRs: four waves per SIMD
             if (per_cu < 1) per_cu = 1;
             int g = d->grid_wgs > 0 ? d->grid_wgs : cus * per_cu;
             if (g > grid) g = grid;
             if (g >= 8 && g < grid) g &= ~7;                  // a workgroup's items then all lie in its own XCD's chunk of the tile space
-            return ym_launch_conv_pers(p, 64, 64, d->transposed ? 2 : 0, ns, g, st);
+            return ym_launch_conv_pers(p, 64, 64, d->transposed ? 2 : 0, ns, defer != 0, g, st);
         }
         stages = ns >= 4 && pl.bm == 64 && pl.bn == 64 && !d->transposed ? 24 : (ns == 2 ? 22 : 23);
     }

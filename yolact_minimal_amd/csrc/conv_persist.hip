@@ -43,7 +43,13 @@ __device__ __forceinline__ void wg_sync_lds() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int BM, int BN, int MODE, int NS>
+// DEFER: the un-split item's epilogue is split in two.  Part 1, at the end of its K loop, only moves the accumulators into a
+// dedicated 16 KB LDS tile and requests the residual / scale / shift operands; part 2 (read the tile row-major, affine + residual +
+// ReLU, 16-byte stores) runs inside the NEXT item's K loop, right after the barrier that ends its first K tile -- that barrier is
+// the one the tile exchange needs anyway.  The MFMAs of item i+1 therefore start immediately after item i's last one: co-resident
+// workgroups of one launch run phase-locked (same item length, same start), so without this all of them sat in their epilogues
+// at the same time with the matrix pipe idle (measured: K loop 10 us + epilogue 3.7 us per item at M = 9248, K = 256).
+template <int BM, int BN, int MODE, int NS, bool DEFER>
 __global__ __launch_bounds__(256) void conv_igemm_pers(const ConvP p) {
     static_assert(BM == 64 && BN == 64, "the accumulator staging aliases one ring stage: (BM + BN) * 128 B == BM * BN * 4 B");
     static_assert(MODE == 0 || MODE == 2, "Cin % 32 == 0 convolution / data gradient");
@@ -59,7 +65,8 @@ __global__ __launch_bounds__(256) void conv_igemm_pers(const ConvP p) {
     static_assert((AR + BR) * (D - 1) < 64, "vmcnt field");
     constexpr int WAIT = waitcnt_imm((AR + BR) * (PF ? D - 2 : D - 1), 0);
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    int* s_flag = reinterpret_cast<int*>(smem + NS * STAGE);
+    float* C2 = smem + NS * STAGE;                                   // DEFER: the finished item's accumulator tile (BM x BN fp32)
+    int* s_flag = reinterpret_cast<int*>(smem + NS * STAGE + (DEFER ? BM * BN : 0));
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -227,6 +234,34 @@ __global__ __launch_bounds__(256) void conv_igemm_pers(const ConvP p) {
     const size_t slice = (size_t)p.M * p.Cout;
     const int act_relu = p.seg[0].act == YM_ACT_RELU;
 
+    // ---- deferred epilogue (DEFER): the finished item whose stores are still to be issued ----------------
+    bool pend = false, c_dirty = false;        // c_dirty: a wave may still be reading C2 (no barrier since part 2)
+    int pend_m0 = 0, pend_n0 = 0;
+    f32x4 pend_sc = {1.f, 1.f, 1.f, 1.f}, pend_sh = {0.f, 0.f, 0.f, 0.f}, pend_res[ENR];
+    auto flush_pending = [&]() __attribute__((always_inline)) {
+        const int pn = pend_n0 + col4 * 4;
+        if (pn < p.Cout) {
+            float* outb = p.seg[0].out + pn;
+#pragma unroll
+            for (int rk = 0; rk < ENR; ++rk) {
+                const int row = row0 + rk * RPP;
+                const int m = pend_m0 + row;
+                if (m < p.M) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(C2 + row * BN + col4 * 4);
+                    v = __builtin_elementwise_fma(v, pend_sc, pend_sh);
+                    v += pend_res[rk];                                   // zeros when there is no residual
+                    if (act_relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];
+                    }
+                    *reinterpret_cast<f32x4*>(outb + (size_t)m * p.Cout) = v;
+                }
+            }
+        }
+        pend = false;
+        c_dirty = true;
+    };
+
     // ---- the stream ---------------------------------------------------------------------------------
     setup_loader(ld_item);
 #pragma unroll
@@ -242,7 +277,7 @@ __global__ __launch_bounds__(256) void conv_igemm_pers(const ConvP p) {
         // epilogue operands of the un-split item are requested BEFORE its K loop (they return behind the D tiles already in flight)
         const bool direct = nks == 1;
         f32x4 pre_sc = {1.f, 1.f, 1.f, 1.f}, pre_sh = {0.f, 0.f, 0.f, 0.f}, pre_res[ENR];
-        if (direct) {
+        if (direct && !DEFER) {
             if (n < p.Cout) {
                 if (p.scale) pre_sc = *reinterpret_cast<const f32x4*>(p.scale + n);
                 if (p.shift) pre_sh = *reinterpret_cast<const f32x4*>(p.shift + n);
@@ -256,6 +291,30 @@ __global__ __launch_bounds__(256) void conv_igemm_pers(const ConvP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc_odd[r] = 0.f; }
         const int nt = it.kt_end - it.kt_beg;
+#ifdef YM_TRACE
+        // ablations of the trace build (YM_PERS_ABL -> p.bnb_relu; tools/pers_ablation.py): 1 = operand stream only, 2 = LDS reads +
+        // MFMAs only, 3 = MFMAs only (register operands), 5 = MFMAs only and NO per-tile barrier
+        if (p.bnb_relu >= 1 && p.bnb_relu <= 5) {
+            const f32x4 ra = {1.f, 2.f, 3.f, 4.f}, rb = {.5f, .25f, .125f, 1.f};
+            for (int t = 0; t < nt; ++t) {
+                if (p.bnb_relu == 1) dma_next(nb);
+                else if (p.bnb_relu == 2) compute(buf);
+                else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) mfma_group(ra, rb);
+                }
+                if (p.bnb_relu != 5) {
+                    __builtin_amdgcn_s_waitcnt(WAIT);
+                    __builtin_amdgcn_s_barrier();
+                }
+                nb = buf;
+                buf = buf == NS - 1 ? 0 : buf + 1;
+                if constexpr (DEFER) {
+                    if (t == 0) { if (pend) flush_pending(); } else c_dirty = false;
+                }
+            }
+        } else
+#endif
         if constexpr (PF) {
             f32x4 fa0, fb0, fa1, fb1;
             read_frag(buf, 0, fa0, fb0);           // (this tile landed at least one barrier ago)
@@ -281,6 +340,9 @@ __global__ __launch_bounds__(256) void conv_igemm_pers(const ConvP p) {
                 __builtin_amdgcn_s_barrier();
                 nb = buf;
                 buf = buf1;
+                if constexpr (DEFER) {             // every wave's copy of the previous item's tile is in C2 now: issue its stores
+                    if (t == 0) { if (pend) flush_pending(); } else c_dirty = false;
+                }
             }
         } else {
             for (int t = 0; t < nt; ++t) {
@@ -290,9 +352,34 @@ __global__ __launch_bounds__(256) void conv_igemm_pers(const ConvP p) {
                 __builtin_amdgcn_s_barrier();          // ... and for every wave: stage `buf` may be re-staged by the next dma_next
                 nb = buf;
                 buf = buf == NS - 1 ? 0 : buf + 1;
+                if constexpr (DEFER) {
+                    if (t == 0) { if (pend) flush_pending(); } else c_dirty = false;
+                }
             }
         }
         acc += acc_odd;
+        if (DEFER && direct) {
+            // part 1: park the tile in C2 and request the epilogue operands; the stores follow under the next item's MFMAs
+            if (c_dirty) wg_sync_lds();            // (a one-K-tile item: somebody may still be reading the previous tile)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                C2[(wm * 32 + 4 * khalf + (r & 3) + 8 * (r >> 2)) * BN + wn * 32 + frag_row] = acc[r];
+            pend_sc = f32x4{1.f, 1.f, 1.f, 1.f};
+            pend_sh = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (n < p.Cout) {
+                if (p.scale) pend_sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+                if (p.shift) pend_sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+            }
+#pragma unroll
+            for (int k = 0; k < ENR; ++k) {
+                const int m = m0 + row0 + k * RPP;
+                pend_res[k] = buf_ld16(rs_res, (m < p.M && n < p.Cout) ? (unsigned)(((size_t)m * p.Cout + n) * 4) : OOB);
+            }
+            pend_m0 = m0; pend_n0 = n0;
+            pend = true;
+            c_dirty = false;
+            continue;
+        }
 
         // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----
         float* C = smem + nb * STAGE;              // the stage consumed last: no DMA targets it before the next item's first iteration
@@ -367,42 +454,51 @@ __global__ __launch_bounds__(256) void conv_igemm_pers(const ConvP p) {
         }
         wg_sync_lds();                             // stage `nb` is free again: the next item's first dma_next re-stages it
     }
+    if constexpr (DEFER) {
+        if (pend) {                                // the last item's stores
+            wg_sync_lds();
+            flush_pending();
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the run-ahead loads of "no work left" still target this workgroup's LDS
 }
 
-template <int BM, int BN, int MODE, int NS>
+template <int BM, int BN, int MODE, int NS, bool DEFER>
 int launch_pers(const ConvP& p, int grid, hipStream_t st) {
-    const size_t lds = ym_conv_pers_lds_bytes(BM, BN, NS);
+    const size_t lds = ym_conv_pers_lds_bytes(BM, BN, NS, DEFER);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_pers<BM, BN, MODE, NS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_pers<BM, BN, MODE, NS, DEFER>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_pers<BM, BN, MODE, NS>), dim3(grid), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv_igemm_pers<BM, BN, MODE, NS, DEFER>), dim3(grid), dim3(256), lds, st, p);
     return ym_check_launch("conv_igemm_pers");
 }
 
-template <int MODE>
+template <int MODE, bool DEFER>
 int launch_pers_ns(const ConvP& p, int ns, int grid, hipStream_t st) {
     switch (ns) {
-        case 2: return launch_pers<64, 64, MODE, 2>(p, grid, st);
-        case 3: return launch_pers<64, 64, MODE, 3>(p, grid, st);
-        case 4: return launch_pers<64, 64, MODE, 4>(p, grid, st);
-        case 6: return launch_pers<64, 64, MODE, 6>(p, grid, st);
-        case 8: return launch_pers<64, 64, MODE, 8>(p, grid, st);
+        case 2: return launch_pers<64, 64, MODE, 2, DEFER>(p, grid, st);
+        case 3: return launch_pers<64, 64, MODE, 3, DEFER>(p, grid, st);
+        case 4: return launch_pers<64, 64, MODE, 4, DEFER>(p, grid, st);
+        case 6: return launch_pers<64, 64, MODE, 6, DEFER>(p, grid, st);
+        case 8: return launch_pers<64, 64, MODE, 8, DEFER>(p, grid, st);
         default: ym_set_error("conv(persistent): ring depth %d not built (2, 3, 4, 6, 8)", ns); return YM_EINVAL;
     }
 }
 
 }  // namespace
 
-size_t ym_conv_pers_lds_bytes(int bm, int bn, int ns) { return (size_t)ns * (bm + bn) * 32 * sizeof(float) + 16; }
+size_t ym_conv_pers_lds_bytes(int bm, int bn, int ns, bool defer) {
+    return (size_t)ns * (bm + bn) * 32 * sizeof(float) + (defer ? (size_t)bm * bn * sizeof(float) : 0) + 16;
+}
 
-int ym_launch_conv_pers(const ConvP& p, int bm, int bn, int mode, int ns, int grid, hipStream_t st) {
+int ym_launch_conv_pers(const ConvP& p, int bm, int bn, int mode, int ns, bool defer, int grid, hipStream_t st) {
     if (bm != 64 || bn != 64 || (mode != 0 && mode != 2)) {
         ym_set_error("conv(persistent): 64x64 tile, convolution or data gradient only (got %dx%d mode %d)", bm, bn, mode);
         return YM_EINVAL;
     }
-    return mode == 0 ? launch_pers_ns<0>(p, ns, grid, st) : launch_pers_ns<2>(p, ns, grid, st);
+    if (defer) return mode == 0 ? launch_pers_ns<0, true>(p, ns, grid, st) : launch_pers_ns<2, true>(p, ns, grid, st);
+    return mode == 0 ? launch_pers_ns<0, false>(p, ns, grid, st) : launch_pers_ns<2, false>(p, ns, grid, st);
 }
