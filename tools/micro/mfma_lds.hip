@@ -73,6 +73,33 @@ __global__ __launch_bounds__(256) void k(float* out, int tiles, const float* src
             TILE11(b1, b0)
         }
         fa[0] += b0[0][0] * 1e-30f;
+    } else if (MODE == 12 || MODE == 13) {
+        // ring of 2 (12) / 3 (13) with the LDS-DMA stream, fragments software-pipelined WITHIN the tile (group g+1 is read before the
+        // MFMAs of group g; group 0 right after the barrier) -- 13 also reads the next tile's group 0 before the barrier
+        constexpr int NSTG = MODE == 13 ? 3 : 2;
+        int nb = NSTG - 1;
+        f32x4 fa0, fb0, fa1, fb1;
+        RD(fa0, fb0, smem, 0)
+        for (int t = 0; t < tiles; ++t) {
+            const float* s = smem + buf * 128 * 32;
+            const int buf1 = buf == NSTG - 1 ? 0 : buf + 1;
+            const float* s1 = smem + buf1 * 128 * 32;
+            float* dst = smem + nb * 128 * 32 + (tid >> 6) * 8 * 32;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(dst + i * 32 * 32), 16, (int)((goffb + (unsigned)i * 4096u) % span), 0, 0, 0);
+            goffb = (goffb + 16384u) % span;
+            RD(fa1, fb1, s, 1) __builtin_amdgcn_sched_barrier(0); MM(fa0, fb0) __builtin_amdgcn_sched_barrier(0);
+            RD(fa0, fb0, s, 2) __builtin_amdgcn_sched_barrier(0); MM(fa1, fb1) __builtin_amdgcn_sched_barrier(0);
+            RD(fa1, fb1, s, 3) __builtin_amdgcn_sched_barrier(0); MM(fa0, fb0) __builtin_amdgcn_sched_barrier(0);
+            if (MODE == 13) { RD(fa0, fb0, s1, 0) __builtin_amdgcn_sched_barrier(0); }
+            MM(fa1, fb1)
+            if (MODE == 13) __builtin_amdgcn_s_waitcnt(0x0070); else __builtin_amdgcn_s_waitcnt(0x0070);
+            __builtin_amdgcn_s_barrier();
+            if (MODE == 12) { RD(fa0, fb0, s1, 0) }
+            nb = buf;
+            buf = buf1;
+        }
     } else if (MODE >= 4) {
         constexpr int NSTG = MODE == 6 ? 3 : 2;
         constexpr int NLD = MODE == 7 ? 2 : 4;
@@ -142,7 +169,7 @@ void run(const char* name, int w) {
     float* out;
     (void)hipMalloc(&out, 4);
     const int tiles = 20000, wgs = 256 * w;
-    const int lds = MODE == 6 ? 49152 : 32768;
+    const int lds = (MODE == 6 || MODE == 13) ? 49152 : 32768;
     float* src;
     (void)hipMalloc(&src, 1 << 20);
     (void)hipMemset(src, 0, 1 << 20);
@@ -176,6 +203,8 @@ int main() {
     for (int w : {1, 3}) run<8>("LDS-DMA stream, vmcnt waited only every 8th tile", w);
     for (int w : {1, 3}) run<9>("loads to VGPRs only (no ds_write)", w);
     for (int w : {1, 3}) run<10>("LDS-DMA stream issued by ONE wave of the workgroup", w);
+    for (int w : {1, 2, 3, 4}) run<12>("LDS-DMA ring of 2, fragments pipelined within the tile", w);
+    for (int w : {1, 2, 3}) run<13>("LDS-DMA ring of 3, fragments pipelined across the barrier", w);
     for (int w : {1, 2, 3, 4}) run<11>("A through LDS (DMA), B fragments straight from global (coalesced)", w);
     return 0;
 }
