@@ -152,6 +152,9 @@ class _Conv:
             d.tile_m, d.tile_n, d.ksplit, d.kwaves, d.stages = hit[0], hit[1], hit[2], self.kwaves, self.stages
             d.tail_tiles, d.tail_ksplit = self.tail
             d.grid_wgs = hit[7] if len(hit) > 7 else 0          # persistent kernel (stages 4x): workgroups launched
+            cap = int(os.environ.get('YM_MAX_KSPLIT', '0') or 0)     # experiment knob: cap the K split of the tuned choice
+            if cap and self.ksplit > cap:
+                self.ksplit = d.ksplit = cap
         self.apply_mma(conv_mma())
         return ho, wo
 
@@ -172,6 +175,9 @@ class _Conv:
             self.tile, self.ksplit, self.kwaves = (hit[0], hit[1]), hit[2], (hit[3] if len(hit) > 3 else 0)
             self.stages = hit[4] if len(hit) > 4 else 0
             self.tail = (hit[5], hit[6]) if len(hit) > 6 else (0, 0)
+            cap = int(os.environ.get('YM_MAX_KSPLIT', '0') or 0)     # experiment knob: cap the K split of the tuned choice
+            if cap and self.ksplit > cap:
+                self.ksplit = cap
             d.tile_m, d.tile_n, d.ksplit, d.kwaves = self.tile[0], self.tile[1], self.ksplit, self.kwaves
             d.tail_tiles, d.tail_ksplit = self.tail
             d.grid_wgs = hit[7] if len(hit) > 7 else 0
