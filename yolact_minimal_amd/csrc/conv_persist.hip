@@ -10,10 +10,10 @@
 //     tiles are multiplied and while its epilogue runs.  In conv_igemm_f32 those slots fetched past-the-end garbage, and every
 //     item (= workgroup there) paid address set-up + a cold L2/MALL round trip (~1.7 us) before its first MFMA and an epilogue
 //     (~2-3 us) with nothing in flight: at M ~ 9 k (batch 8) that was 6.9 k + 8.2 k cycles around 8.2 k cycles of MFMA per tile.
-//   * The accumulator tile is staged for the row-major epilogue in the ring stage that was consumed LAST (the only stage no DMA
-//     targets until the next item's first iteration): 64x64 fp32 = exactly one 16 KB stage, so the ring depth is the whole LDS
-//     bill -- NS = 3 -> 48 KB = 3 workgroups per CU, NS = 8 -> 128 KB for the batch-1 regime, where a launch has about one item
-//     per CU, every access misses the (per-launch cold) L2 and a lone wave per SIMD must have ~2 us of operands in flight.
+//   * The accumulator tile goes through LDS for the row-major epilogue (16-byte stores).  Un-split items (DEFER, the default): a
+//     dedicated 16 KB tile next to the ring, so that the stores can be issued later (below); ring of 2 + tile = 48 KB = 3
+//     workgroups per CU.  K-split items (and DEFER = false): the ring stage that was consumed LAST, the only stage no DMA targets
+//     until the next item's first iteration -- 64x64 fp32 is exactly one 16 KB stage.
 //   * Lean code (10 KB against 36 KB for conv_igemm_f32<64,64,...>): ReLU / identity only and NO fused BatchNorm statistics.  A
 //     launch that carries them (ym_conv_desc.bn_sum: the training forward and most data gradients) stays on the per-item kernel:
 //     an instantiation with the statistics epilogue was built and measured 3x SLOWER than that kernel (150 vs 50 us for the
@@ -43,12 +43,12 @@ __device__ __forceinline__ void wg_sync_lds() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// DEFER: the un-split item's epilogue is split in two.  Part 1, at the end of its K loop, only moves the accumulators into a
-// dedicated 16 KB LDS tile and requests the residual / scale / shift operands; part 2 (read the tile row-major, affine + residual +
-// ReLU, 16-byte stores) runs inside the NEXT item's K loop, right after the barrier that ends its first K tile -- that barrier is
-// the one the tile exchange needs anyway.  The MFMAs of item i+1 therefore start immediately after item i's last one: co-resident
-// workgroups of one launch run phase-locked (same item length, same start), so without this all of them sat in their epilogues
-// at the same time with the matrix pipe idle (measured: K loop 10 us + epilogue 3.7 us per item at M = 9248, K = 256).
+// DEFER: the un-split item's epilogue is split in two.  Part 1, at the end of its K loop, only moves the accumulators into the
+// dedicated LDS tile and requests the residual / scale / shift operands; part 2 (read the tile row-major, affine + residual + ReLU,
+// 16-byte stores) runs inside the NEXT item's K loop, right after the barrier that ends its first K tile -- the barrier the tile
+// hand-off needs anyway.  The MFMAs of item i+1 start immediately after item i's last one.  Measured: +2 % (49.6 vs 50.8 us on the
+// 2320-tile layer3 conv at batch 8): co-resident workgroups cover each other's epilogues better than their phase-locked start
+// suggests; what bounds a 64x64 tile is the write of its operand tiles into LDS.
 template <int BM, int BN, int MODE, int NS, bool DEFER>
 __global__ __launch_bounds__(256) void conv_igemm_pers(const ConvP p) {
     static_assert(BM == 64 && BN == 64, "the accumulator staging aliases one ring stage: (BM + BN) * 128 B == BM * BN * 4 B");
