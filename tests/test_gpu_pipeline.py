@@ -172,6 +172,33 @@ def test_requests_in_flight_give_the_single_request_results():
             assert (a is None and b is None) or torch.equal(a, b)
 
 
+def test_a_request_starts_behind_the_stream_that_produced_its_image():
+    """`submit` runs the request on the slot's own stream: it has to wait for whatever the caller's stream still has queued in
+    front of the image (H2D copy, `val_aug`) -- here ~10 ms of fills followed by the copy that makes the image."""
+    import bench
+    from yolact_minimal_amd.pipeline import RequestPipeline
+    dev = torch.device(DEV)
+    net, cfg = bench.build_net('res50_coco', 256, dev)
+    one = bench.Workload(net, cfg, 1, 256, dev, with_post=False, inflight=1)
+    one.engine.run(one.img)
+    torch.cuda.synchronize()
+    want = [t.clone() for t in one.engine.outputs()]
+    pipe = RequestPipeline(net, cfg, 256, 256, dev, depth=2, with_post=False)
+    img = torch.zeros_like(one.img)
+    pipe.warm_up(img)
+    big = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    for it in range(2):
+        img.zero_()
+        torch.cuda.synchronize()
+        for _ in range(8):
+            big.fill_(1.0)                      # queued work in front of ...
+        img.copy_(one.img)                      # ... the image
+        pipe.submit(img)
+        got = pipe.drain()[0]
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+
+
 def test_chained_forward_nms_after_nms_matches_the_reference(golden_dir):
     """eval.py:45-52 as ONE chain at the benchmarked size: res101_coco 544 px, `nms` / `after_nms` consume the HIP forward's OWN
     outputs (every other post-processing test feeds synthetic head outputs).  Golden from the REAL reference

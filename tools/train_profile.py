@@ -17,8 +17,11 @@ ap.add_argument('--cfg', default='res101_coco')
 ap.add_argument('--batch', type=int, default=8)
 ap.add_argument('--steps', type=int, default=8)
 ap.add_argument('--ab', default='', help="A/B inside one process: name of a boolean switch of train_engine (e.g. _FUSE_BN_BWD)")
+ap.add_argument('--prio', action='store_true', help='run the step on a high-priority stream (the weight-gradient side stream stays normal)')
 args = ap.parse_args()
 dev = torch.device('cuda:0')
+if args.prio:
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
 cfg = build_cfg(args.cfg, 'train', 544, train_bs=args.batch, bs_per_gpu=args.batch)
 torch.manual_seed(0)
 tr = Trainer(Yolact(cfg), cfg, dev)

@@ -276,10 +276,24 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
     const float invM = 1.f / (float)M;
     if (blockIdx.x == 0)
         for (int c = threadIdx.x; c < C; c += 256) { dgamma_f[c] = (float)dgamma[c]; dbeta_f[c] = (float)dbeta[c]; }
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int cq = (int)(i % C4);
-        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + cq * 4), is = *reinterpret_cast<const f32x4*>(invstd + cq * 4);
-        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + cq * 4);
+    // When the grid stride is a multiple of C/4 a thread keeps its channel quad for the whole tensor: the seven per-channel vectors
+    // (mean, invstd, gamma, beta, the two fp64 sums) are then loaded and converted ONCE instead of per 16 bytes of dout (they were
+    // 8 of the 11 load instructions of an iteration of this HBM-bound pass).  Same arithmetic, same order.
+    const size_t stride = (size_t)gridDim.x * 256;
+    const bool fixed_c = stride % (size_t)C4 == 0;
+    f32x4 mu, is, g, bt = {0.f, 0.f, 0.f, 0.f}, dbf, dgf;
+    auto load_channel = [&](int cq) __attribute__((always_inline)) {
+        mu = *reinterpret_cast<const f32x4*>(mean + cq * 4);
+        is = *reinterpret_cast<const f32x4*>(invstd + cq * 4);
+        g = *reinterpret_cast<const f32x4*>(gamma + cq * 4);
+        if (relu && !out) bt = *reinterpret_cast<const f32x4*>(beta + cq * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dbf[e] = (float)dbeta[cq * 4 + e]; dgf[e] = (float)dgamma[cq * 4 + e]; }
+    };
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (fixed_c && i < total) load_channel((int)(i % C4));
+    for (; i < total; i += stride) {
+        if (!fixed_c) load_channel((int)(i % C4));
         f32x4 dz = *reinterpret_cast<const f32x4*>(dout + i * 4);
         const f32x4 yy = *reinterpret_cast<const f32x4*>(y + i * 4);
         if (relu && out) {
@@ -287,7 +301,6 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
 #pragma unroll
             for (int e = 0; e < 4; ++e) dz[e] = o[e] > 0.f ? dz[e] : 0.f;
         } else if (relu) {                                        // no saved `out`: the same affine as the forward pass
-            const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + cq * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) dz[e] = bn_affine(yy[e], mu[e], is[e], g[e], bt[e]) > 0.f ? dz[e] : 0.f;
         }
@@ -296,7 +309,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float xh = (yy[e] - mu[e]) * is[e];
-            r[e] = g[e] * is[e] * (dz[e] - (float)dbeta[cq * 4 + e] * invM - xh * (float)dgamma[cq * 4 + e] * invM);
+            r[e] = g[e] * is[e] * (dz[e] - dbf[e] * invM - xh * dgf[e] * invM);
         }
         *reinterpret_cast<f32x4*>(dy + i * 4) = r;
     }

@@ -63,9 +63,14 @@ class RequestPipeline:
         self.pending[slot] = None
         if not self.with_post:
             pend.synchronize()
-            return self.engines[slot].outputs()
+            return self.engines[slot].outputs()           # the slot's own buffers: valid until the slot runs its next request
         ids, scores, box_px, masks, counts, ev = pend
         ev.synchronize()                                  # THIS request only
+        # the results were allocated on the slot's stream and are consumed on the caller's: tell the allocator, or the slot's next
+        # request could be handed the block while a kernel of the caller still reads it
+        cur = torch.cuda.current_stream(self.device)
+        for t in (ids, scores, box_px, masks):
+            t.record_stream(cur)
         out = []
         for b, n in enumerate(self.counts_host[slot].tolist()):
             self.detections += n
@@ -75,11 +80,15 @@ class RequestPipeline:
     def submit(self, img, head_outputs=None):
         """Enqueue one request ([batch,3,H,W] images, device resident) on the next slot and return the finished result of the request
         that used this slot before (None the first `depth` times).  `head_outputs`: post-process these (class, box, coef, proto)
-        tensors instead of the forward's own outputs (bench.py: a random-init network yields degenerate detections)."""
+        tensors instead of the forward's own outputs (bench.py: a random-init network yields degenerate detections).
+        The request is ordered behind everything the caller's current stream has queued; the caller must not overwrite `img` before
+        the request has finished (use one input buffer per slot when images arrive by H2D copy)."""
         slot = self.submitted % self.depth
         self.submitted += 1
         done = self.finish(slot)
         ev = self.events[slot]
+        # `img` / `head_outputs` were produced on the caller's stream (an H2D copy, `val_aug`): the slot's stream starts behind that
+        self.streams[slot].wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.streams[slot]):
             eng = self.engines[slot]
             eng.run(img)

@@ -122,6 +122,9 @@ def _configure_conv(d, key, stats=False):
             d.mma, d.stages = mma, 0
 
 
+_MSPLIT_SCALE = float(os.environ.get('YM_WGRAD_MSPLIT_SCALE', '1'))
+
+
 def _configure_wgrad(d, key):
     hit = _table().get(key)
     if hit is None and _TUNING:
@@ -150,6 +153,8 @@ def _configure_wgrad(d, key):
     if hit is not None:
         d.msplit = hit[0]
         d.lds_buffers = hit[1] if len(hit) > 1 else 2
+        if _MSPLIT_SCALE != 1.0 and d.msplit > 1:    # experiment knob: the table was tuned with the chip to itself
+            d.msplit = max(1, int(round(d.msplit * _MSPLIT_SCALE)))
 
 
 def dump_new_entries(path):
