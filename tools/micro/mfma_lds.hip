@@ -4,6 +4,13 @@
 //   hipcc -O3 --offload-arch=gfx950 tools/micro/mfma_lds.hip -o tools/micro/mfma_lds
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+// -DFASTADDR: wrap the stream offsets with one v_and instead of an integer modulo (~12 VALU instructions each): the modulo alone
+// made the "operand stream" cost 48 VALU instructions per lane and K tile, and VALU issue displaces MFMA issue
+#ifdef FASTADDR
+#define WRAP & ~-(int)
+#else
+#define WRAP %
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define RD(fa_, fb_, base, g) fa_ = *reinterpret_cast<const f32x4*>(base + a_off + goff[g]); fb_ = *reinterpret_cast<const f32x4*>(base + b_off + goff[g]);
@@ -19,7 +26,7 @@ __global__ __launch_bounds__(256) void k(float* out, int tiles, const float* src
     extern __shared__ __attribute__((aligned(16))) float smem[];       // 2 (3) stages x (64 + 64) rows x 32 floats
     typedef __attribute__((address_space(3))) void* lds_ptr;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, span, 0x00020000);
-    unsigned goffb = (unsigned)((blockIdx.x * 16384u + threadIdx.x * 16u) % span);
+    unsigned goffb = (unsigned)((blockIdx.x * 16384u + threadIdx.x * 16u) WRAP span);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     for (int i = tid; i < 2 * 128 * 32; i += 256) smem[i] = (float)((i * 2654435761u) >> 20) * 1e-6f;
     __syncthreads();
@@ -50,17 +57,17 @@ __global__ __launch_bounds__(256) void k(float* out, int tiles, const float* src
         int nb = 1;
         f32x4 b0[4], b1[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) b0[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((goffb + g * 4096u) % span), 0, 0));
+        for (int g = 0; g < 4; ++g) b0[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((goffb + g * 4096u) WRAP span), 0, 0));
         for (int t = 0; t < tiles; t += 2) {
 #define TILE11(bcur, bnext)                                                                                                      \
             {                                                                                                                    \
                 const float* s = smem + buf * 128 * 32;                                                                          \
                 float* dst = smem + nb * 128 * 32 + (tid >> 6) * 8 * 32;                                                         \
-                goffb = (goffb + 16384u) % span;                                                                                 \
+                goffb = (goffb + 16384u) WRAP span;                                                                                 \
                 _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                    \
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(dst + i * 32 * 32), 16, (int)((goffb + i * 4096u) % span), 0, 0, 0); \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(dst + i * 32 * 32), 16, (int)((goffb + i * 4096u) WRAP span), 0, 0, 0); \
                 _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                                    \
-                    bnext[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((goffb + 8192u + g * 4096u) % span), 0, 0)); \
+                    bnext[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((goffb + 8192u + g * 4096u) WRAP span), 0, 0)); \
                 _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                                  \
                     fa = *reinterpret_cast<const f32x4*>(s + a_off + goff[g]);                                                   \
                     MM(fa, bcur[g])                                                                                              \
@@ -87,8 +94,8 @@ __global__ __launch_bounds__(256) void k(float* out, int tiles, const float* src
             float* dst = smem + nb * 128 * 32 + (tid >> 6) * 8 * 32;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(dst + i * 32 * 32), 16, (int)((goffb + (unsigned)i * 4096u) % span), 0, 0, 0);
-            goffb = (goffb + 16384u) % span;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(dst + i * 32 * 32), 16, (int)((goffb + (unsigned)i * 4096u) WRAP span), 0, 0, 0);
+            goffb = (goffb + 16384u) WRAP span;
             RD(fa1, fb1, s, 1) __builtin_amdgcn_sched_barrier(0); MM(fa0, fb0) __builtin_amdgcn_sched_barrier(0);
             RD(fa0, fb0, s, 2) __builtin_amdgcn_sched_barrier(0); MM(fa1, fb1) __builtin_amdgcn_sched_barrier(0);
             RD(fa1, fb1, s, 3) __builtin_amdgcn_sched_barrier(0); MM(fa0, fb0) __builtin_amdgcn_sched_barrier(0);
@@ -112,17 +119,17 @@ __global__ __launch_bounds__(256) void k(float* out, int tiles, const float* src
                 if ((tid >> 6) == 0) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(smem + nb * 128 * 32 + i * 8 * 32), 16, (int)((goffb + (unsigned)i * 1024u) % span), 0, 0, 0);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(smem + nb * 128 * 32 + i * 8 * 32), 16, (int)((goffb + (unsigned)i * 1024u) WRAP span), 0, 0, 0);
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < NLD; ++i) {
-                    const unsigned o = (goffb + (unsigned)i * 4096u) % span;
+                    const unsigned o = (goffb + (unsigned)i * 4096u) WRAP span;
                     if (MODE == 5 || MODE == 9) st[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o, 0, 0));
                     else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(dst + i * 32 * 32), 16, (int)o, 0, 0, 0);
                 }
             }
-            goffb = (goffb + 16384u) % span;
+            goffb = (goffb + 16384u) WRAP span;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 fa = *reinterpret_cast<const f32x4*>(s + a_off + goff[g]);
@@ -133,7 +140,10 @@ __global__ __launch_bounds__(256) void k(float* out, int tiles, const float* src
 #pragma unroll
                 for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(smem + nb * 128 * 32 + i * 32 * 32 + tid * 4) = st[i];
             }
-            if (MODE == 9) { fa[0] += st[0][0] * 1e-30f + st[1][1] * 1e-30f + st[2][2] * 1e-30f + st[3][3] * 1e-30f; }
+            if (MODE == 9) {                 // keep the loads alive without spending VALU on them (an earlier `fa[0] += ...` was dead code:
+#pragma unroll                               // the compiler dropped the loads and this mode measured nothing)
+                for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(st[i]));
+            }
             if (MODE == 6) __builtin_amdgcn_s_waitcnt(0x0074);
             else if (MODE == 8) { if ((t & 7) == 7) __builtin_amdgcn_s_waitcnt(0x0070); else __builtin_amdgcn_s_waitcnt(0xC07F); }
             else __builtin_amdgcn_s_waitcnt(0x0070);
@@ -191,7 +201,17 @@ void run(const char* name, int w) {
     (void)hipFree(out);
 }
 
-int main() {
+int main(int argc, char**) {
+    if (argc > 1) {          // counter runs (rocprofv3 --pmc): one launch set per interesting mode at 3 waves per SIMD
+        run<3>("fragments software-pipelined + s_barrier per K tile", 3);
+        run<13>("LDS-DMA ring of 3, fragments pipelined across the barrier", 3);
+        run<5>("barrier + operand stream through VGPRs + ds_write", 3);
+        run<9>("loads to VGPRs only (no ds_write)", 3);
+        run<7>("LDS-DMA stream, HALF the bytes (2 loads per lane and tile)", 3);
+        run<12>("LDS-DMA ring of 2, fragments pipelined within the tile", 3);
+        run<11>("A through LDS (DMA), B fragments straight from global (coalesced)", 3);
+        return 0;
+    }
     for (int w : {1, 2, 3, 4}) run<0>("MFMA only, two alternating accumulators", w);
     for (int w : {1, 2, 3, 4}) run<1>("+ 2 ds_read_b128 and lgkmcnt(0) per 4 MFMAs", w);
     for (int w : {1, 2, 3, 4}) run<2>("+ s_barrier per K tile (16 MFMAs)", w);

@@ -28,6 +28,19 @@ constexpr unsigned OOB = 0xFFFFFFF0u;
 __device__ __forceinline__ f32x4 buf_ld16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
 }
+// The same with the block-uniform part of the offset in the instruction's SGPR operand (`soffset`: added to the address, NOT part
+// of the range check, so a lane whose `byte_off` is out of range still reads 0).  Every VALU instruction of a K loop takes an issue
+// slot from the MFMAs (tools/micro/mfma_lds.hip: 48 extra VALU instructions per 16 MFMAs = -17 % of the matrix pipe; the
+// persistent 64x64 kernel gained 5 % from the 14 it lost this way), so the K loops keep their per-tile offset arithmetic scalar.
+__device__ __forceinline__ f32x4 buf_ld16_s(__amdgpu_buffer_rsrc_t r, unsigned byte_off, int soffset) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, soffset, 0));
+}
+// compile-time ring stages: a K loop written per stage (unrolled by the ring depth) has every LDS address as base + immediate
+template <int I> struct IC { static constexpr int value = I; };
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(IC<I>{}); static_for<I + 1, N>(f); }
+}
 // agent-scope (sc1) accesses: coherent across the 8 XCD L2s without cache maintenance (aux bit 4 = sc1 on gfx94x/gfx950)
 constexpr int AUX_SC1 = 16;
 __device__ __forceinline__ f32x4 buf_ld16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {

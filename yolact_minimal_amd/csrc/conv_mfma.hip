@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
     float* Bs = smem + LB * BM * RP;          // [LB][BN][RP]
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the DMA's LDS destination goes through M0
     const int wm = wave >> 1, wn = wave & 1;
     YM_STAMP(0);
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
@@ -159,16 +159,16 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
         c0 = (int)uc0; kh = (int)ukh; kw = (int)ukw;
     }
 
-    // One K tile of both operands: `sink_a(i, byte_offset)` / `sink_b(i, byte_offset)` receive the source offset of this lane's
-    // 16 bytes of staging row i.  The per-tile integer work is kept to an add + or per row: everything that depends on the filter
-    // tap (bounds test, pixel offset) is refreshed only when the tap changes (every Cin/32 tiles; never for a 1x1 conv), rows
-    // that must read zeros carry an all-ones mask (offset | 0xFFFFFFF0 is beyond any buffer -> the raw buffer load returns 0), and
-    // weight rows past Cout sit at the END of the buffer so that adding the K offset keeps them out of range.  Tiles past the end
-    // of this block's K range are fetched like any other (the counted vmcnt waits need an unconditional load count) and never
-    // consumed, so they need no special casing — a buffer load cannot fault.
-    unsigned a_tapbase[AR], a_mask[AR];
+    // One K tile of both operands: `sink_a(i, lane_offset, block_offset)` / `sink_b(...)` receive the source of this lane's 16
+    // bytes of staging row i as a per-lane byte offset + a block-uniform one (-> the load's SGPR offset).  There is NO per-tile
+    // vector arithmetic: everything that depends on the filter tap (bounds test, pixel offset) is refreshed only when the tap
+    // changes (every Cin/32 tiles; never for a 1x1 conv), rows that must read zeros carry an all-ones mask in the lane offset
+    // (offset | 0xFFFFFFF0 is beyond any buffer -> the raw buffer load returns 0; the SGPR offset is not range-checked), and
+    // weight rows past Cout sit at the END of the buffer.  Tiles past the end of this block's K range are fetched like any other
+    // (the counted vmcnt waits need an unconditional load count) and never consumed — a buffer load cannot fault.
+    unsigned a_off[AR];
     bool tap_dirty = true;
-    auto gather_tile = [&](int kt, auto&& sink_a, auto&& sink_b) {
+    auto gather_tile = [&](int kt, auto&& sink_a, auto&& sink_b) __attribute__((always_inline)) {
         if (MODE == 0 || MODE == 2) {
             if (tap_dirty) {                                  // block-uniform
                 tap_dirty = false;
@@ -178,21 +178,18 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
                         const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
                         const int Hh = RG ? a_h[RG ? i : 0] : p.H, Ww = RG ? a_w[RG ? i : 0] : p.W;
                         const bool ok = (unsigned)ih < (unsigned)Hh && (unsigned)iw < (unsigned)Ww;
-                        a_tapbase[i] = (unsigned)(((a_pix[i] + kh * Ww + kw) * p.Cin + c4 * 4) * 4);
-                        a_mask[i] = ok ? 0u : OOB;
+                        a_off[i] = (unsigned)(((a_pix[i] + kh * Ww + kw) * p.Cin + c4 * 4) * 4) | (ok ? 0u : OOB);
                     } else {
                         const int sh = p.stride >> 1, smask = p.stride - 1;     // stride is 1 or 2
                         const int th = a_ih0[i] - kh, tw = a_iw0[i] - kw;
                         const int yh = th >> sh, yw = tw >> sh;
                         const bool ok = th >= 0 && tw >= 0 && ((th | tw) & smask) == 0 && yh < p.H && yw < p.W;
-                        a_tapbase[i] = (unsigned)((((a_pix[i] + yh) * p.W + yw) * p.Cin + c4 * 4) * 4);
-                        a_mask[i] = ok ? 0u : OOB;
+                        a_off[i] = (unsigned)((((a_pix[i] + yh) * p.W + yw) * p.Cin + c4 * 4) * 4) | (ok ? 0u : OOB);
                     }
                 }
             }
-            const unsigned c0b = (unsigned)(c0 * 4);
 #pragma unroll
-            for (int i = 0; i < AR; ++i) sink_a(i, (a_tapbase[i] + c0b) | a_mask[i]);
+            for (int i = 0; i < AR; ++i) sink_a(i, a_off[i], c0 * 4);
             c0 += BK;
             if (c0 >= p.Cin) {
                 c0 = 0;
@@ -208,19 +205,18 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
                 const int ih = a_ih0[i] + th, iw = a_iw0[i] + tw;
                 const bool ok = tap_ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
                 const unsigned off = (unsigned)((a_pix[i] + th * p.W + tw) * 16);
-                sink_a(i, ok ? off : OOB);
+                sink_a(i, ok ? off : OOB, 0);
             }
         }
-        const unsigned kb = (unsigned)(kt * BK * 4);
 #pragma unroll
-        for (int i = 0; i < BR; ++i) sink_b(i, wrow[i] + kb);
+        for (int i = 0; i < BR; ++i) sink_b(i, wrow[i], kt * BK * 4);
     };
     constexpr int NSET = (NS == 3 && !DL) ? 2 : 1;
     f32x4 rA[NSET][DL ? 1 : AR], rB[NSET][DL ? 1 : BR];
-    auto load_tile = [&](int kt, auto set_c) {               // register staging
+    auto load_tile = [&](int kt, auto set_c) __attribute__((always_inline)) {               // register staging
         constexpr int SET = decltype(set_c)::value;
-        gather_tile(kt, [&](int i, unsigned off) { rA[SET][DL ? 0 : i] = buf_ld16(rs_in, off); },
-                    [&](int i, unsigned off) { rB[SET][DL ? 0 : i] = buf_ld16(rs_w, off); });
+        gather_tile(kt, [&](int i, unsigned off, int soff) { rA[SET][DL ? 0 : i] = buf_ld16_s(rs_in, off, soff); },
+                    [&](int i, unsigned off, int soff) { rB[SET][DL ? 0 : i] = buf_ld16_s(rs_w, off, soff); });
     };
     // split mode: 4 floats -> SPL x 4 bf16 (round to nearest even; the residual of each step is exact in fp32)
     auto split_store = [&](unsigned short* row, const f32x4 v, int plane_stride) {
@@ -240,7 +236,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
             }
         }
     };
-    auto store_tile = [&](int buf, auto set_c) {
+    auto store_tile = [&](int buf, auto set_c) __attribute__((always_inline)) {
         constexpr int SET = decltype(set_c)::value;
         float* a = As + buf * BM * RP;
         float* b = Bs + buf * BN * RP;
@@ -260,12 +256,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
         for (int i = 0; i < BR; ++i)
             *reinterpret_cast<f32x4*>(b + (rbase + 32 * i) * RP + c4 * 4) = rB[SET][DL ? 0 : i];
     };
-    auto dma_tile = [&](int kt, int buf) {                   // global -> LDS, asynchronous (tracked by vmcnt)
+    auto dma_tile = [&](int kt, int buf) __attribute__((always_inline)) {                   // global -> LDS, asynchronous (tracked by vmcnt)
         typedef __attribute__((address_space(3))) void* lds_ptr;
         float* a = As + (buf * BM + 8 * wave) * RP;          // wave-uniform; lane l lands at +16*l bytes = row l/8, slot l%8
         float* b = Bs + (buf * BN + 8 * wave) * RP;
-        gather_tile(kt, [&](int i, unsigned off) { __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr)(a + 32 * i * RP), 16, (int)off, 0, 0, 0); },
-                    [&](int i, unsigned off) { __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(b + 32 * i * RP), 16, (int)off, 0, 0, 0); });
+        gather_tile(kt, [&](int i, unsigned off, int soff) { __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr)(a + 32 * i * RP), 16, (int)off, soff, 0, 0); },
+                    [&](int i, unsigned off, int soff) { __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(b + 32 * i * RP), 16, (int)off, soff, 0, 0); });
     };
 
     f32x16 acc[TM][TN];
@@ -292,7 +288,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) goff[g] = DL ? (((2 * g + khalf) ^ ((frag_row >> 1) & 7)) * 4) : (g * 8 + khalf * 4);
 
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf) __attribute__((always_inline)) {
         if constexpr (SPL > 0) {
             // bf16 32x32x16: lane l supplies A[i = l & 31][k = 8 * (l >> 5) .. + 7] of a 16-deep block: one ds_read_b128 per plane
             typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -379,7 +375,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
         static_assert((AR + BR) * (D - 2) < 16, "vmcnt field");
         constexpr int WAIT = 0x070 | ((AR + BR) * (D - 2));   // tiles <= t+1 landed at the barrier that ends tile t-1; lgkmcnt(0): see RING_WAIT
         const int nt = kt_end - kt_beg;
-        auto read_frag = [&](int buf, int g, f32x4 (&fa)[TM], f32x4 (&fb)[TN]) {
+        auto read_frag = [&](int buf, int g, f32x4 (&fa)[TM], f32x4 (&fb)[TN]) __attribute__((always_inline)) {
             const float* a = As + buf * BM * RP + a_frag_off + goff[g];
             const float* b = Bs + buf * BN * RP + b_frag_off + goff[g];
 #pragma unroll
@@ -387,7 +383,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * RP);
         };
-        auto mfma_group = [&](const f32x4 (&fa)[TM], const f32x4 (&fb)[TN]) {
+        auto mfma_group = [&](const f32x4 (&fa)[TM], const f32x4 (&fb)[TN]) __attribute__((always_inline)) {
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 if constexpr (DUAL) {
@@ -409,9 +405,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
         YM_STAMP(1);
         f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
         read_frag(0, 0, fa0, fb0);
-        int buf = 0, nb = D;
-        for (int t = 0; t < nt; ++t) {
-            const int buf1 = buf == NS - 1 ? 0 : buf + 1;
+        // The loop is unrolled by the ring depth: tile t lives in stage t % NS, a literal at every call site below, so that every LDS
+        // address (fragment reads, DMA destination) is a register + immediate and the loop body has no address VALU (conv_common.h).
+        auto tile = [&](auto S, int t) __attribute__((always_inline)) {
+            constexpr int buf = decltype(S)::value, buf1 = (buf + 1) % NS, nb = (buf + D) % NS;
             dma_tile(kt_beg + t + D, nb);
             read_frag(buf, 1, fa1, fb1);
             __builtin_amdgcn_sched_barrier(0);
@@ -430,9 +427,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
             mfma_group(fa1, fb1);
             __builtin_amdgcn_s_waitcnt(WAIT);
             __builtin_amdgcn_s_barrier();
-            buf = buf1;
-            nb = nb == NS - 1 ? 0 : nb + 1;
-        }
+        };
+        int t = 0;
+        for (; t + NS <= nt; t += NS) static_for<0, NS>([&](auto S) __attribute__((always_inline)) { tile(S, t + decltype(S)::value); });
+        static_for<0, NS - 1>([&](auto S) __attribute__((always_inline)) { if (t + decltype(S)::value < nt) tile(S, t + decltype(S)::value); });
         __builtin_amdgcn_s_waitcnt(0xF70);
         __builtin_amdgcn_s_barrier();
     } else if constexpr (DL) {
@@ -451,15 +449,17 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
         __builtin_amdgcn_s_waitcnt(WAIT);
         __builtin_amdgcn_s_barrier();
         YM_STAMP(1);
-        int buf = 0, nb = D;                               // nb = (buf + D) % NS: the buffer tile t-1 was read from
-        for (int t = 0; t < nt; ++t) {
+        // unrolled by the ring depth: tile t lives in stage t % NS, a literal at every call site (no address VALU in the loop body)
+        auto tile = [&](auto S, int t) __attribute__((always_inline)) {
+            constexpr int buf = decltype(S)::value, nb = (buf + D) % NS;     // nb: the buffer tile t-1 was read from
             dma_tile(kt_beg + t + D, nb);
             compute(buf);
             __builtin_amdgcn_s_waitcnt(WAIT);              // tile t+1 of THIS wave has landed ...
             __builtin_amdgcn_s_barrier();                  // ... and of every wave; everyone is done reading tile t
-            buf = buf == NS - 1 ? 0 : buf + 1;
-            nb = nb == NS - 1 ? 0 : nb + 1;
-        }
+        };
+        int t = 0;
+        for (; t + NS <= nt; t += NS) static_for<0, NS>([&](auto S) __attribute__((always_inline)) { tile(S, t + decltype(S)::value); });
+        static_for<0, NS - 1>([&](auto S) __attribute__((always_inline)) { if (t + decltype(S)::value < nt) tile(S, t + decltype(S)::value); });
         __builtin_amdgcn_s_waitcnt(0xF70);                 // the past-the-end prefetches still write LDS: drain before reuse
         __builtin_amdgcn_s_barrier();
     } else if constexpr (NS == 3) {
@@ -506,13 +506,16 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
         store_tile(0, I0{});
         __syncthreads();
         YM_STAMP(1);
-        for (int kt = kt_beg; kt < kt_end; ++kt) {
-            const int cur = (kt - kt_beg) & 1;
+        auto tile = [&](auto S, int kt) __attribute__((always_inline)) {
+            constexpr int cur = decltype(S)::value;
             load_tile(kt + 1, I0{});
             compute(cur);
             store_tile(cur ^ 1, I0{});
             __syncthreads();
-        }
+        };
+        int kt = kt_beg;
+        for (; kt + 2 <= kt_end; kt += 2) { tile(IC<0>{}, kt); tile(IC<1>{}, kt + 1); }
+        if (kt < kt_end) tile(IC<0>{}, kt);
     }
 
     if constexpr (DUAL) acc[0][0] += acc_odd;

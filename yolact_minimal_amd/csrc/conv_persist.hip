@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void conv_igemm_pers(const ConvP p) {
     int* s_flag = reinterpret_cast<int*>(smem + NS * STAGE + (DEFER ? BM * BN : 0));
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the DMA's LDS destination goes through M0
     const int wm = wave >> 1, wn = wave & 1;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void conv_igemm_pers(const ConvP p) {
     const int c4 = (tid & 7) ^ ((tid >> 4) & 7);   // which float4 of the 32-float K row this lane fetches (XOR swizzle, see conv_mfma.hip)
     const int rbase = tid >> 3;                    // 0..31
     int a_pix[AR], a_ih0[AR], a_iw0[AR];
-    unsigned wrow[BR], a_tapbase[AR], a_mask[AR];
+    unsigned wrow[BR], a_off[AR];              // per-lane byte offsets; the K position inside the tap / the filter row goes in `soffset`
     int kh = 0, kw = 0, c0 = 0;
     bool tap_dirty = true;
     int ld_item = (int)blockIdx.x, ld_kt = 0, ld_end = 0;
@@ -147,7 +147,10 @@ __global__ __launch_bounds__(256) void conv_igemm_pers(const ConvP p) {
         ld_kt = it.kt_beg; ld_end = live ? it.kt_end : 0x7FFFFFFF;
     };
 
-    // next K tile of the stream -> ring stage `stage` (asynchronous, tracked by vmcnt: AR + BR loads per lane, always)
+    // next K tile of the stream -> ring stage `stage` (asynchronous, tracked by vmcnt: AR + BR loads per lane, always).  No VALU
+    // work per tile (VALU instructions take MFMA issue slots, tools/micro/mfma_lds.hip): the lane offsets change only with the filter
+    // tap, the block-uniform K offsets ride in the instruction's SGPR offset (excluded from the range check, so a masked lane stays
+    // out of range), and the LDS destination is scalar.
     auto dma_next = [&](int stage) __attribute__((always_inline)) {
         typedef __attribute__((address_space(3))) void* lds_ptr;
         if (ld_kt == ld_end) {                     // block-uniform
@@ -161,28 +164,24 @@ __global__ __launch_bounds__(256) void conv_igemm_pers(const ConvP p) {
                 if (MODE == 0) {
                     const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
                     const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-                    a_tapbase[i] = (unsigned)(((a_pix[i] + kh * p.W + kw) * p.Cin + c4 * 4) * 4);
-                    a_mask[i] = ok ? 0u : OOB;
+                    a_off[i] = (unsigned)(((a_pix[i] + kh * p.W + kw) * p.Cin + c4 * 4) * 4) | (ok ? 0u : OOB);
                 } else {
                     const int sh = p.stride >> 1, smask = p.stride - 1;     // stride is 1 or 2
                     const int th = a_ih0[i] - kh, tw = a_iw0[i] - kw;
                     const int yh = th >> sh, yw = tw >> sh;
                     const bool ok = th >= 0 && tw >= 0 && ((th | tw) & smask) == 0 && yh < p.H && yw < p.W;
-                    a_tapbase[i] = (unsigned)((((a_pix[i] + yh) * p.W + yw) * p.Cin + c4 * 4) * 4);
-                    a_mask[i] = ok ? 0u : OOB;
+                    a_off[i] = (unsigned)((((a_pix[i] + yh) * p.W + yw) * p.Cin + c4 * 4) * 4) | (ok ? 0u : OOB);
                 }
             }
         }
         float* a = smem + stage * STAGE + 8 * wave * RP;        // wave-uniform; lane l lands at +16 l bytes = row l / 8, slot l % 8
         float* b = a + BM * RP;
-        const unsigned c0b = (unsigned)(c0 * 4);
 #pragma unroll
         for (int i = 0; i < AR; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr)(a + 32 * i * RP), 16, (int)((a_tapbase[i] + c0b) | a_mask[i]), 0, 0, 0);
-        const unsigned kb = (unsigned)(ld_kt * BK * 4);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr)(a + 32 * i * RP), 16, (int)a_off[i], c0 * 4, 0, 0);
 #pragma unroll
         for (int i = 0; i < BR; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(b + 32 * i * RP), 16, (int)(wrow[i] + kb), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(b + 32 * i * RP), 16, (int)wrow[i], ld_kt * BK * 4, 0, 0);
         ++ld_kt;
         c0 += BK;
         if (c0 >= p.Cin) {
