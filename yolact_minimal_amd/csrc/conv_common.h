@@ -28,8 +28,9 @@ constexpr unsigned OOB = 0xFFFFFFF0u;
 __device__ __forceinline__ f32x4 buf_ld16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
 }
-// The same with the block-uniform part of the offset in the instruction's SGPR operand (`soffset`: added to the address, NOT part
-// of the range check, so a lane whose `byte_off` is out of range still reads 0).  Every VALU instruction of a K loop takes an issue
+// The same with the block-uniform part of the offset in the instruction's SGPR operand (`soffset`).  The range check compares
+// lane offset + SGPR offset with the record count WITHOUT wrapping at 32 bits (measured: conv_wgrad_dma), so a lane whose
+// `byte_off` is the out-of-range marker still reads 0 whatever the SGPR offset is.  Every VALU instruction of a K loop takes an issue
 // slot from the MFMAs (tools/micro/mfma_lds.hip: 48 extra VALU instructions per 16 MFMAs = -17 % of the matrix pipe; the
 // persistent 64x64 kernel gained 5 % from the 14 it lost this way), so the K loops keep their per-tile offset arithmetic scalar.
 __device__ __forceinline__ f32x4 buf_ld16_s(__amdgpu_buffer_rsrc_t r, unsigned byte_off, int soffset) {

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
     // bytes of staging row i as a per-lane byte offset + a block-uniform one (-> the load's SGPR offset).  There is NO per-tile
     // vector arithmetic: everything that depends on the filter tap (bounds test, pixel offset) is refreshed only when the tap
     // changes (every Cin/32 tiles; never for a 1x1 conv), rows that must read zeros carry an all-ones mask in the lane offset
-    // (offset | 0xFFFFFFF0 is beyond any buffer -> the raw buffer load returns 0; the SGPR offset is not range-checked), and
+    // (offset | 0xFFFFFFF0 is beyond any buffer -> the raw buffer load returns 0 whatever the SGPR offset adds: no 32-bit wrap), and
     // weight rows past Cout sit at the END of the buffer.  Tiles past the end of this block's K range are fetched like any other
     // (the counted vmcnt waits need an unconditional load count) and never consumed — a buffer load cannot fault.
     unsigned a_off[AR];

@@ -149,8 +149,8 @@ __global__ __launch_bounds__(256) void conv_igemm_pers(const ConvP p) {
 
     // next K tile of the stream -> ring stage `stage` (asynchronous, tracked by vmcnt: AR + BR loads per lane, always).  No VALU
     // work per tile (VALU instructions take MFMA issue slots, tools/micro/mfma_lds.hip): the lane offsets change only with the filter
-    // tap, the block-uniform K offsets ride in the instruction's SGPR offset (excluded from the range check, so a masked lane stays
-    // out of range), and the LDS destination is scalar.
+    // tap, the block-uniform K offsets ride in the instruction's SGPR offset (the range check does not wrap at 32 bits, so a masked
+    // lane stays out of range), and the LDS destination is scalar.
     auto dma_next = [&](int stage) __attribute__((always_inline)) {
         typedef __attribute__((address_space(3))) void* lds_ptr;
         if (ld_kt == ld_end) {                     // block-uniform

@@ -220,6 +220,159 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradP p) {
     }
 }
 
+// DMA-staged weight gradient (`lds_buffers` 22 / 23 / 24), Cin % 32 == 0, n tile 128.  Same products in the same order as
+// conv_wgrad_f32 -- for one `msplit` the same bits -- but the operand stream is organised so that the pixel loop carries almost no
+// vector arithmetic: VALU instructions take issue slots from the MFMAs (conv_common.h), and conv_wgrad_f32 spends 160-180 of them
+// per 64 MFMAs on the coordinates of FOUR staging pixels per thread (0.57 MFMA-busy).  Here
+//   * a DMA instruction (64 lanes x 16 B = 1 KB of LDS) covers 8 pixels x one 32-channel group, so every lane works on ONE pixel of
+//     the step and its NR loads per operand differ only in the channel group: the LDS image is [stage][group 0-3][pixel][32];
+//   * dY is linear in the pixel index: lane offset fixed for the whole slice, the step in the load's SGPR offset -- no VALU at all;
+//   * X: one pixel decomposition per lane and step; the filter tap of a channel group is block-uniform and rides in the SGPR offset
+//     (the descriptor's base is moved back by the padding so that the lane offset is never negative);
+//     padding taps / rows past the slice / channel groups past K read zeros through an out-of-range lane offset;
+//   * the ring is unrolled by its depth: fragment reads and DMA destinations are register + immediate.
+template <int NB, int TM>
+__global__ __launch_bounds__(256) void conv_wgrad_dma(const WgradP p) {
+    constexpr int NR = TM / 8;                   // DMA instructions per operand, step and wave
+    constexpr int PBK = TM / 8;                  // 8-pixel blocks per step
+    constexpr int GS = TM * 32;                  // floats of one (stage, channel group): [pixel][32]
+    constexpr int STG = 4 * GS;                  // floats per stage and operand
+    constexpr int D = NB - 1;                    // prefetch distance in pixel steps
+    static_assert(2 * NR * (D > 0 ? D - 1 : 0) < 16, "vmcnt field");
+    constexpr int WAIT = 0x070 | (2 * NR * (D - 1));            // vmcnt(2 NR (D-1)) lgkmcnt(0)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ys = smem;                            // [NB][4][TM][32]
+    float* Xs = smem + NB * STG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wk = wave & 1;
+
+    int id = ym_xcd_remap(blockIdx.x, gridDim.x);
+    const int ms = id % p.msplit;
+    id /= p.msplit;
+    const int tile_n = id / p.tiles_k, tile_k = id - tile_n * p.tiles_k;
+    const int n0 = tile_n * 128, k0 = tile_k * TBK;
+    const int m_beg = ms * p.m_per_split, m_end = min(p.M, m_beg + p.m_per_split);
+
+    // this wave's DMA instructions j = 0 .. NR-1: pixel block `pbk` of the step, channel groups g0 + j
+    const int pbk = wave % PBK, g0 = (wave / PBK) * NR;
+    const int prow = 8 * pbk + (lane >> 3), c4 = lane & 7;
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
+    // X: the base is moved back by the padding, the lane offset addresses pixel (oh*s, ow*s), the tap adds (kh*W + kw) pixels
+    const long long padoff = (long long)(p.pad * p.W + p.pad) * p.Cinp * 4;
+    // (the range check compares lane offset + SGPR offset with the record count: the count grows by what the base moved back)
+    const __amdgpu_buffer_rsrc_t rs_x =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x - padoff), 0, p.x_bytes + (unsigned)padoff, 0x00020000);
+    unsigned yv[NR], kmask[NR];
+    int xs_off[NR], khp[NR], kwp[NR];            // block-uniform per channel group: byte offset of its tap + channel, tap - pad
+    bool plain = p.KH * p.KW == 1 && p.pad == 0; // no bounds test, no masks: the lane offset is used as it is
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int ncol = n0 + (g0 + j) * 32 + c4 * 4;
+        yv[j] = (unsigned)(((m_beg + prow) * p.Cout + ncol) * 4) | (ncol < p.Cout ? 0u : OOB);
+        const int kk = k0 + (g0 + j) * 32;       // (Cin % 32 == 0: a group never straddles two taps, K is a multiple of 32)
+        const bool k_ok = kk < p.Ktot;
+        const int tap = k_ok ? kk / p.Cinp : 0, ci = kk - tap * p.Cinp;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        xs_off[j] = k_ok ? ((kh * p.W + kw) * p.Cinp + ci) * 4 : 0;
+        khp[j] = kh - p.pad; kwp[j] = kw - p.pad;
+        kmask[j] = k_ok ? 0u : OOB;
+        plain = plain && k_ok;
+    }
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    // (`stage` is a literal at every call site and the lambdas are inlined)
+    auto load = [&](int mt, int stage) __attribute__((always_inline)) {
+        float* yd = Ys + ((stage * 4 + g0) * TM + 8 * pbk) * 32;          // scalar; lane l lands at +16 l bytes = pixel l / 8, slot l % 8
+        float* xd = Xs + ((stage * 4 + g0) * TM + 8 * pbk) * 32;
+        const int ystep = (mt - m_beg) * p.Cout * 4;
+        const unsigned m = (unsigned)(mt + prow);
+        const unsigned b = fastdiv(m, p.mg_howo, p.sh_howo);
+        const unsigned rem = m - b * p.HoWo;
+        const unsigned oh = fastdiv(rem, p.mg_wo, p.sh_wo);
+        const unsigned ow = rem - oh * p.Wo;
+        const int ih0 = (int)oh * p.stride, iw0 = (int)ow * p.stride;
+        const unsigned xb = (unsigned)((((int)b * p.H + ih0) * p.W + iw0) * p.Cinp * 4 + c4 * 16);
+        if (mt + TM <= m_end && plain) {         // block-uniform: the common step of a 1x1 convolution
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const int xo = xs_off[j];        // (a copy: hipcc's host pass silently drops the kernel when an array ELEMENT is passed here)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_ptr)(yd + j * GS), 16, (int)yv[j], ystep, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr)(xd + j * GS), 16, (int)xb, xo, 0, 0);
+            }
+        } else {
+            const unsigned dead = (int)m < m_end ? 0u : OOB;              // rows past the slice (its last step; the run-ahead loads)
+            unsigned inside = 0u;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                if (j == 0 || khp[j] != khp[j - 1] || kwp[j] != kwp[j - 1]) {      // block-uniform: a new tap
+                    const int ih = ih0 + khp[j], iw = iw0 + kwp[j];
+                    inside = ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) ? 0u : OOB;
+                }
+                const int xo = xs_off[j];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_ptr)(yd + j * GS), 16, (int)(yv[j] | dead), ystep, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr)(xd + j * GS), 16, (int)(xb | inside | kmask[j] | dead), xo, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int fr = lane & 31, khalf = lane >> 5;
+    const float* ya = Ys + (wn * 2 * TM + khalf) * 32 + fr;             // pixel row 2s + khalf of groups 2 wn, 2 wn + 1
+    const float* xf = Xs + (wk * 2 * TM + khalf) * 32 + fr;
+    auto compute = [&](int stage) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < TM / 2; ++s) {
+            const float a0 = ya[stage * STG + 2 * s * 32], a1 = ya[stage * STG + GS + 2 * s * 32];
+            const float b0 = xf[stage * STG + 2 * s * 32], b1 = xf[stage * STG + GS + 2 * s * 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    };
+
+    static_for<0, D>([&](auto SC) __attribute__((always_inline)) { load(m_beg + decltype(SC)::value * TM, decltype(SC)::value); });
+    __builtin_amdgcn_s_waitcnt(WAIT);                                   // step 0 has landed
+    __builtin_amdgcn_s_barrier();
+    auto step = [&](auto SC, int mt) __attribute__((always_inline)) {
+        constexpr int cur = decltype(SC)::value;
+        load(mt + D * TM, (cur + D) % NB);                              // into the stage step t-1 was read from
+        compute(cur);
+        // this wave's DMA of step t+1 has landed and its reads of step t are retired (lgkmcnt(0): the DMA issued after the barrier
+        // re-stages that buffer) ... and so for every wave after the barrier
+        __builtin_amdgcn_s_waitcnt(WAIT);
+        __builtin_amdgcn_s_barrier();
+    };
+    int mt = m_beg;
+    for (; mt + (NB - 1) * TM < m_end; mt += NB * TM)
+        static_for<0, NB>([&](auto SC) __attribute__((always_inline)) { step(SC, mt + decltype(SC)::value * TM); });
+    static_for<0, NB - 1>([&](auto SC) __attribute__((always_inline)) {
+        if (mt + decltype(SC)::value * TM < m_end) step(SC, mt + decltype(SC)::value * TM);
+    });
+    __builtin_amdgcn_s_waitcnt(0xF70);           // the past-the-end prefetches (zeros) are still landing in LDS
+
+    // D[i = n][j = kk]: col = lane&31 -> kk, row = (r&3) + 8*(r>>2) + 4*khalf -> n
+    float* wsb = p.ws + (size_t)ms * p.Cout * p.Ktot;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int kcol = k0 + wk * 64 + j * 32 + fr;
+        if (kcol >= p.Ktot) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * 64 + i * 32 + 4 * khalf + (r & 3) + 8 * (r >> 2);
+                if (n < p.Cout) wsb[(size_t)n * p.Ktot + kcol] = acc[i][j][r];
+            }
+        }
+    }
+}
+
 // sum the msplit slabs in order and scatter [n][tap][ci] -> OIHW [n][ci][kh][kw] (ci < Cin_real); rows may be routed to up to three
 // OIHW tensors (ym_wgrad_desc.row_end / dw_seg) and added to what is there (accumulate)
 struct WOut { float* dw[3]; int row_end[3]; int accumulate; };
@@ -264,7 +417,11 @@ int wplan(const ym_wgrad_desc* d, WPlan* pl) {
     pl->nb = d->lds_buffers == 1 ? 1 : 2;
     if (d->lds_buffers == 22 || d->lds_buffers == 23 || d->lds_buffers == 24) {
         YM_REQUIRE(pl->tbn == 128, "wgrad: the DMA-staged variants (lds_buffers 22/23/24) need more than 64 output channels");
-        pl->nb = d->lds_buffers;
+        // conv_wgrad_dma: whole 32-channel groups per filter tap (and a padding the usual convolutions have); anything else runs
+        // on the register-staged double buffer
+        const bool dma_ok = d->Cin % 32 == 0 && 2 * d->pad <= d->KH - 1 && 2 * d->pad <= d->KW - 1 &&
+                            (unsigned long long)d->B * d->H * d->W * d->Cin * 4ull + (unsigned long long)(d->pad * d->W + d->pad) * d->Cin * 4ull < 0xFFFFFFF0ull;
+        pl->nb = dma_ok ? d->lds_buffers : 2;
     }
     pl->tiles_n = ym_cdiv(d->Cout, pl->tbn);
     pl->tiles_k = ym_cdiv(pl->Ktot, TBK);
@@ -322,9 +479,8 @@ extern "C" int ym_conv2d_wgrad(const ym_wgrad_desc* d, void* workspace, size_t w
         YM_WG_ATTR(0, 128, 2); YM_WG_ATTR(1, 128, 2); YM_WG_ATTR(0, 64, 2); YM_WG_ATTR(1, 64, 2);
         YM_WG_ATTR(0, 128, 1); YM_WG_ATTR(1, 128, 1); YM_WG_ATTR(0, 64, 1); YM_WG_ATTR(1, 64, 1);
 #undef YM_WG_ATTR
-#define YM_WG_ATTR_DL(I, N, T) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_f32<I, 128, N, true, T>), hipFuncAttributeMaxDynamicSharedMemorySize, big)
-        YM_WG_ATTR_DL(0, 2, 32); YM_WG_ATTR_DL(1, 2, 32); YM_WG_ATTR_DL(0, 3, 16); YM_WG_ATTR_DL(1, 3, 16);
-        YM_WG_ATTR_DL(0, 4, 16); YM_WG_ATTR_DL(1, 4, 16);
+#define YM_WG_ATTR_DL(N, T) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_dma<N, T>), hipFuncAttributeMaxDynamicSharedMemorySize, big)
+        YM_WG_ATTR_DL(2, 32); YM_WG_ATTR_DL(3, 16); YM_WG_ATTR_DL(4, 16);
 #undef YM_WG_ATTR_DL
         attr_set = true;
     }
@@ -336,11 +492,7 @@ extern "C" int ym_conv2d_wgrad(const ym_wgrad_desc* d, void* workspace, size_t w
         if (p.incr) hipLaunchKernelGGL((conv_wgrad_f32<1, T, N>), wgrid, dim3(256), lds, st, p);   \
         else hipLaunchKernelGGL((conv_wgrad_f32<0, T, N>), wgrid, dim3(256), lds, st, p);          \
     } while (0)
-#define YM_WG_LAUNCH_DL(N, T)                                                                                  \
-    do {                                                                                                       \
-        if (p.incr) hipLaunchKernelGGL((conv_wgrad_f32<1, 128, N, true, T>), wgrid, dim3(256), lds, st, p);   \
-        else hipLaunchKernelGGL((conv_wgrad_f32<0, 128, N, true, T>), wgrid, dim3(256), lds, st, p);          \
-    } while (0)
+#define YM_WG_LAUNCH_DL(N, T) hipLaunchKernelGGL((conv_wgrad_dma<N, T>), wgrid, dim3(256), lds, st, p)
     if (pl.nb == 22) YM_WG_LAUNCH_DL(2, 32);
     else if (pl.nb == 23) YM_WG_LAUNCH_DL(3, 16);
     else if (pl.nb == 24) YM_WG_LAUNCH_DL(4, 16);
