@@ -49,7 +49,10 @@ __device__ __forceinline__ void wg_sync_lds() {
 // hand-off needs anyway.  The MFMAs of item i+1 start immediately after item i's last one.  Measured: +2 % (49.6 vs 50.8 us on the
 // 2320-tile layer3 conv at batch 8): co-resident workgroups cover each other's epilogues better than their phase-locked start
 // suggests; what bounds a 64x64 tile is the write of its operand tiles into LDS.
-template <int BM, int BN, int MODE, int NS, bool DEFER>
+// ALIGNED: every work item has a multiple of NS K tiles (checked on the host), so every item starts in ring stage 0 and the K loop
+// is unrolled by the ring depth with literal stages: fragment reads and DMA destinations are register + immediate, no address VALU
+// in the loop (the run-time-stage loop below needs 10 per K tile: VALU instructions take MFMA issue slots, conv_common.h).
+template <int BM, int BN, int MODE, int NS, bool DEFER, bool ALIGNED>
 __global__ __launch_bounds__(256) void conv_igemm_pers(const ConvP p) {
     static_assert(BM == 64 && BN == 64, "the accumulator staging aliases one ring stage: (BM + BN) * 128 B == BM * BN * 4 B");
     static_assert(MODE == 0 || MODE == 2, "Cin % 32 == 0 convolution / data gradient");
@@ -195,18 +198,23 @@ __global__ __launch_bounds__(256) void conv_igemm_pers(const ConvP p) {
     const int frag_row = lane & 31, khalf = lane >> 5;
     const int a_frag_off = (wm * 32 + frag_row) * RP;
     const int b_frag_off = BM * RP + (wn * 32 + frag_row) * RP;
-    int goff[4];
+    // this lane's fragment of K group g in stage 0: 8 LDS address registers; stage s = + s * STAGE, a literal in the ALIGNED loops
+    // (explicit LDS pointers: through generic pointers kept in an array hipcc fell back to flat loads)
+    typedef const __attribute__((address_space(3))) f32x4* lds_frag_ptr;
+    lds_frag_ptr pa[4], pb[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) goff[g] = ((2 * g + khalf) ^ ((frag_row >> 1) & 7)) * 4;
+    for (int g = 0; g < 4; ++g) {
+        const int goff = ((2 * g + khalf) ^ ((frag_row >> 1) & 7)) * 4;
+        pa[g] = (lds_frag_ptr)(smem + a_frag_off + goff);
+        pb[g] = (lds_frag_ptr)(smem + b_frag_off + goff);
+    }
     f32x16 acc, acc_odd;         // two accumulators take alternate K steps: consecutive MFMAs of the lone wave are independent
 
     auto compute = [&](int stage) __attribute__((always_inline)) {
-        const float* a = smem + stage * STAGE + a_frag_off;
-        const float* b = smem + stage * STAGE + b_frag_off;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 fa = *reinterpret_cast<const f32x4*>(a + goff[g]);
-            const f32x4 fb = *reinterpret_cast<const f32x4*>(b + goff[g]);
+            const f32x4 fa = pa[g][stage * (STAGE / 4)];
+            const f32x4 fb = pb[g][stage * (STAGE / 4)];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0], fb[0], acc, 0, 0, 0);
             acc_odd = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1], fb[1], acc_odd, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[2], fb[2], acc, 0, 0, 0);
@@ -215,8 +223,8 @@ __global__ __launch_bounds__(256) void conv_igemm_pers(const ConvP p) {
     };
 
     auto read_frag = [&](int stage, int g, f32x4& fa, f32x4& fb) __attribute__((always_inline)) {
-        fa = *reinterpret_cast<const f32x4*>(smem + stage * STAGE + a_frag_off + goff[g]);
-        fb = *reinterpret_cast<const f32x4*>(smem + stage * STAGE + b_frag_off + goff[g]);
+        fa = pa[g][stage * (STAGE / 4)];
+        fb = pb[g][stage * (STAGE / 4)];
     };
     auto mfma_group = [&](const f32x4& fa, const f32x4& fb) __attribute__((always_inline)) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0], fb[0], acc, 0, 0, 0);
@@ -314,7 +322,57 @@ __global__ __launch_bounds__(256) void conv_igemm_pers(const ConvP p) {
             }
         } else
 #endif
-        if constexpr (PF) {
+        if constexpr (ALIGNED && PF) {
+            f32x4 fa0, fb0, fa1, fb1;
+            read_frag(0, 0, fa0, fb0);             // (this tile landed at least one barrier ago)
+            // (the deferred stores of the previous item are issued between the first and the second tile, OUTSIDE the generic lambda:
+            // with flush_pending() inside it hipcc kept the closure in scratch memory)
+            auto tile = [&](auto SC, int t) __attribute__((always_inline)) {
+                    constexpr int B0 = decltype(SC)::value, B1 = (B0 + 1) % NS, BP = (B0 + NS - 1) % NS;
+                    dma_next(BP);
+                    read_frag(B0, 1, fa1, fb1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_group(fa0, fb0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_frag(B0, 2, fa0, fb0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_group(fa1, fb1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_frag(B0, 3, fa1, fb1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_group(fa0, fb0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (B0 + 1 < NS || t + NS < nt) read_frag(B1, 0, fa0, fb0);      // first group of this item's next tile
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_group(fa1, fb1);
+                    __builtin_amdgcn_s_waitcnt(WAIT);
+                    __builtin_amdgcn_s_barrier();
+            };
+            for (int t = 0; t < nt; t += NS) {
+                tile(IC<0>{}, t);
+                if constexpr (DEFER) {             // every wave's copy of the previous item's tile is in C2 now: issue its stores
+                    if (t == 0) { if (pend) flush_pending(); } else c_dirty = false;
+                }
+                static_for<1, NS>([&](auto SC) __attribute__((always_inline)) { tile(SC, t); });
+                if constexpr (DEFER) c_dirty = false;
+            }
+        } else if constexpr (ALIGNED) {
+            auto tile = [&](auto SC) __attribute__((always_inline)) {
+                constexpr int B0 = decltype(SC)::value;
+                dma_next((B0 + NS - 1) % NS);
+                compute(B0);
+                __builtin_amdgcn_s_waitcnt(WAIT);
+                __builtin_amdgcn_s_barrier();
+            };
+            for (int t = 0; t < nt; t += NS) {
+                tile(IC<0>{});
+                if constexpr (DEFER) {
+                    if (t == 0) { if (pend) flush_pending(); } else c_dirty = false;
+                }
+                static_for<1, NS>([&](auto SC) __attribute__((always_inline)) { tile(SC); });
+                if constexpr (DEFER) c_dirty = false;
+            }
+        } else if constexpr (PF) {
             f32x4 fa0, fb0, fa1, fb1;
             read_frag(buf, 0, fa0, fb0);           // (this tile landed at least one barrier ago)
             for (int t = 0; t < nt; ++t) {
@@ -462,27 +520,31 @@ __global__ __launch_bounds__(256) void conv_igemm_pers(const ConvP p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the run-ahead loads of "no work left" still target this workgroup's LDS
 }
 
-template <int BM, int BN, int MODE, int NS, bool DEFER>
+template <int BM, int BN, int MODE, int NS, bool DEFER, bool ALIGNED>
 int launch_pers(const ConvP& p, int grid, hipStream_t st) {
     const size_t lds = ym_conv_pers_lds_bytes(BM, BN, NS, DEFER);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_pers<BM, BN, MODE, NS, DEFER>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_pers<BM, BN, MODE, NS, DEFER, ALIGNED>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_pers<BM, BN, MODE, NS, DEFER>), dim3(grid), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv_igemm_pers<BM, BN, MODE, NS, DEFER, ALIGNED>), dim3(grid), dim3(256), lds, st, p);
     return ym_check_launch("conv_igemm_pers");
 }
 
 template <int MODE, bool DEFER>
 int launch_pers_ns(const ConvP& p, int ns, int grid, hipStream_t st) {
+    // every item a multiple of `ns` K tiles?  (main slices: kt_per_split each, the last one the rest; tail slices: tail_ktps)
+    const bool main_ok = p.main_blocks == 0 || (p.nkt % ns == 0 && (p.ksplit == 1 || p.kt_per_split % ns == 0));
+    const bool tail_ok = p.total_items == p.main_blocks || (p.nkt % ns == 0 && p.tail_ktps % ns == 0);
+    const bool al = main_ok && tail_ok && ns <= 4;
     switch (ns) {
-        case 2: return launch_pers<64, 64, MODE, 2, DEFER>(p, grid, st);
-        case 3: return launch_pers<64, 64, MODE, 3, DEFER>(p, grid, st);
-        case 4: return launch_pers<64, 64, MODE, 4, DEFER>(p, grid, st);
-        case 6: return launch_pers<64, 64, MODE, 6, DEFER>(p, grid, st);
-        case 8: return launch_pers<64, 64, MODE, 8, DEFER>(p, grid, st);
+        case 2: return al ? launch_pers<64, 64, MODE, 2, DEFER, true>(p, grid, st) : launch_pers<64, 64, MODE, 2, DEFER, false>(p, grid, st);
+        case 3: return al ? launch_pers<64, 64, MODE, 3, DEFER, true>(p, grid, st) : launch_pers<64, 64, MODE, 3, DEFER, false>(p, grid, st);
+        case 4: return al ? launch_pers<64, 64, MODE, 4, DEFER, true>(p, grid, st) : launch_pers<64, 64, MODE, 4, DEFER, false>(p, grid, st);
+        case 6: return launch_pers<64, 64, MODE, 6, DEFER, false>(p, grid, st);
+        case 8: return launch_pers<64, 64, MODE, 8, DEFER, false>(p, grid, st);
         default: ym_set_error("conv(persistent): ring depth %d not built (2, 3, 4, 6, 8)", ns); return YM_EINVAL;
     }
 }
