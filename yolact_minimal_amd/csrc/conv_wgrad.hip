@@ -376,13 +376,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma(const WgradP p) {
 // sum the msplit slabs in order and scatter [n][tap][ci] -> OIHW [n][ci][kh][kw] (ci < Cin_real); rows may be routed to up to three
 // OIHW tensors (ym_wgrad_desc.row_end / dw_seg) and added to what is there (accumulate)
 struct WOut { float* dw[3]; int row_end[3]; int accumulate; };
+// (32-bit indices and multiply-shift divisions: this kernel runs on the side stream UNDER the data-gradient MFMA kernels, and its
+// vector instructions -- two integer divisions per element were ~80 of them -- take issue slots from their MFMAs)
 __global__ __launch_bounds__(256) void wgrad_reduce_unpack(const float* __restrict__ ws, const WOut o, int msplit,
-                                                           int Cout_real, int Cout, int Ktot, int Cinp, int Cin_real, int KHW) {
-    const size_t total = (size_t)Cout_real * Ktot;
+                                                           int Cout_real, int Cout, int Ktot, int Cinp, int Cin_real, int KHW,
+                                                           FastDiv fd_ktot, FastDiv fd_cinp) {
+    const unsigned total = (unsigned)Cout_real * (unsigned)Ktot;
     const size_t slab = (size_t)Cout * Ktot;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        const int n = (int)(e / Ktot), kk = (int)(e - (size_t)n * Ktot);
-        const int tap = kk / Cinp, ci = kk - tap * Cinp;
+    for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
+        unsigned un, ukk, utap, uci;
+        fd_ktot.divmod(e, un, ukk);
+        fd_cinp.divmod(ukk, utap, uci);
+        const int n = (int)un, tap = (int)utap, ci = (int)uci;
         if (ci >= Cin_real) continue;
         float v = 0.f;
         for (int s = 0; s < msplit; ++s) v += ws[(size_t)s * slab + e];
@@ -515,7 +520,8 @@ extern "C" int ym_conv2d_wgrad(const ym_wgrad_desc* d, void* workspace, size_t w
         o.dw[0] = d->dw; o.dw[1] = d->dw; o.dw[2] = d->dw;
         o.row_end[0] = d->Cout_real; o.row_end[1] = d->Cout_real; o.row_end[2] = d->Cout_real;
     }
+    YM_REQUIRE(total < (1ull << 31), "wgrad: gradient tensor too large for 32-bit indexing");
     hipLaunchKernelGGL(wgrad_reduce_unpack, dim3(grid), dim3(256), 0, st, (const float*)workspace, o, pl.msplit, d->Cout_real,
-                       d->Cout, pl.Ktot, d->Cin, d->Cin_real, d->KH * d->KW);
+                       d->Cout, pl.Ktot, d->Cin, d->Cin_real, d->KH * d->KW, FastDiv::make((unsigned)pl.Ktot), FastDiv::make((unsigned)d->Cin));
     return ym_check_launch("wgrad_reduce_unpack");
 }
