@@ -13,8 +13,8 @@ Image size is 544 (the reference cannot run at 550: SURVEY.md §0.1).  Weights: 
 `--inflight S` (default 4 at bs=1): S independent bs=1 requests are in flight on S HIP streams (S engines with their own activations,
 split-K scratch, arrival counters and hipGraphs; GPU_MAX_HW_QUEUES=8 so that every stream has a hardware queue of its own).  A
 bs=1 forward is a chain of ~190 dependent launches, each ~9 us of launch boundary + address set-up + epilogue around ~7 us of MFMA
-work, so ONE chain keeps the matrix pipe ~35 % busy; the other requests' kernels run in those holes.  Measured on one MI355X,
-forward + nms + after_nms: 1 request 325 img/s, 2: 468, 3: 545, 4: 594, 5: 495, 6: 532, 8: 479 (the part runs four compute pipes).
+work, so ONE chain keeps the matrix pipe ~35 % busy; the other requests' kernels run in those holes.  Measured on one MI355X
+(mid-round 3; the end-of-round figures are 338 / 600), forward + nms + after_nms: 1 request 325 img/s, 2: 468, 3: 545, 4: 594, 5: 495, 6: 532, 8: 479 (the part runs four compute pipes).
 Every step is still ONE image through forward + nms + after_nms with ONE host read of its detection count (taken when the slot is
 reused, S steps later: the count is copied to pinned memory behind the request, so the host never waits on what it just
 enqueued).  `--inflight 1` is the single-request latency mode of rounds 1-2; its numbers stay in the line under
@@ -580,6 +580,11 @@ def main():
                 f3 = Workload(n2, c2, b, args.img_size, device, with_post=False, inflight=2)
                 tf3 = timed(f3, 16, 4, lambda: None) / 16
                 del f3
+                tf4 = None
+                if name == args.cfg:                  # four batches in flight (forward only), the named backbone only
+                    f4 = Workload(n2, c2, b, args.img_size, device, with_post=False, inflight=4)
+                    tf4 = timed(f4, 24, 8, lambda: None) / 24
+                    del f4
                 if name.startswith('swin'):
                     fl2 += 1.8e9 * b          # attention matmuls (QK^T, PV), not run by the conv kernel
                 extra[f'{name}_bs{b}'] = dict(img_s=round(b / t3, 1), forward_only_img_s=round(b / tf3, 1),
@@ -587,6 +592,9 @@ def main():
                                               frac_f32_mfma_peak=round(fl2 / tf3 / 1e12 / F32_MFMA_PEAK_TFLOPS, 4), batches_in_flight=2,
                                               one_batch_at_a_time=dict(img_s=round(b * 8 / t2, 1), forward_only_img_s=round(b / tf2, 1),
                                                                        frac_f32_mfma_peak=round(fl2 / tf2 / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)))
+                if tf4 is not None:
+                    extra[f'{name}_bs{b}']['four_batches_in_flight'] = dict(
+                        forward_only_img_s=round(b / tf4, 1), frac_f32_mfma_peak=round(fl2 / tf4 / 1e12 / F32_MFMA_PEAK_TFLOPS, 4))
         if not args.no_extra and world == 1:
             extra['post'] = post_bench(net, cfg, device, args.img_size)
             if args.batch == 1 and not args.no_post:

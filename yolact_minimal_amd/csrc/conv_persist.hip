@@ -48,7 +48,7 @@ __device__ __forceinline__ void wg_sync_lds() {
 // 16-byte stores) runs inside the NEXT item's K loop, right after the barrier that ends its first K tile -- the barrier the tile
 // hand-off needs anyway.  The MFMAs of item i+1 start immediately after item i's last one.  Measured: +2 % (49.6 vs 50.8 us on the
 // 2320-tile layer3 conv at batch 8): co-resident workgroups cover each other's epilogues better than their phase-locked start
-// suggests; what bounds a 64x64 tile is the write of its operand tiles into LDS.
+// suggests.
 // ALIGNED: every work item has a multiple of NS K tiles (checked on the host), so every item starts in ring stage 0 and the K loop
 // is unrolled by the ring depth with literal stages: fragment reads and DMA destinations are register + immediate, no address VALU
 // in the loop (the run-time-stage loop below needs 10 per K tile: VALU instructions take MFMA issue slots, conv_common.h).

@@ -1,4 +1,4 @@
-"""Serving with several independent requests in flight on one MI355X (batch 1: 325 -> 594 img/s; batch 8: 673 -> 739 forward-only).
+"""Serving with several independent requests in flight on one MI355X (batch 1: 338 -> 600 img/s; batch 8: 700 -> 760 forward-only).
 
 The reference evaluates one image at a time (`eval.py:36-69`: forward -> nms -> after_nms, a device synchronisation around each).
 On this part a bs=1 forward is a chain of ~190 dependent launches of 0.6-1.4 GFLOP each: every launch pays a kernel boundary, an
@@ -10,7 +10,7 @@ but the read-only weights) and `depth` HIP streams, and runs request i on slot i
 the count is copied to pinned host memory behind the request and read when the slot comes up again, so the host never waits on
 the request it has just enqueued.
 
-Measured (res101_coco 544 px, MI355X, forward + nms + after_nms(480x640)): depth 1: 325 img/s, 2: 468, 3: 545, 4: 594, 5: 495,
+Measured mid-round 3 (res101_coco 544 px, MI355X, forward + nms + after_nms(480x640)): depth 1: 325 img/s, 2: 468, 3: 545, 4: 594, 5: 495,
 8: 479 -- the part schedules four compute pipes; GPU_MAX_HW_QUEUES must be >= depth + 1 (ROCm multiplexes HIP streams onto 4
 hardware queues by default and two streams that share a queue do not overlap): set it to 8 before the first HIP call.
 """
