@@ -251,8 +251,8 @@ typedef struct {
                              /* [row_end[1],Cout_real) -> dw_seg[1].  row_end[0] = 0 means a single tensor (dw).                 */
     int32_t lds_buffers;     /* tuning knob: 0 / 2 = double-buffered pixel steps (2 workgroups per CU), 1 = single buffer (3 per CU);   */
                              /* 22 / 23 / 24 = operands DMA'd global -> LDS (no staging registers): 32 pixels x ring of 2, 16 pixels x  */
-                             /* ring of 3 / 4 (more than 64 output channels only).  Same products in the same order: for a given        */
-                             /* msplit every variant returns the same bits.                                                              */
+                             /* ring of 3 / 4 (more than 64 output channels only; Cin % 32 != 0 runs as 2).  Same products in the same  */
+                             /* order: for a given msplit every variant returns the same bits.                                           */
 } ym_wgrad_desc;
 size_t ym_conv2d_wgrad_workspace_bytes(const ym_wgrad_desc* d);
 int ym_conv2d_wgrad(const ym_wgrad_desc* d, void* workspace, size_t workspace_bytes, ym_stream_t s);

@@ -180,7 +180,8 @@ def test_bn_backward_sums_ride_on_the_consumers_dgrad(force_stages, force_grid, 
 
 @pytest.mark.parametrize('cin,cout,k,stride,hw,b,msplit', [(128, 256, 1, 1, 34, 4, 7), (64, 128, 3, 1, 23, 3, 5), (128, 160, 3, 2, 30, 2, 3),
                                                            (4, 96, 7, 2, 64, 2, 9), (256, 352, 3, 1, 9, 8, 2), (256, 256, 3, 2, 10, 2, 4),
-                                                           (128, 192, 1, 1, 3, 1, 1)])
+                                                           (128, 192, 1, 1, 3, 1, 1), (64, 64, 3, 1, 21, 2, 3), (256, 64, 1, 1, 17, 3, 2),
+                                                           (64, 48, 3, 2, 19, 2, 2)])
 def test_conv_wgrad_staging_variants_agree(cin, cout, k, stride, hw, b, msplit):
     """Weight gradient under every operand-staging variant (ym_wgrad_desc.lds_buffers: registers 2 / 1, DMA rings 22 / 23 / 24): the
     pixel reduction runs in the same order in all of them, so for one msplit the results are the SAME BITS; repeated launches of
@@ -200,7 +201,8 @@ def test_conv_wgrad_staging_variants_agree(cin, cout, k, stride, hw, b, msplit):
     xg, dyg = xg.to(DEV), _nhwc(dy).to(DEV)
     ws = torch.empty(1 << 27, dtype=torch.uint8, device=DEV)
     outs = {}
-    for nb in (2, 1, 22, 23, 24):
+    variants = (2, 1, 22, 23, 24) if cout > 64 else (2, 1, 22)      # (<= 64 output channels: the 64-wide n tile has one DMA ring)
+    for nb in variants:
         d = WgradDesc()
         dw = torch.full((cout, cin_real, k, k), float('nan'), device=DEV)
         d.x, d.dy, d.dw = xg.data_ptr(), dyg.data_ptr(), dw.data_ptr()
@@ -214,7 +216,7 @@ def test_conv_wgrad_staging_variants_agree(cin, cout, k, stride, hw, b, msplit):
         for r_ in runs[1:]:
             assert torch.equal(r_, runs[0]), f'lds_buffers={nb}: run-to-run difference'
         outs[nb] = runs[0]
-    for nb in (1, 22, 23, 24):
+    for nb in variants[1:]:
         assert torch.equal(outs[nb], outs[2]), f'lds_buffers={nb} differs from the double-buffered variant'
     scale = float(want.abs().max())
     torch.testing.assert_close(outs[2], want, rtol=2e-4, atol=2e-5 * max(1.0, scale))

@@ -231,30 +231,35 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradP p) {
 //     (the descriptor's base is moved back by the padding so that the lane offset is never negative);
 //     padding taps / rows past the slice / channel groups past K read zeros through an out-of-range lane offset;
 //   * the ring is unrolled by its depth: fragment reads and DMA destinations are register + immediate.
-template <int NB, int TM>
+// TBN = 64 (layers with <= 64 output channels): two dY groups, waves 1 x 4 of 64(n) x 32(kk) as in conv_wgrad_f32<., 64>.
+template <int NB, int TM, int TBN = 128>
 __global__ __launch_bounds__(256) void conv_wgrad_dma(const WgradP p) {
-    constexpr int NR = TM / 8;                   // DMA instructions per operand, step and wave
     constexpr int PBK = TM / 8;                  // 8-pixel blocks per step
+    constexpr int WPB = 4 / PBK;                 // waves per pixel block
+    constexpr int NGY = TBN / 32;                // 32-channel groups of the dY tile (the X tile always has 4)
+    constexpr int NRY = NGY / WPB, NRX = 4 / WPB;    // DMA instructions per step and wave: dY, X
+    constexpr int KT = TBN == 128 ? 2 : 1;       // 32-wide kk blocks per wave
+    static_assert(NRY >= 1, "64-wide n tile: 32-pixel steps only");
     constexpr int GS = TM * 32;                  // floats of one (stage, channel group): [pixel][32]
-    constexpr int STG = 4 * GS;                  // floats per stage and operand
+    constexpr int STGY = NGY * GS, STGX = 4 * GS;    // floats per stage
     constexpr int D = NB - 1;                    // prefetch distance in pixel steps
-    static_assert(2 * NR * (D > 0 ? D - 1 : 0) < 16, "vmcnt field");
-    constexpr int WAIT = 0x070 | (2 * NR * (D - 1));            // vmcnt(2 NR (D-1)) lgkmcnt(0)
+    static_assert((NRY + NRX) * (D > 0 ? D - 1 : 0) < 16, "vmcnt field");
+    constexpr int WAIT = 0x070 | ((NRY + NRX) * (D - 1));       // vmcnt((NRY + NRX)(D-1)) lgkmcnt(0)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ys = smem;                            // [NB][4][TM][32]
-    float* Xs = smem + NB * STG;
+    float* Ys = smem;                            // [NB][NGY][TM][32]
+    float* Xs = smem + NB * STGY;                // [NB][4][TM][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave >> 1, wk = wave & 1;
+    const int wn = TBN == 128 ? (wave >> 1) : 0, wk = TBN == 128 ? (wave & 1) : wave;
 
     int id = ym_xcd_remap(blockIdx.x, gridDim.x);
     const int ms = id % p.msplit;
     id /= p.msplit;
     const int tile_n = id / p.tiles_k, tile_k = id - tile_n * p.tiles_k;
-    const int n0 = tile_n * 128, k0 = tile_k * TBK;
+    const int n0 = tile_n * TBN, k0 = tile_k * TBK;
     const int m_beg = ms * p.m_per_split, m_end = min(p.M, m_beg + p.m_per_split);
 
-    // this wave's DMA instructions j = 0 .. NR-1: pixel block `pbk` of the step, channel groups g0 + j
-    const int pbk = wave % PBK, g0 = (wave / PBK) * NR;
+    // this wave's DMA instructions: pixel block `pbk` of the step, dY groups g0y + j (j < NRY), X groups g0x + j (j < NRX)
+    const int pbk = wave % PBK, g0y = (wave / PBK) * NRY, g0x = (wave / PBK) * NRX;
     const int prow = 8 * pbk + (lane >> 3), c4 = lane & 7;
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
     // X: the base is moved back by the padding, the lane offset addresses pixel (oh*s, ow*s), the tap adds (kh*W + kw) pixels
@@ -262,14 +267,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma(const WgradP p) {
     // (the range check compares lane offset + SGPR offset with the record count: the count grows by what the base moved back)
     const __amdgpu_buffer_rsrc_t rs_x =
         __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x - padoff), 0, p.x_bytes + (unsigned)padoff, 0x00020000);
-    unsigned yv[NR], kmask[NR];
-    int xs_off[NR], khp[NR], kwp[NR];            // block-uniform per channel group: byte offset of its tap + channel, tap - pad
+    unsigned yv[NRY], kmask[NRX];
+    int xs_off[NRX], khp[NRX], kwp[NRX];         // block-uniform per channel group: byte offset of its tap + channel, tap - pad
     bool plain = p.KH * p.KW == 1 && p.pad == 0; // no bounds test, no masks: the lane offset is used as it is
 #pragma unroll
-    for (int j = 0; j < NR; ++j) {
-        const int ncol = n0 + (g0 + j) * 32 + c4 * 4;
-        yv[j] = (unsigned)(((m_beg + prow) * p.Cout + ncol) * 4) | (ncol < p.Cout ? 0u : OOB);
-        const int kk = k0 + (g0 + j) * 32;       // (Cin % 32 == 0: a group never straddles two taps, K is a multiple of 32)
+    for (int j = 0; j < NRY; ++j) {
+        const int ncol = n0 + (g0y + j) * 32 + c4 * 4;
+        yv[j] = (unsigned)((m_beg + prow) * p.Cout + ncol) * 4u | (ncol < p.Cout ? 0u : OOB);
+    }
+#pragma unroll
+    for (int j = 0; j < NRX; ++j) {
+        const int kk = k0 + (g0x + j) * 32;      // (Cin % 32 == 0: a group never straddles two taps, K is a multiple of 32)
         const bool k_ok = kk < p.Ktot;
         const int tap = k_ok ? kk / p.Cinp : 0, ci = kk - tap * p.Cinp;
         const int kh = tap / p.KW, kw = tap - kh * p.KW;
@@ -281,58 +289,65 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma(const WgradP p) {
     typedef __attribute__((address_space(3))) void* lds_ptr;
     // (`stage` is a literal at every call site and the lambdas are inlined)
     auto load = [&](int mt, int stage) __attribute__((always_inline)) {
-        float* yd = Ys + ((stage * 4 + g0) * TM + 8 * pbk) * 32;          // scalar; lane l lands at +16 l bytes = pixel l / 8, slot l % 8
-        float* xd = Xs + ((stage * 4 + g0) * TM + 8 * pbk) * 32;
-        const int ystep = (mt - m_beg) * p.Cout * 4;
+        float* yd = Ys + ((stage * NGY + g0y) * TM + 8 * pbk) * 32;       // scalar; lane l lands at +16 l bytes = pixel l / 8, slot l % 8
+        float* xd = Xs + ((stage * 4 + g0x) * TM + 8 * pbk) * 32;
+        const int ystep = (int)((unsigned)((mt - m_beg) * p.Cout) * 4u);
         const unsigned m = (unsigned)(mt + prow);
         const unsigned b = fastdiv(m, p.mg_howo, p.sh_howo);
         const unsigned rem = m - b * p.HoWo;
         const unsigned oh = fastdiv(rem, p.mg_wo, p.sh_wo);
         const unsigned ow = rem - oh * p.Wo;
         const int ih0 = (int)oh * p.stride, iw0 = (int)ow * p.stride;
-        const unsigned xb = (unsigned)((((int)b * p.H + ih0) * p.W + iw0) * p.Cinp * 4 + c4 * 16);
+        const unsigned xb = (unsigned)((((int)b * p.H + ih0) * p.W + iw0) * p.Cinp) * 4u + (unsigned)(c4 * 16);   // (elements < 2^31, bytes < 2^32)
         if (mt + TM <= m_end && plain) {         // block-uniform: the common step of a 1x1 convolution
 #pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                const int xo = xs_off[j];        // (a copy: hipcc's host pass silently drops the kernel when an array ELEMENT is passed here)
+            for (int j = 0; j < NRY; ++j)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_ptr)(yd + j * GS), 16, (int)yv[j], ystep, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NRX; ++j) {
+                const int xo = xs_off[j];        // (a copy: hipcc's host pass silently drops the kernel when an array ELEMENT is passed here)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr)(xd + j * GS), 16, (int)xb, xo, 0, 0);
             }
         } else {
             const unsigned dead = (int)m < m_end ? 0u : OOB;              // rows past the slice (its last step; the run-ahead loads)
             unsigned inside = 0u;
 #pragma unroll
-            for (int j = 0; j < NR; ++j) {
+            for (int j = 0; j < NRY; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_ptr)(yd + j * GS), 16, (int)(yv[j] | dead), ystep, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NRX; ++j) {
                 if (j == 0 || khp[j] != khp[j - 1] || kwp[j] != kwp[j - 1]) {      // block-uniform: a new tap
                     const int ih = ih0 + khp[j], iw = iw0 + kwp[j];
                     inside = ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) ? 0u : OOB;
                 }
                 const int xo = xs_off[j];
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_ptr)(yd + j * GS), 16, (int)(yv[j] | dead), ystep, 0, 0);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr)(xd + j * GS), 16, (int)(xb | inside | kmask[j] | dead), xo, 0, 0);
             }
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][KT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < KT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int fr = lane & 31, khalf = lane >> 5;
     const float* ya = Ys + (wn * 2 * TM + khalf) * 32 + fr;             // pixel row 2s + khalf of groups 2 wn, 2 wn + 1
-    const float* xf = Xs + (wk * 2 * TM + khalf) * 32 + fr;
+    const float* xf = Xs + (wk * KT * TM + khalf) * 32 + fr;            // ... of groups KT wk (, KT wk + 1)
     auto compute = [&](int stage) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < TM / 2; ++s) {
-            const float a0 = ya[stage * STG + 2 * s * 32], a1 = ya[stage * STG + GS + 2 * s * 32];
-            const float b0 = xf[stage * STG + 2 * s * 32], b1 = xf[stage * STG + GS + 2 * s * 32];
+            const float a0 = ya[stage * STGY + 2 * s * 32], a1 = ya[stage * STGY + GS + 2 * s * 32];
+            const float b0 = xf[stage * STGX + 2 * s * 32];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            if constexpr (KT == 2) {
+                const float b1 = xf[stage * STGX + GS + 2 * s * 32];
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
         }
     };
 
@@ -359,8 +374,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma(const WgradP p) {
     // D[i = n][j = kk]: col = lane&31 -> kk, row = (r&3) + 8*(r>>2) + 4*khalf -> n
     float* wsb = p.ws + (size_t)ms * p.Cout * p.Ktot;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int kcol = k0 + wk * 64 + j * 32 + fr;
+    for (int j = 0; j < KT; ++j) {
+        const int kcol = k0 + wk * (32 * KT) + j * 32 + fr;
         if (kcol >= p.Ktot) continue;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -421,7 +436,7 @@ int wplan(const ym_wgrad_desc* d, WPlan* pl) {
     pl->tbn = d->Cout_real <= 64 ? 64 : 128;
     pl->nb = d->lds_buffers == 1 ? 1 : 2;
     if (d->lds_buffers == 22 || d->lds_buffers == 23 || d->lds_buffers == 24) {
-        YM_REQUIRE(pl->tbn == 128, "wgrad: the DMA-staged variants (lds_buffers 22/23/24) need more than 64 output channels");
+        YM_REQUIRE(pl->tbn == 128 || d->lds_buffers == 22, "wgrad: layers with <= 64 output channels have the 32-pixel DMA ring (lds_buffers 22) only");
         // conv_wgrad_dma: whole 32-channel groups per filter tap (and a padding the usual convolutions have); anything else runs
         // on the register-staged double buffer
         const bool dma_ok = d->Cin % 32 == 0 && 2 * d->pad <= d->KH - 1 && 2 * d->pad <= d->KW - 1 &&
@@ -475,7 +490,7 @@ extern "C" int ym_conv2d_wgrad(const ym_wgrad_desc* d, void* workspace, size_t w
     }
     hipStream_t st = (hipStream_t)s;
     // 22: DMA, 32 pixels x ring of 2 (64 KB); 23: DMA, 16 pixels x ring of 3 (48 KB); 24: DMA, 16 pixels x ring of 4 (64 KB)
-    const size_t lds = pl.nb == 22 ? (size_t)2 * 2 * 32 * DP * 4 : pl.nb == 23 ? (size_t)2 * 3 * 16 * DP * 4
+    const size_t lds = pl.nb == 22 ? (size_t)2 * 32 * (pl.tbn + 128) * 4 : pl.nb == 23 ? (size_t)2 * 3 * 16 * DP * 4
                      : pl.nb == 24 ? (size_t)2 * 4 * 16 * DP * 4 : (size_t)2 * pl.nb * TBM * LP * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
@@ -487,6 +502,7 @@ extern "C" int ym_conv2d_wgrad(const ym_wgrad_desc* d, void* workspace, size_t w
 #define YM_WG_ATTR_DL(N, T) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_dma<N, T>), hipFuncAttributeMaxDynamicSharedMemorySize, big)
         YM_WG_ATTR_DL(2, 32); YM_WG_ATTR_DL(3, 16); YM_WG_ATTR_DL(4, 16);
 #undef YM_WG_ATTR_DL
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_dma<2, 32, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
         attr_set = true;
     }
     // incremental coordinates need: (rows advanced per step) + 1 < 2 * Ho, so that two conditional wraps suffice
@@ -498,7 +514,8 @@ extern "C" int ym_conv2d_wgrad(const ym_wgrad_desc* d, void* workspace, size_t w
         else hipLaunchKernelGGL((conv_wgrad_f32<0, T, N>), wgrid, dim3(256), lds, st, p);          \
     } while (0)
 #define YM_WG_LAUNCH_DL(N, T) hipLaunchKernelGGL((conv_wgrad_dma<N, T>), wgrid, dim3(256), lds, st, p)
-    if (pl.nb == 22) YM_WG_LAUNCH_DL(2, 32);
+    if (pl.nb == 22 && pl.tbn == 64) hipLaunchKernelGGL((conv_wgrad_dma<2, 32, 64>), wgrid, dim3(256), lds, st, p);
+    else if (pl.nb == 22) YM_WG_LAUNCH_DL(2, 32);
     else if (pl.nb == 23) YM_WG_LAUNCH_DL(3, 16);
     else if (pl.nb == 24) YM_WG_LAUNCH_DL(4, 16);
     else if (pl.tbn == 64) { if (pl.nb == 1) YM_WG_LAUNCH(64, 1); else YM_WG_LAUNCH(64, 2); }

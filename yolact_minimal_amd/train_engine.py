@@ -132,7 +132,8 @@ def _configure_wgrad(d, key):
         best = (1e30, 0, 2)
         tbn = 64 if d.Cout_real <= 64 else 128
         tiles = -(-d.Cout // tbn) * -(-(d.KH * d.KW * d.Cin) // 128)
-        for nb, slots in ((2, 512), (1, 768)) + (((22, 512), (23, 768), (24, 512)) if d.Cout_real > 64 else ()):
+        # (22 / 23 / 24: the DMA rings; layers with <= 64 output channels have the 32-pixel ring only, at 48 KB = 3 workgroups per CU)
+        for nb, slots in ((2, 512), (1, 768)) + (((22, 512), (23, 768), (24, 512)) if d.Cout_real > 64 else ((22, 768),)):
             # pixel splits that make the grid a whole number of rounds of the chip (2 workgroups of 68 KB LDS per CU = 512 slots,
             # 3 of 34 KB with the single-buffer variant = 768): power-of-two splits alone left e.g. 756 workgroups = 1.5 rounds
             # for the layer3 3x3 (msplit 14 -> 504 = one round)
