@@ -214,6 +214,168 @@ __global__ __launch_bounds__(256) void k_gemm(const uint16_t* __restrict__ A, co
     }
 }
 
+// k_gemm2: the same GEMM with a K loop that issues NO vector instruction besides MFMAs (VALU instructions
+// take MFMA issue slots -- k_gemm spends 32-96 of them per 24 MFMAs on offset adds, v_readfirstlane of the DMA destination,
+// fragment addresses and, worst, 64 v_accvgpr_mov per pair of tiles that shuffle the accumulators between two register sets).
+// Lane offsets are fixed for the whole launch and the K position rides in the load's SGPR offset; the wave index is scalar; the
+// ring (NS even) is unrolled by its depth so that every LDS address is register + immediate and the two fragment sets alternate
+// statically.  Past-the-end tiles read whatever follows (never consumed; beyond the buffer the load returns zeros).
+template <int I> struct IC { static constexpr int value = I; };
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(IC<I>{}); static_for<I + 1, N>(f); }
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void k_gemm2(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, float* __restrict__ out,
+                                               int M, int N, int K, const float* __restrict__ scale, const float* __restrict__ shift, int relu,
+                                               int tiles_n) {
+    static_assert(NS % 2 == 0 && NS >= 4, "even ring: the fragment sets alternate statically");
+    constexpr int BM = 128, BN = 128;
+    constexpr int PLANE = 128 * 32, OPND = 3 * PLANE, STAGE = 2 * OPND;
+    constexpr int D = NS - 1, LPS = 6;
+    constexpr int WAIT = waitcnt_imm(LPS * (D - 2), 0);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int KB = K / 32, KT = K / 16;
+    const unsigned a_bytes = (unsigned)((size_t)M * KB * 192), w_bytes = (unsigned)((size_t)N * KB * 192);
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, w_bytes, 0x00020000);
+    unsigned a_off[3], w_off[3];
+    int lds_off[3];                              // scalar
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int q = wave * 3 + i, plane = q >> 2, row = (q & 3) * 32 + (lane >> 1), slot = lane & 1;
+        const int chunk = slot ^ ((row >> 3) & 1);
+        const int m = m0 + row, n = n0 + row;
+        a_off[i] = m < M ? (unsigned)((size_t)m * KB * 192 + plane * 64 + chunk * 16) : 0xFFFFFFF0u;
+        w_off[i] = n < N ? (unsigned)((size_t)n * KB * 192 + plane * 64 + chunk * 16) : 0xFFFFFFF0u;
+        lds_off[i] = plane * PLANE + (q & 3) * 32 * 32;
+    }
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto dma_tile = [&](int kt, int stage) __attribute__((always_inline)) {
+        char* base = smem + stage * STAGE;
+        const int kb = (kt >> 1) * 192 + (kt & 1) * 32;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr)(base + lds_off[i]), 16, (int)a_off[i], kb, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(base + OPND + lds_off[i]), 16, (int)w_off[i], kb, 0, 0);
+    };
+    const int r32 = lane & 31, kh = lane >> 5;
+    const int coff = (kh ^ ((r32 >> 3) & 1)) * 16;
+    typedef const __attribute__((address_space(3))) bf16x8* lds_frag_ptr;
+    lds_frag_ptr pa[2], pb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        pa[i] = (lds_frag_ptr)(smem + (wm * 64 + i * 32 + r32) * 32 + coff);
+        pb[i] = (lds_frag_ptr)(smem + OPND + (wn * 64 + i * 32 + r32) * 32 + coff);
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto read_frags = [&](int stage, bf16x8 (&fa)[2][3], bf16x8 (&fb)[2][3]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                fa[i][p] = pa[i][(stage * STAGE + p * PLANE) / 16];
+                fb[i][p] = pb[i][(stage * STAGE + p * PLANE) / 16];
+            }
+    };
+    auto mfma_block = [&](const bf16x8 (&fa)[2][3], const bf16x8 (&fb)[2][3]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int sig = 2; sig >= 0; --sig)
+#pragma unroll
+            for (int pa_ = 0; pa_ <= sig; ++pa_)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa_], fb[j][sig - pa_], acc[i][j], 0, 0, 0);
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) dma_tile(d, d);
+    __builtin_amdgcn_s_waitcnt(WAIT);
+    __builtin_amdgcn_s_barrier();
+    bf16x8 fa0[2][3], fb0[2][3], fa1[2][3], fb1[2][3];
+    read_frags(0, fa0, fb0);
+    auto tile = [&](auto SC, int t) __attribute__((always_inline)) {
+        constexpr int S = decltype(SC)::value, S1 = (S + 1) % NS, SP = (S + NS - 1) % NS;
+        dma_tile(t + D, SP);
+        if constexpr (S % 2 == 0) {
+            read_frags(S1, fa1, fb1);              // tile t+1 landed one barrier ago
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_block(fa0, fb0);
+        } else {
+            read_frags(S1, fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_block(fa1, fb1);
+        }
+        __builtin_amdgcn_s_waitcnt(WAIT);
+        __builtin_amdgcn_s_barrier();
+    };
+    int t = 0;
+    for (; t + NS <= KT; t += NS) static_for<0, NS>([&](auto SC) __attribute__((always_inline)) { tile(SC, t + decltype(SC)::value); });
+    static_for<0, NS - 1>([&](auto SC) __attribute__((always_inline)) { if (t + decltype(SC)::value < KT) tile(SC, t + decltype(SC)::value); });
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));          // past-the-end DMAs still target LDS
+    __builtin_amdgcn_s_barrier();
+
+    constexpr int CP = BN + 4;
+    static_assert(NS * STAGE >= BM * CP * 4, "the accumulator staging needs 66 KB of the ring");
+    float* C = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                C[(wm * 64 + i * 32 + 4 * kh + (r & 3) + 8 * (r >> 2)) * CP + wn * 64 + j * 32 + r32] = acc[i][j][r];
+    __syncthreads();
+    const int col4 = tid & 31, row0 = tid >> 5;
+    const int n = n0 + col4 * 4;
+    if (n < N) {
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (scale) sc = *reinterpret_cast<const f32x4*>(scale + n);
+        if (shift) sh = *reinterpret_cast<const f32x4*>(shift + n);
+#pragma unroll
+        for (int rk = 0; rk < 16; ++rk) {
+            const int row = row0 + rk * 8, m = m0 + row;
+            if (m < M) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(C + row * CP + col4 * 4);
+                v = __builtin_elementwise_fma(v, sc, sh);
+                if (relu & 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];
+                }
+                *reinterpret_cast<f32x4*>(out + (size_t)m * N + n) = v;
+            }
+        }
+    }
+}
+
+template <int NS>
+int launch2(const uint16_t* A, const uint16_t* W, float* out, int M, int N, int K, const float* scale, const float* shift, int relu,
+            hipStream_t st) {
+    const size_t lds = (size_t)NS * 24576;
+    static bool set = false;
+    if (!set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm2<NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        set = true;
+    }
+    const int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128;
+    hipLaunchKernelGGL((k_gemm2<NS>), dim3(tiles_m * tiles_n), dim3(256), lds, st, A, W, out, M, N, K, scale, shift, relu, tiles_n);
+    return (int)hipGetLastError();
+}
+
 template <int NS, bool PF>
 int launch(const uint16_t* A, const uint16_t* W, float* out, int M, int N, int K, const float* scale, const float* shift, int relu,
            hipStream_t st) {
@@ -243,6 +405,7 @@ extern "C" int pg_gemm(const uint16_t* A, const uint16_t* W, float* out, int M, 
                        int relu, int ns, int pf, void* stream) {
     if (K % 32 || N % 4) return -1;
     hipStream_t st = (hipStream_t)stream;
+    if (pf == 2) return ns == 4 ? launch2<4>(A, W, out, M, N, K, scale, shift, relu, st) : launch2<6>(A, W, out, M, N, K, scale, shift, relu, st);
     if (ns == 3) return pf ? launch<3, true>(A, W, out, M, N, K, scale, shift, relu, st) : launch<3, false>(A, W, out, M, N, K, scale, shift, relu, st);
     if (ns == 4) return pf ? launch<4, true>(A, W, out, M, N, K, scale, shift, relu, st) : launch<4, false>(A, W, out, M, N, K, scale, shift, relu, st);
     return pf ? launch<6, true>(A, W, out, M, N, K, scale, shift, relu, st) : launch<6, false>(A, W, out, M, N, K, scale, shift, relu, st);

@@ -64,7 +64,7 @@ for (b, hw, cin, cout) in ((8, 34, 256, 1024), (8, 68, 512, 128), (8, 136, 2304,
     flops = 2.0 * M * N * K
     line = f'M{M} N{N} K{K}: f32 MFMA {hit} {t_f32:7.1f} us {flops / t_f32 / 1e6:6.1f} TF err {err_f32:.1e} |'
     t_split = timeit(lambda: L.pg_split(x.data_ptr(), pa.data_ptr(), M, K, st))
-    for ns, pf in ((3, 0), (6, 0), (4, 1), (6, 1)):
+    for ns, pf in ((3, 0), (6, 0), (4, 1), (6, 1), (4, 2), (6, 2)):       # pf 2 = k_gemm2: no vector instructions in the K loop
         def run():
             rc = L.pg_gemm(pa.data_ptr(), pw.data_ptr(), out2.data_ptr(), M, N, K, sc.data_ptr(), sh.data_ptr(), 1, ns, pf, st)
             assert rc == 0, rc
@@ -73,7 +73,7 @@ for (b, hw, cin, cout) in ((8, 34, 256, 1024), (8, 68, 512, 128), (8, 136, 2304,
         torch.cuda.synchronize()
         err = float((out2.double() - ref).abs().max() / ref.abs().max())
         t = timeit(run)
-        line += f' planes ns{ns}{"pf" if pf else ""} {t:6.1f} us {flops / t / 1e6:6.1f} TF err {err:.1e} |'
+        line += f' planes ns{ns}{("", "pf", "v2")[pf]} {t:6.1f} us {flops / t / 1e6:6.1f} TF err {err:.1e} |'
     for ns in (3, 6):
         for abl, name in ((1, 'DMA only'), (2, 'MFMA + LDS reads only')):
             t = timeit(lambda: L.pg_gemm(pa.data_ptr(), pw.data_ptr(), out2.data_ptr(), M, N, K, sc.data_ptr(), sh.data_ptr(), 1 | (abl << 4), ns, 0, st))
