@@ -529,15 +529,25 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
         constexpr int C4 = BN / 4;                 // float4 per row
         constexpr int RPP = 256 / C4;              // rows per pass
         float* C = smem;
+#ifdef YM_TRACE
+        // ablation of the trace build (YM_PERS_ABL=9): no staging through LDS, the stores take accumulator registers as they are
+        // (WRONG values, same stores): an upper bound for what an epilogue that stores straight from the MFMA layout could save
+        const bool epi_abl = p.bnb_relu == 9 && p.bn_sum == nullptr;
+        if (!epi_abl) {
+#else
+        constexpr bool epi_abl = false;
+        {
+#endif
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    C[(wm * (BM / 2) + i * 32 + 4 * khalf + (r & 3) + 8 * (r >> 2)) * CP + wn * (BN / 2) + j * 32 + frag_row] =
-                        acc[i][j][r];
-        __syncthreads();
+                    for (int r = 0; r < 16; ++r)
+                        C[(wm * (BM / 2) + i * 32 + 4 * khalf + (r & 3) + 8 * (r >> 2)) * CP + wn * (BN / 2) + j * 32 + frag_row] =
+                            acc[i][j][r];
+            __syncthreads();
+        }
         const int col4 = tid % C4, row0 = tid / C4;
         const int n = n0 + col4 * 4;
         double bsum[4] = {0.0, 0.0, 0.0, 0.0}, bsq[4] = {0.0, 0.0, 0.0, 0.0};   // fp64: var = E[x^2]-E[x]^2 must not cancel in fp32
@@ -613,6 +623,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
                             v += a; v += b; v += c; v += d;
                         }
                         for (; s2 < nks; ++s2) v += buf_ld16_sc1(rs_ws, off + (unsigned)s2 * sb);
+                    } else if (epi_abl) {
+                        v = f32x4{acc[0][0][(4 * rk) & 15], acc[0][0][(4 * rk + 1) & 15], acc[0][0][(4 * rk + 2) & 15], acc[0][0][(4 * rk + 3) & 15]};
                     } else {
                         v = *reinterpret_cast<const f32x4*>(C + row * CP + col4 * 4);
                     }
