@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Persistent conv kernel (stages 4x, csrc/conv_persist.hip) against the tuned per-item kernels, per layer shape.
 
-    python tools/pers_bench.py bs1|bs8|train [--write]          (train = the data-gradient launches of the bs=8 shapes)
+    python tools/pers_bench.py bs1|bs8|train|swin [--write]     (train = the data-gradient launches of the bs=8 shapes)
 
 For every 64x64-tile shape of the plan: time the tuned entry, then the persistent kernel over ring depth x workgroups per CU
 (with the tail split that evens out the last round of a static item assignment) and, at bs=1, over the K split.  `--write`
@@ -33,6 +33,12 @@ def bottleneck(bs, hw, wide, mid, first_stride=None):
 def shapes(which):
     bs = 1 if which == 'bs1' else 8
     out = []
+    if which == 'swin':          # Swin-T bs=8 linears the persistent kernel covers (ReLU / identity epilogues: qkv, proj, fc2, merging)
+        for hw, c in ((136, 96), (68, 192), (34, 384), (17, 768)):
+            out += [(8, hw, hw, c, 3 * c, 1, 1, 0), (8, hw, hw, c, c, 1, 1, 1), (8, hw, hw, 4 * c, c, 1, 1, 1)]
+            if hw > 17:
+                out.append((8, hw // 2, hw // 2, 4 * c, 2 * c, 1, 1, 0))
+        return out
     for hw, wide, mid in ((136, 256, 64), (68, 512, 128), (34, 1024, 256), (17, 2048, 512)):
         out += bottleneck(bs, hw, wide, mid)
     # FPN / protonet / head 3x3 256 -> 256 at 68 / 34 / 17 and the lateral 1x1s
