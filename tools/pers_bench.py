@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Persistent conv kernel (stages 4x, csrc/conv_persist.hip) against the tuned per-item kernels, per layer shape.
 
-    python tools/pers_bench.py bs1|bs8|train|swin [--write]     (train = the data-gradient launches of the bs=8 shapes)
+    python tools/pers_bench.py bs1|bs8|train|swin|swin_train [--write]     (train = the data-gradient launches of the bs=8 shapes)
 
 For every 64x64-tile shape of the plan: time the tuned entry, then the persistent kernel over ring depth x workgroups per CU
 (with the tail split that evens out the last round of a static item assignment) and, at bs=1, over the K split.  `--write`
@@ -33,9 +33,13 @@ def bottleneck(bs, hw, wide, mid, first_stride=None):
 def shapes(which):
     bs = 1 if which == 'bs1' else 8
     out = []
-    if which == 'swin':          # Swin-T bs=8 linears the persistent kernel covers (ReLU / identity epilogues: qkv, proj, fc2, merging)
+    if which in ('swin', 'swin_train'):
+        # Swin-T bs=8 linears the persistent kernel covers (ReLU / identity epilogues: qkv, proj, fc2, merging); swin_train: the
+        # data gradients of ALL its linears (no BatchNorm, so none of them carries fused statistics)
         for hw, c in ((136, 96), (68, 192), (34, 384), (17, 768)):
             out += [(8, hw, hw, c, 3 * c, 1, 1, 0), (8, hw, hw, c, c, 1, 1, 1), (8, hw, hw, 4 * c, c, 1, 1, 1)]
+            if which == 'swin_train':
+                out.append((8, hw, hw, c, 4 * c, 1, 1, 0))
             if hw > 17:
                 out.append((8, hw // 2, hw // 2, 4 * c, 2 * c, 1, 1, 0))
         return out
@@ -88,7 +92,7 @@ def main():
     only = [a for a in sys.argv[2:] if not a.startswith('--')]
     total_old = total_new = 0.0
     for spec in shapes(which):
-        if which == 'train':
+        if which in ('train', 'swin_train'):
             d, keep, sig = make_dgrad_desc(*spec[:7])
             M = spec[0] * d.Ho * d.Wo
             spec = (spec[0], 0, 0, d.Cin, d.Cout) + tuple(spec[5:])
