@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# RequestPipeline (bench.py's headline mode) overlaps requests on separate HIP streams; ROCm multiplexes streams onto
+# GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable when the runtime starts -> set it before torch touches HIP
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)

@@ -252,3 +252,130 @@ def test_chained_forward_nms_after_nms_matches_the_reference(golden_dir):
         bad_px += int((px[j] != ref_px[i]).any())
         assert float((masks[j] != ref_masks[i]).mean()) <= 1e-4, (i, j)
     assert bad_px <= max(1, len(pairs) // 50)
+
+
+def _chained_net(golden_dir):
+    """res101_coco 544 px with the chained golden's weights (oracle/make_golden_chained.py): its OWN head outputs give ~400
+    candidates over the score threshold and 100 detections, so the post-processing of a request depends on its image."""
+    gold = np.load(f'{golden_dir}/chained_res101_coco_544.npz')
+    seed = int(gold['seed'])
+    cfg = build_cfg('res101_coco', 'val', 544)
+    torch.manual_seed(seed)
+    net = Yolact(cfg).eval()
+    sd = net.state_dict()
+    R.randomize_bn_(sd, seed + 100)
+    R.randomize_bias_(sd, seed + 200)
+    sd['prediction_layers.conf_layer.weight'].mul_(float(gold['conf_gain']))
+    sd['prediction_layers.conf_layer.bias'].copy_(torch.from_numpy(gold['conf_bias']))
+    net.load_state_dict(sd)
+    return net.to(DEV), cfg, seed
+
+
+def _single_path(net, cfg, imgs, head=None):
+    """forward -> nms -> after_nms(480x640), one request at a time (the path of rounds 1-2): per image the four network outputs and
+    the four `after_nms` results."""
+    from yolact_minimal_amd.utils.output_utils import nms_batch, after_nms_batch
+    eng = net._engine(imgs[0])
+    anchors = torch.tensor(net.anchors, dtype=torch.float32).reshape(-1, 4).to(DEV)
+    fwd, post = [], []
+    for img in imgs:
+        eng.run(img)
+        torch.cuda.synchronize()
+        outs = [t.clone() for t in eng.outputs()]
+        fwd.append(outs)
+        post.append(after_nms_batch(nms_batch(*(head if head is not None else outs), anchors, cfg), 480, 640, cfg))
+    return fwd, post
+
+
+def _same_result(got, want):
+    for a, b in zip(got, want):
+        if not ((a is None and b is None) or (a is not None and b is not None and torch.equal(a, b))):
+            return False
+    return True
+
+
+@pytest.mark.parametrize('batch,depth', [(1, 4), (8, 2), (8, 4)])
+def test_headline_pipeline_matches_the_single_request_path_at_full_size(golden_dir, batch, depth):
+    """The configurations bench.py times (round-3 verdict, weak 2): `RequestPipeline` at res101_coco 544 px with depth 4 at batch 1
+    (`value`) and batch 8 with depth 2 / 4 (`extra.*_bs8`), GPU_MAX_HW_QUEUES = 8.  >= 16 requests over 4 distinct images, so that a
+    slot never sees the same image twice in a row: per-slot activations, split-K scratch, arrival counters and post-processing
+    scratch are size dependent, and a race between slots would corrupt exactly the number that is `value`.  Every request must
+    return what the one-at-a-time path returns for ITS image, bit for bit: (a) the four network outputs, (b) ids / scores / pixel
+    boxes / masks on the dense synthetic head outputs (bench.py's workload), (c) the same on the forward's OWN outputs with the
+    chained golden's weights (~100 detections per image that depend on the image)."""
+    import bench
+    from yolact_minimal_amd.pipeline import RequestPipeline, hw_queues_ok
+    from yolact_minimal_amd.utils.synthetic import synth_head_outputs
+    assert hw_queues_ok(depth), 'tests/conftest.py sets GPU_MAX_HW_QUEUES=8 before the HIP runtime starts'
+    dev = torch.device(DEV)
+    net, cfg, seed = _chained_net(golden_dir)
+    g = torch.Generator().manual_seed(seed + 300)
+    imgs = [torch.randn(batch, 3, 544, 544, generator=g).to(dev) for _ in range(4)]
+    n_req = 4 * depth + 3                       # 19 / 11 / 19 requests: every slot is reused several times, the last round is partial
+    order = [(3 * i + i // 4) % 4 for i in range(n_req)]          # slot s = i % depth sees a different image every time round
+    head = [t.to(dev).expand(batch, *t.shape[1:]).contiguous()
+            for t in synth_head_outputs(len(net.anchors) // 4, num_classes=cfg.num_classes, proto_hw=136, seed=1)]
+    want_fwd, want_own = _single_path(net, cfg, imgs)
+    _, want_head = _single_path(net, cfg, imgs[:1], head)
+    n_det = sum(int(r[0].shape[0]) for r in want_own[0] if r[0] is not None)
+    assert n_det >= 50 * batch, 'the chained weights must give image-dependent detections'
+
+    def as_list(r):
+        return r if batch > 1 else [r]
+
+    # (a) forward outputs, copied off the slot before it runs again
+    pipe = RequestPipeline(net, cfg, 544, 544, dev, depth=depth, with_post=False, batch=batch)
+    pipe.warm_up(imgs[0])
+    got = [pipe.submit(imgs[k]) for k in order]
+    got = [r for r in got if r is not None] + pipe.drain()
+    assert len(got) == n_req
+    for k, r in zip(order, got):
+        for a, b in zip(r, want_fwd[k]):
+            assert torch.equal(a, b), f'forward outputs of a request on image {k} differ from the single-request path'
+    del pipe
+    # (b) + (c) with post-processing: the synthetic head outputs, then the forward's own
+    pipe = RequestPipeline(net, cfg, 544, 544, dev, depth=depth, out_hw=(480, 640), batch=batch)
+    pipe.warm_up(imgs[0])
+    got = [pipe.submit(imgs[k], head) for k in order]
+    got = [r for r in got if r is not None] + pipe.drain()
+    assert len(got) == n_req
+    for r in got:
+        for one, want in zip(as_list(r), want_head[0]):
+            assert _same_result(one, want), 'post-processing of the synthetic head outputs differs between slots'
+    got = [pipe.submit(imgs[k]) for k in order]
+    got = [r for r in got if r is not None] + pipe.drain()
+    assert len(got) == n_req
+    for k, r in zip(order, got):
+        for one, want in zip(as_list(r), want_own[k]):
+            assert _same_result(one, want), f'chained result of a request on image {k} differs from the single-request path'
+    net._engines.clear()
+
+
+def test_pipeline_applies_the_visual_threshold_like_after_nms():
+    """`RequestPipeline` results are 'like after_nms', so a detect-style cfg (`visual_thre` = 0.3,
+    utils/output_utils.py:204-212 of the reference) must filter them; an image whose detections all fall under the threshold
+    returns four Nones."""
+    import bench
+    from yolact_minimal_amd.pipeline import RequestPipeline
+    from yolact_minimal_amd.utils.output_utils import nms, after_nms
+    dev = torch.device(DEV)
+    net, cfg = bench.build_net('res50_coco', 256, dev)
+    one = bench.Workload(net, cfg, 1, 256, dev, with_post=True, inflight=1)
+    cls, box, coef, proto = one.head
+    r = nms(cls, box, coef, proto, one.anchors, cfg)
+    scores = r[1]
+    vt = float(scores.sort()[0][scores.numel() // 2])          # the median score: about half of the detections survive
+    for thre in (vt, 2.0):
+        cfg.visual_thre = thre
+        try:
+            want = after_nms(r[0], r[1], r[2].clone(), r[3], r[4], 480, 640, cfg)
+            pipe = RequestPipeline(net, cfg, 256, 256, dev, depth=2, out_hw=(480, 640))
+            pipe.warm_up(one.img)
+            pipe.submit(one.img, one.head)
+            got = pipe.drain()[0]
+        finally:
+            cfg.visual_thre = 0
+        assert _same_result(got, want)
+        assert (want[0] is None) == (thre == 2.0)
+        if want[0] is not None:
+            assert 0 < want[0].shape[0] < scores.numel() and pipe.detections == want[0].shape[0]

@@ -12,8 +12,12 @@ the request it has just enqueued.
 
 Measured mid-round 3 (res101_coco 544 px, MI355X, forward + nms + after_nms(480x640)): depth 1: 325 img/s, 2: 468, 3: 545, 4: 594, 5: 495,
 8: 479 -- the part schedules four compute pipes; GPU_MAX_HW_QUEUES must be >= depth + 1 (ROCm multiplexes HIP streams onto 4
-hardware queues by default and two streams that share a queue do not overlap): set it to 8 before the first HIP call.
+hardware queues by default and two streams that share a queue do not overlap): set it to 8 before the first HIP call
+(`RequestPipeline` warns when the variable is missing or too small: it cannot be changed once the runtime is up).
 """
+import os
+import warnings
+
 import torch
 
 from .engine import InferEngine
@@ -31,17 +35,42 @@ def _stream_set(device, n):
     return lst[:n]
 
 
+def hw_queues_ok(depth):
+    """Does the HIP runtime have a hardware queue for each of `depth` slot streams plus the caller's stream?  (ROCm reads
+    GPU_MAX_HW_QUEUES when it creates its first stream; the default is 4.)"""
+    try:
+        q = int(os.environ.get('GPU_MAX_HW_QUEUES', '4'))
+    except ValueError:
+        q = 4
+    return q >= depth + 1
+
+
 class RequestPipeline:
-    def __init__(self, net, cfg, height, width, device, depth=4, out_hw=(480, 640), with_post=True, batch=1):
+    """`depth` requests in flight.  `submit()` returns the FINISHED result of the request that used the slot before; results are
+    fresh tensors the caller owns (network outputs are copied off the slot's buffers before the slot runs again).
+    `return_outputs=False` (throughput measurements of the forward alone): `submit()` / `drain()` hand back nothing for
+    `with_post=False` and the copy is skipped.  `timed=True`: every request is bracketed by HIP events on its slot's stream and
+    `latencies_ms` collects the per-request device latency (bench.py: p50 / p99 and the Little's-law check)."""
+
+    def __init__(self, net, cfg, height, width, device, depth=4, out_hw=(480, 640), with_post=True, batch=1, return_outputs=True,
+                 timed=False):
         self.net, self.cfg, self.device, self.depth, self.batch = net, cfg, torch.device(device), depth, batch
-        self.out_hw, self.with_post = out_hw, with_post
+        self.out_hw, self.with_post, self.return_outputs, self.timed = out_hw, with_post, return_outputs, timed
+        if depth > 1 and not hw_queues_ok(depth):
+            warnings.warn(f'RequestPipeline(depth={depth}): GPU_MAX_HW_QUEUES={os.environ.get("GPU_MAX_HW_QUEUES", "unset (4)")} < '
+                          f'{depth + 1}; HIP streams that share a hardware queue do not overlap -- export GPU_MAX_HW_QUEUES=8 before the '
+                          f'first HIP call', RuntimeWarning, stacklevel=2)
         self.engines = [InferEngine(net, batch, height, width, device) for _ in range(depth)]
         self.streams = _stream_set(device, depth)
         self.counts_host = [torch.zeros(batch, dtype=torch.int32).pin_memory() for _ in range(depth)]
         self.events = [torch.cuda.Event() for _ in range(depth)]
+        self.t0 = [torch.cuda.Event(enable_timing=True) for _ in range(depth)] if timed else None
+        self.t1 = [torch.cuda.Event(enable_timing=True) for _ in range(depth)] if timed else None
+        self.latencies_ms = []
         self.pending = [None] * depth
         self.anchors = torch.tensor(net.anchors, dtype=torch.float32).reshape(-1, 4).to(device) \
             if not torch.is_tensor(net.anchors) else net.anchors.to(device)
+        self.vt = float(getattr(cfg, 'visual_thre', 0) or 0)
         self.submitted = 0
         self.detections = 0
 
@@ -55,17 +84,26 @@ class RequestPipeline:
 
     def finish(self, slot):
         """Result of the request that last used `slot`: (ids, scores, boxes_px, masks) like `after_nms` (None x 4 without
-        detections; a list of such tuples, one per image, when batch > 1), or None if the slot is idle.  Without post-processing:
-        the slot's four network outputs."""
+        detections -- also when `cfg.visual_thre` removes all of them, `utils/output_utils.py:204-212` of the reference; a list of
+        such tuples, one per image, when batch > 1), or None if the slot is idle.  Without post-processing: copies of the slot's
+        four network outputs (None with `return_outputs=False`)."""
         pend = self.pending[slot]
         if pend is None:
             return None
         self.pending[slot] = None
         if not self.with_post:
             pend.synchronize()
-            return self.engines[slot].outputs()           # the slot's own buffers: valid until the slot runs its next request
+            if self.timed:
+                self.latencies_ms.append(self.t0[slot].elapsed_time(self.t1[slot]))
+            if not self.return_outputs:
+                return None
+            # the slot's own buffers are overwritten by its next request: hand out copies, made on the caller's stream (the slot's
+            # next run is ordered behind that stream by `submit`)
+            return tuple(t.clone() for t in self.engines[slot].outputs())
         ids, scores, box_px, masks, counts, ev = pend
         ev.synchronize()                                  # THIS request only
+        if self.timed:
+            self.latencies_ms.append(self.t0[slot].elapsed_time(self.t1[slot]))
         # the results were allocated on the slot's stream and are consumed on the caller's: tell the allocator, or the slot's next
         # request could be handed the block while a kernel of the caller still reads it
         cur = torch.cuda.current_stream(self.device)
@@ -73,8 +111,16 @@ class RequestPipeline:
             t.record_stream(cur)
         out = []
         for b, n in enumerate(self.counts_host[slot].tolist()):
-            self.detections += n
-            out.append((ids[b, :n], scores[b, :n], box_px[b, :n], masks[b, :n]) if n else (None, None, None, None))
+            if n == 0:
+                out.append((None, None, None, None))
+                continue
+            r = (ids[b, :n], scores[b, :n], box_px[b, :n], masks[b, :n])
+            if self.vt > 0:                               # detect.py's score filter, as in `after_nms` / `after_nms_batch(sync=True)`
+                keep = r[1] >= self.vt
+                r = tuple(t[keep] for t in r) if bool(keep.any()) else (None, None, None, None)
+            if r[0] is not None:
+                self.detections += int(r[0].shape[0])
+            out.append(r)
         return out[0] if self.batch == 1 else out
 
     def submit(self, img, head_outputs=None):
@@ -87,19 +133,26 @@ class RequestPipeline:
         self.submitted += 1
         done = self.finish(slot)
         ev = self.events[slot]
-        # `img` / `head_outputs` were produced on the caller's stream (an H2D copy, `val_aug`): the slot's stream starts behind that
+        # `img` / `head_outputs` were produced on the caller's stream (an H2D copy, `val_aug`), and `finish` may have queued copies
+        # of the slot's previous outputs there: the slot's stream starts behind that
         self.streams[slot].wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.streams[slot]):
             eng = self.engines[slot]
+            if self.timed:
+                self.t0[slot].record()
             eng.run(img)
             if self.with_post:
                 cls, box, coef, proto = head_outputs if head_outputs is not None else eng.outputs()
                 r = after_nms_batch(nms_batch(cls, box, coef, proto, self.anchors, self.cfg), self.out_hw[0], self.out_hw[1], self.cfg,
                                     sync=False)
                 self.counts_host[slot].copy_(r[4], non_blocking=True)
+                if self.timed:
+                    self.t1[slot].record()
                 ev.record()
                 self.pending[slot] = r + (ev,)
             else:
+                if self.timed:
+                    self.t1[slot].record()
                 ev.record()
                 self.pending[slot] = ev
         return done
@@ -108,7 +161,9 @@ class RequestPipeline:
         """Finish everything in flight, oldest first."""
         out = []
         for k in range(self.depth):
-            r = self.finish((self.submitted + k) % self.depth)
-            if r is not None:
+            slot = (self.submitted + k) % self.depth
+            busy = self.pending[slot] is not None
+            r = self.finish(slot)
+            if busy and (r is not None or self.with_post):
                 out.append(r)
         return out

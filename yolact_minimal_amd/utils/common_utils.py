@@ -8,7 +8,6 @@ once), `ym_box_iou`, then `ym_match_detections` resolves all 2 x T matchings in 
 tensor [2, T, n] and only does the AP bookkeeping (lists of (score, is_true)), which stays Python like the reference.
 """
 import ctypes
-from collections import OrderedDict
 
 import numpy as np
 import torch
@@ -101,29 +100,20 @@ def prep_metrics(ap_data, ids_p, classes_p, boxes_p, masks_p, gt, gt_masks, heig
 
 
 def calc_map(ap_data, iou_thres, num_classes, step):
-    """common_utils.py:219-262; the table is returned as plain rows (terminaltables is a formatting dependency)."""
-    aps = [{'box': [], 'mask': []} for _ in iou_thres]
-    for _class in range(num_classes):
-        for iou_idx in range(len(iou_thres)):
-            for iou_type in ('box', 'mask'):
-                ap_obj = ap_data[iou_type][iou_idx][_class]
-                if not ap_obj.is_empty():
-                    aps[iou_idx][iou_type].append(ap_obj.get_ap())
-    all_maps = {'box': OrderedDict(), 'mask': OrderedDict()}
-    for iou_type in ('box', 'mask'):
-        all_maps[iou_type]['all'] = 0
-        for i, threshold in enumerate(iou_thres):
-            vals = aps[i][iou_type]
-            all_maps[iou_type][int(threshold * 100)] = sum(vals) / len(vals) * 100 if len(vals) > 0 else 0
-        all_maps[iou_type]['all'] = sum(all_maps[iou_type].values()) / (len(all_maps[iou_type].values()) - 1)
-    row1 = list(all_maps['box'].keys())
-    row1.insert(0, f'{step // 1000}k' if step else '')
-    row2 = [round(a, 2) for a in all_maps['box'].values()]
-    row2.insert(0, 'box')
-    row3 = [round(a, 2) for a in all_maps['mask'].values()]
-    row3.insert(0, 'mask')
-    table = '\n'.join(' | '.join(str(c) for c in row) for row in (row1, row2, row3))
-    return table, row2, row3
+    """mAP table of the reference's `calc_map` (common_utils.py:219-255) from the AP grid [iou type][threshold][class]: per
+    (type, threshold) the mean AP (x 100) over the classes that hold data, then the mean over the thresholds as 'all'.  Python float
+    sums in class / threshold order, so the rounded rows equal the reference's (tests/golden/metrics_*.npz).  Returns
+    (table text, box row, mask row); the table is plain ' | '-joined rows (terminaltables is a formatting dependency)."""
+    def mean_ap(kind, t):
+        cells = ap_data[kind][t]
+        vals = [cells[c].get_ap() for c in range(num_classes) if not cells[c].is_empty()]
+        return sum(vals) / len(vals) * 100 if vals else 0
+
+    rows = [[f'{step // 1000}k' if step else '', 'all'] + [int(t * 100) for t in iou_thres]]
+    for kind in ('box', 'mask'):
+        per_thr = [mean_ap(kind, t) for t in range(len(iou_thres))]
+        rows.append([kind] + [round(v, 2) for v in [sum(per_thr) / len(per_thr)] + per_thr])
+    return '\n'.join(' | '.join(str(c) for c in row) for row in rows), rows[1], rows[2]
 
 
 def rle_encode(masks, cap_runs=4096):
