@@ -80,7 +80,7 @@ class Workload:
     requests overlap (yolact_minimal_amd.pipeline.RequestPipeline: one engine + one stream per slot); see the module docstring.
     `chained`: post-process the forward's OWN outputs (eval.py:45-52) instead of the dense synthetic head outputs."""
 
-    def __init__(self, net, cfg, batch, img_size, device, with_post=True, seed=0, inflight=1, chained=False):
+    def __init__(self, net, cfg, batch, img_size, device, with_post=True, seed=0, inflight=1, chained=False, timed=False):
         from yolact_minimal_amd.utils.synthetic import synth_head_outputs
         from yolact_minimal_amd.pipeline import RequestPipeline
         self.net, self.cfg, self.batch, self.device = net, cfg, batch, device
@@ -98,7 +98,7 @@ class Workload:
         self.pipe = None
         if self.inflight > 1:
             self.pipe = RequestPipeline(net, cfg, img_size, img_size, device, depth=self.inflight, out_hw=(480, 640), with_post=with_post,
-                                        batch=batch)
+                                        batch=batch, return_outputs=False, timed=timed)
             self.pipe.warm_up(self.img)
             self.engine = self.pipe.engines[0]
         else:
@@ -384,6 +384,7 @@ def train_bench(cfg_name, img_size, batch, steps, warmup, world, local_rank, dev
     losses = None
     for _ in range(warmup):
         losses = tr.step(img, boxes, masks)
+    tr.enable_timing()                     # three HIP event pairs per step (buffer broadcast, backward end -> last bucket reduced)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -392,14 +393,53 @@ def train_bench(cfg_name, img_size, batch, steps, warmup, world, local_rank, dev
     torch.cuda.synchronize()
     barrier()
     elapsed = reduce_max(time.perf_counter() - t0, device)
+    timing = tr.timing_summary()
     flops_img = 3.0 * {'res101': 157.2e9, 'res50_': 113.4e9, 'swin_t': 119.2e9}.get(cfg_name[:6], 157.2e9)   # step ~ 3x forward
     opt = 'AdamW' if cfg_name.startswith('swin') else 'SGD'
     img_s = batch * world * steps / elapsed
-    return dict(img_s=round(img_s, 2), ms_per_step=round(elapsed / steps * 1e3, 2), steps=steps, warmup=warmup,
-                batch_per_gpu=batch, global_batch=batch * world, parallelism=f'ddp{world} (RCCL all-reduce, 25 MB buckets)', optimizer=opt,
-                tflops_per_gpu=round(img_s / world * flops_img / 1e12, 2),
-                frac_f32_mfma_peak=round(img_s / world * flops_img / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
-                last_losses=[round(float(l.detach()), 4) for l in losses], finite=all(bool(torch.isfinite(l)) for l in losses))
+    out = dict(img_s=round(img_s, 2), ms_per_step=round(elapsed / steps * 1e3, 2), steps=steps, warmup=warmup,
+               batch_per_gpu=batch, global_batch=batch * world, parallelism=f'ddp{world} (RCCL all-reduce, 25 MB buckets)', optimizer=opt,
+               tflops_per_gpu=round(img_s / world * flops_img / 1e12, 2),
+               frac_f32_mfma_peak=round(img_s / world * flops_img / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+               last_losses=[round(float(l.detach()), 4) for l in losses], finite=all(bool(torch.isfinite(l)) for l in losses))
+    if tr.ddp:
+        out['ddp'] = ddp_block(tr, timing, img_s, world, cfg_name, batch)
+    return out
+
+
+def ddp_block(tr, timing, img_s, world, cfg_name, batch):
+    """The north star's DDP figures (reference train.py:70-77,122; README.md:54-57), readable from the record alone: training
+    img/s of the whole job and per GPU, the 1-GPU reference it scales against (the committed N = 1 line of this round), what the
+    collectives cost where backward could not hide them, and what the process group actually saw."""
+    import torch.distributed as dist
+    ref, ref_src = None, None
+    for r in (4, 3):
+        q = os.path.join(REPO, 'profiles', f'r0{r}_bench_line.json')
+        if os.path.exists(q):
+            try:
+                tb = json.load(open(q))['extra']['train' if batch != 16 else 'train_bs16']
+                if tb.get('batch_per_gpu') == batch and cfg_name == 'res101_coco':
+                    ref, ref_src = float(tb['img_s']), os.path.relpath(q, REPO)
+                    break
+            except (KeyError, ValueError, TypeError):
+                pass
+    try:
+        nccl = '.'.join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:                                   # (gloo control-flow tests)
+        nccl = None
+    red = tr.reducer
+    log = getattr(red, 'last_launch_log', []) if red is not None else []
+    return dict(train_img_s=round(img_s, 2), per_gpu=round(img_s / world, 2), vs_1gpu_reference_img_s=ref,
+                scaling_vs_1gpu=round(img_s / ref, 3) if ref else None, reference_source=ref_src,
+                world_size_seen=dist.get_world_size() if dist.is_initialized() else 1,
+                backend=dist.get_backend() if dist.is_initialized() else None, rccl_version=nccl,
+                buckets=len(red.buckets) if red is not None else None,
+                bucket_mb=[round((e - a) * 4 / 2 ** 20, 1) for a, e, _ in red.buckets] if red is not None else None,
+                buckets_launched_during_backward=sum(1 for _, _, in_finish in log if not in_finish),
+                allreduce_exposed_ms=timing.get('allreduce_exposed_ms'), buffer_broadcast_ms=timing.get('buffer_broadcast_ms'),
+                backward_ms=timing.get('backward_ms'),
+                note='allreduce_exposed_ms: end of backward on the device (both streams joined) -> last bucket reduced, from HIP events '
+                     'on the step\'s stream; buffer_broadcast_ms: the one-message BN running-stat broadcast of the step')
 
 
 def cpu_baseline(cfg_name, img_size, threads=None, budget_s=12.0, max_img=10):
@@ -488,13 +528,24 @@ def main():
     net, cfg = build_net(args.cfg, args.img_size, device)
     inflight = args.inflight if args.inflight > 0 else (4 if args.batch == 1 else 2)
     wl = Workload(net, cfg, args.batch, args.img_size, device, with_post=not args.no_post, inflight=inflight)
-    elapsed = timed(wl, args.steps, args.warmup, barrier)
+    elapsed_local = timed(wl, args.steps, args.warmup, barrier)
+    elapsed = elapsed_local
     if dist is not None:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     imgs = args.batch * args.steps * world
     value = imgs / elapsed
+    region_flops = wl.engine.total_flops * args.steps          # conv flops this rank executed inside the region `value` times
+    # spread: the driver's sample is K steps (20 steps = 33 ms at bs=1) -> the same region five more times, and five regions of
+    # >= 200 steps (this rank's own clock; every rank takes part so that the barriers match)
+    rep_k = [timed(wl, args.steps, 0, barrier) / args.steps * 1e3 for _ in range(5)]
+    long_steps = max(args.steps, 200 // max(1, args.batch))
+    rep_long = [timed(wl, long_steps, 0, barrier) / long_steps * 1e3 for _ in range(5)]
+    spread = dict(unit='ms_per_step', region_steps=args.steps, first_region=round(elapsed_local / args.steps * 1e3, 4),
+                  repeats=[round(x, 4) for x in rep_k], min=round(min(rep_k), 4), median=round(sorted(rep_k)[2], 4), max=round(max(rep_k), 4),
+                  long_region_steps=long_steps, long_repeats=[round(x, 4) for x in rep_long], long_min=round(min(rep_long), 4),
+                  long_median=round(sorted(rep_long)[2], 4), long_max=round(max(rep_long), 4))
     del wl
     train = None
     if not args.no_train:
@@ -518,24 +569,41 @@ def main():
     if rank == 0:
         # forward-only rate on the same engine, and the live conv roofline
         fw = Workload(net, cfg, args.batch, args.img_size, device, with_post=False)
-        t_fwd = timed(fw, args.steps, 2, lambda: None) / args.steps           # ONE request at a time (graph replay)
-        t_fwd_multi, single = t_fwd, None
+        k1 = max(args.steps, 50)
+        t_fwd = min(timed(fw, k1, 2, lambda: None), timed(fw, k1, 0, lambda: None)) / k1      # ONE request at a time (graph replay)
+        t_fwd_multi, single, latency = t_fwd, None, None
         if inflight > 1:
             fwm = Workload(net, cfg, args.batch, args.img_size, device, with_post=False, inflight=inflight)
-            t_fwd_multi = timed(fwm, 4 * args.steps, 4, lambda: None) / (4 * args.steps)      # seconds per image, requests overlapped
+            t_fwd_multi = timed(fwm, 4 * k1, 4, lambda: None) / (4 * k1)      # seconds per image, requests overlapped
             del fwm
             one = Workload(net, cfg, args.batch, args.img_size, device, with_post=not args.no_post, inflight=1)
-            t_one = timed(one, args.steps, 5, lambda: None) / args.steps
+            t_one = min(timed(one, k1, 5, lambda: None), timed(one, k1, 0, lambda: None)) / k1
             del one
+            # per-request device latency (HIP events on the slot's stream around forward + nms + after_nms) with `inflight` requests
+            # overlapped, and the Little's-law check: requests in flight = throughput x latency must come out as `inflight` if the
+            # requests really overlap (one at a time it would be 1)
+            lat = Workload(net, cfg, args.batch, args.img_size, device, with_post=not args.no_post, inflight=inflight, timed=True)
+            n_lat = 400 // max(1, args.batch)
+            t_lat = timed(lat, n_lat, 8, lambda: None) / n_lat
+            ls = sorted(lat.pipe.latencies_ms[-n_lat:])
+            del lat
+            mean_l = sum(ls) / len(ls)
+            latency = dict(unit='ms', requests=len(ls), p50=round(ls[len(ls) // 2], 3), p99=round(ls[min(len(ls) - 1, int(len(ls) * 0.99))], 3),
+                           mean=round(mean_l, 3), min=round(ls[0], 3), max=round(ls[-1], 3), ms_per_step=round(t_lat * 1e3, 4),
+                           requests_in_flight_by_littles_law=round(mean_l / (t_lat * 1e3), 3),
+                           single_request_ms=round(t_one * 1e3, 3),
+                           note='device time of ONE request (its own stream: forward + nms + after_nms) while the others run; '
+                                'throughput x latency = requests in flight')
         flops, conv_secs, launches, layers = conv_roofline(fw.engine, fw.img)
         achieved = flops / conv_secs / 1e12
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(REPO, 'profiles', 'r03_pmc_hbm_infer_bs1_res101.json')
-        if args.cfg == 'res101_coco' and args.batch == 1 and os.path.exists(pmc_path):
+        pmc_path = next((q for q in (os.path.join(REPO, 'profiles', f'r0{r}_pmc_hbm_infer_bs1_res101.json') for r in (4, 3))
+                         if os.path.exists(q)), '')
+        if args.cfg == 'res101_coco' and args.batch == 1 and pmc_path:
             # HBM-side bytes per conv launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2
             # gfx950 correction + WRITE_SIZE); not re-measured live (bench.py cannot wrap itself in rocprofv3)
             traffic = round(json.load(open(pmc_path))['conv_kernels']['traffic_bytes_per_launch'])
-            traffic_src = 'profiles/r03_pmc_hbm_infer_bs1_res101.json'
+            traffic_src = os.path.relpath(pmc_path, REPO)
         # `achieved`: the conv kernels' algorithmic flops over the GRAPH-REPLAY forward (the path `value` times; its few non-conv
         # kernels — layout, max-pool, 3 upsamples, softmax: ~2 % — are left in the denominator, so this is a lower bound that agrees
         # with the rocprofv3 kernel trace under profiles/).  The eager per-launch HIP-event figure is kept beside it.
@@ -549,16 +617,24 @@ def main():
         # with `inflight` requests overlapped the conv launches of different requests share the chip, so a launch's own duration no
         # longer measures anything; `achieved` is then the conv kernels' algorithmic flops of the timed forwards / their wall time
         achieved_multi = flops / t_fwd_multi / 1e12
-        roofline = dict(bound='mfma', achieved=round(achieved_multi, 2), peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-                        frac=round(achieved_multi / F32_MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
+        # `achieved` / `frac`: the conv kernels' algorithmic flops executed inside the SAME timed region as `value` (K steps, forward
+        # + nms + after_nms, `inflight` requests overlapped) / that region's wall time: the post-processing and the few non-conv
+        # kernels stay in the denominator, so this is a lower bound of the conv kernels' own rate.  With requests overlapped a
+        # launch's own duration measures nothing (launches of different requests share the chip): the per-launch figure is
+        # `single_request` (one request at a time), the forward-only aggregate is `forward_only`.
+        achieved_region = region_flops / elapsed_local / 1e12
+        roofline = dict(bound='mfma', achieved=round(achieved_region, 2), peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+                        frac=round(achieved_region / F32_MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
                         kernel='conv_igemm_f32 / conv_igemm_pers (all instantiations)', launches_per_step=launches,
-                        flops_per_launch=round(flops / launches), avg_launch_us=round(t_fwd_multi / launches * 1e6, 2),
-                        forward_graph_ms=round(t_fwd_multi * 1e3, 3), requests_in_flight=inflight,
-                        definition=('algorithmic conv flops per forward / wall time per forward with requests_in_flight forwards '
-                                    'overlapped on as many streams' if inflight > 1 else
-                                    'algorithmic conv flops per forward / graph-replay forward time'),
+                        flops_per_launch=round(flops / launches), avg_launch_us=round(elapsed_local / args.steps / launches * 1e6, 2),
+                        requests_in_flight=inflight,
+                        definition=('algorithmic conv flops of the timed steps / wall time of the SAME region that `value` times '
+                                    '(forward + nms + after_nms, requests_in_flight requests overlapped)'),
+                        forward_only=dict(achieved=round(achieved_multi, 2), frac=round(achieved_multi / F32_MFMA_PEAK_TFLOPS, 4),
+                                          forward_graph_ms=round(t_fwd_multi * 1e3, 3),
+                                          note='separate region, forwards only, same streams'),
                         single_request=single)
-        extra = dict(forward_only_ms=round(t_fwd_multi * 1e3, 3),
+        extra = dict(spread=spread, latency=latency, forward_only_ms=round(t_fwd_multi * 1e3, 3),
                      forward_only_img_s=round(args.batch / t_fwd_multi, 1),
                      forward_tflops=round(flops / t_fwd_multi / 1e12, 2),
                      gflop_per_img=round(flops / args.batch / 1e9, 1))
@@ -603,7 +679,7 @@ def main():
             # reference's 544 px goldens inside the 1e-4 bar (tests/test_gpu_forward.py::test_forward_544_bs8_split_bf16_modes_...);
             # `value` above stays the f32 parity mode.  Roofline here: 3 (6) bf16 MFMA flops per algorithmic flop vs 2.5 PF dense.
             split = {}
-            for name, b, mma in ((args.cfg, 1, 3), (args.cfg, 8, 3), (args.cfg, 8, 6), ('res50_coco', 8, 3), ('swin_tiny_coco', 8, 3)):
+            for name, b, mma in ((args.cfg, 1, 3), (args.cfg, 8, 3), ('res50_coco', 8, 3), ('swin_tiny_coco', 8, 3)):
                 n2, c2 = (net, cfg) if name == args.cfg else build_net(name, args.img_size, device)
                 w2 = Workload(n2, c2, b, args.img_size, device, with_post=not args.no_post)
                 w2.engine.set_mma(mma)
@@ -650,11 +726,16 @@ def main():
         extra['train'] = train
         if train16 is not None:
             extra['train_bs16_per_gpu_ddp8'] = train16
+        if train is not None and 'ddp' in train:          # N > 1: the north star's DDP curve is THIS block (`value` stays the replicas)
+            extra['ddp'] = train['ddp']
         primary_train = args.mode == 'train' and train is not None and 'error' not in train
         out = {
             'metric': (f'img/s {args.cfg} 544x544 DDP training (bs={args.train_batch}/GPU)' if primary_train else
-                       f'img/s {args.cfg} 544x544 inference (bs={args.batch}/GPU)'),
+                       f'img/s {args.cfg} 544x544 inference (bs={args.batch}/GPU'
+                       + (f', {inflight} requests in flight)' if inflight > 1 else ')')),
             'value': train['img_s'] if primary_train else round(value, 2), 'unit': 'img/s', 'n_gpus': world,
+            # the reference's own loop (eval.py:36-69: one image at a time) on the same GPU, beside the overlapped figure
+            'value_single_request': single.get('img_s_with_post') if single else None,
             'steps': train['steps'] if primary_train else args.steps, 'warmup': train['warmup'] if primary_train else args.warmup,
             'ms_per_step': train['ms_per_step'] if primary_train else round(elapsed / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak',

@@ -159,3 +159,18 @@ def test_bench_spawns_one_rank_per_gpu_when_launched_bare(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert 'WORLD_SIZE=2' in str(e.value.code)
+
+
+def test_ddp_block_reports_what_the_scaling_record_needs():
+    """`bench.py --gpus N` (N > 1) keeps `value` = inference replicas and carries the north star's DDP figures under `extra.ddp`:
+    whole-job and per-GPU training img/s, the 1-GPU reference of the committed bench line, bucket layout, how many buckets were
+    handed to the collective during backward, and the exposed all-reduce / buffer-broadcast times."""
+    import types
+    import bench
+    red = types.SimpleNamespace(buckets=[(100, 200, [3, 2]), (0, 100, [1, 0])], last_launch_log=[(0, 2, False), (1, 4, True)])
+    tr = types.SimpleNamespace(reducer=red, ddp=True)
+    blk = bench.ddp_block(tr, dict(allreduce_exposed_ms=1.25, buffer_broadcast_ms=0.05, backward_ms=30.0), 1400.0, 8, 'res101_coco', 8)
+    assert blk['train_img_s'] == 1400.0 and blk['per_gpu'] == 175.0 and blk['buckets'] == 2 and blk['buckets_launched_during_backward'] == 1
+    assert blk['allreduce_exposed_ms'] == 1.25 and blk['buffer_broadcast_ms'] == 0.05 and blk['world_size_seen'] == 1
+    ref = blk['vs_1gpu_reference_img_s']
+    assert ref is None or (ref > 0 and abs(blk['scaling_vs_1gpu'] - round(1400.0 / ref, 3)) < 1e-9 and blk['reference_source'].startswith('profiles/'))

@@ -32,7 +32,7 @@ def main():
             for k, v in res.items():
                 if k not in table:
                     table[k] = v[:7]
-                    detail[k] = v
+                    detail[k] = list(v[:7]) + list(eng.autotune_detail[k])
             net._engines.clear()
             torch.cuda.empty_cache()
     os.makedirs(os.path.dirname(args.out) or '.', exist_ok=True)

@@ -39,6 +39,17 @@ def conv_mma():
     return int(os.environ.get('YM_CONV_MMA', '0') or 0)
 
 
+def _grid_wgs(hit):
+    """Eighth field of a tuned entry = `grid_wgs` of the persistent kernel.  (Old detail rows of `InferEngine.autotune` carried a
+    timing there: anything that is not a non-negative integer is rejected instead of landing in a c_int32 field.)"""
+    if len(hit) <= 7:
+        return 0
+    g = hit[7]
+    if isinstance(g, bool) or not isinstance(g, int) or g < 0:
+        raise ValueError(f'tuned entry {hit}: field 7 must be grid_wgs (a non-negative integer)')
+    return g
+
+
 def tuned_table():
     """Per-shape (tile_m, tile_n, ksplit) choices measured on an MI355X by tools/autotune.py."""
     global _tuned
@@ -91,6 +102,7 @@ class _Conv:
         self.kwaves = 0
         self.stages = 0
         self.tail = (0, 0)           # (tail_tiles, tail_ksplit): see ym_conv_desc
+        self.grid_wgs = 0            # persistent kernel (stages 4x): workgroups launched, 0 = as many as the CUs hold
         self.mma = 0                 # 0 = f32 MFMA (parity mode); 3 / 6 = split-bf16 products (ym_conv_desc.mma)
 
     def refresh(self):
@@ -151,7 +163,7 @@ class _Conv:
             self.tail = (hit[5], hit[6]) if len(hit) > 6 else (0, 0)
             d.tile_m, d.tile_n, d.ksplit, d.kwaves, d.stages = hit[0], hit[1], hit[2], self.kwaves, self.stages
             d.tail_tiles, d.tail_ksplit = self.tail
-            d.grid_wgs = hit[7] if len(hit) > 7 else 0          # persistent kernel (stages 4x): workgroups launched
+            self.grid_wgs = d.grid_wgs = _grid_wgs(hit)         # persistent kernel (stages 4x): workgroups launched
             cap = int(os.environ.get('YM_MAX_KSPLIT', '0') or 0)     # experiment knob: cap the K split of the tuned choice
             if cap and self.ksplit > cap:
                 self.ksplit = d.ksplit = cap
@@ -180,7 +192,7 @@ class _Conv:
                 self.ksplit = cap
             d.tile_m, d.tile_n, d.ksplit, d.kwaves = self.tile[0], self.tile[1], self.ksplit, self.kwaves
             d.tail_tiles, d.tail_ksplit = self.tail
-            d.grid_wgs = hit[7] if len(hit) > 7 else 0
+            self.grid_wgs = d.grid_wgs = _grid_wgs(hit)
             if self.kwaves:                                         # the tuner may prefer the f32 wave kernel for a tiny layer
                 self.mma = 0
                 d.mma = 0
@@ -503,6 +515,7 @@ class InferEngine:
             c.desc.kwaves = c.kwaves
             c.desc.stages = c.stages
             c.desc.tail_tiles, c.desc.tail_ksplit = c.tail
+            c.desc.grid_wgs = c.grid_wgs
             c.desc.mma = c.mma
         self._alloc_workspaces()
         self.graph = None
@@ -515,12 +528,15 @@ class InferEngine:
 
     def autotune(self, iters=10, verbose=False, mma=0, concurrent=False):
         """Time every (tile, ksplit) candidate of every distinct conv shape on this GPU; keep the fastest.
-        Returns {signature: [tile_m, tile_n, ksplit, best_us, default_us]}.
+        Returns {signature: [tile_m, tile_n, ksplit, kwaves, stages, tail_tiles, tail_ksplit, grid_wgs]} = rows of the tuned table;
+        the timings are left in `self.autotune_detail` = {signature: (best_us, default_us)}.  Persistent candidates (stages 4x) are
+        timed and kept with grid_wgs = 0 (as many workgroups as the CUs hold; tools/pers_bench.py sweeps the grid).
         `concurrent`: tune for THROUGHPUT with requests in flight (bench.py --inflight 2) instead of for the latency of a launch
         that has the chip to itself: every candidate is timed as two copies of the launch running side by side on two streams
         (own split-K scratch and arrival counters each); the figure is the wall time per PAIR, so a choice that wins by spreading
         thin over all CUs (many K slices + an exchange) loses to one that does the same work with fewer resources."""
         results = {}
+        self.autotune_detail = {}
         big_ws = torch.empty(1 << 28, device=self.device, dtype=torch.uint8)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ncopy = int(concurrent) if concurrent else 1        # True = 2 copies
@@ -545,6 +561,7 @@ class InferEngine:
             d.tile_m, d.tile_n, d.ksplit, d.kwaves, d.stages = tile[0], tile[1], ks, kwv, stg
             d.mma = mma if (split_ok(c) and kwv == 0) else 0
             d.tail_tiles, d.tail_ksplit = tail
+            d.grid_wgs = 0                       # (never the previous table entry's grid)
             need = hip.conv_workspace_bytes(d)
             if need > big_ws.numel():
                 return None
@@ -584,6 +601,7 @@ class InferEngine:
                 continue
             if c.sig in seen:
                 c.tile, c.ksplit, c.kwaves, c.stages, c.tail = seen[c.sig]
+                c.grid_wgs = 0
                 c.mma = mma if (mma and c.kwaves == 0) else 0
                 continue
             d = c.desc
@@ -640,9 +658,11 @@ class InferEngine:
                 if t is not None and t < best[0] * 0.98:
                     best = (t, tile, ks, kwv, stg, tail)
             c.tile, c.ksplit, c.kwaves, c.stages, c.tail = best[1], best[2], best[3], best[4], best[5]
+            c.grid_wgs = 0
             c.mma = mma if (mma and c.kwaves == 0) else 0
             seen[c.sig] = (c.tile, c.ksplit, c.kwaves, c.stages, c.tail)
-            results[c.sig + (f'_mma{mma}' if mma else '')] = [best[1][0], best[1][1], best[2], best[3], best[4], best[5][0], best[5][1], round(best[0], 2), round(base, 2)]
+            results[c.sig + (f'_mma{mma}' if mma else '')] = [best[1][0], best[1][1], best[2], best[3], best[4], best[5][0], best[5][1], 0]
+            self.autotune_detail[c.sig + (f'_mma{mma}' if mma else '')] = (round(best[0], 2), round(base, 2))
             if verbose:
                 print(f'{c.sig:44s} default {base:8.1f} us -> {best[1]} ks={best[2]} kw={best[3]} st={best[4]} tail={best[5]} {best[0]:8.1f} us', flush=True)
         del big_ws

@@ -103,7 +103,8 @@ def _configure_conv(d, key, stats=False):
         d.kwaves = hit[3] if len(hit) > 3 else 0
         d.stages = hit[4] if len(hit) > 4 else 0
         d.tail_tiles, d.tail_ksplit = (hit[5], hit[6]) if len(hit) > 6 else (0, 0)
-        d.grid_wgs = hit[7] if len(hit) > 7 else 0              # persistent kernel (stages 4x): workgroups launched
+        from .engine import _grid_wgs
+        d.grid_wgs = _grid_wgs(hit)                             # persistent kernel (stages 4x): workgroups launched
     force = os.environ.get('YM_FORCE_STAGES')        # experiments / tests: e.g. 43 = every conv the persistent kernel covers runs on it
     if force:
         d.tile_m, d.tile_n, d.kwaves, d.stages, d.grid_wgs = 64, 64, 0, int(force), int(os.environ.get('YM_FORCE_GRID', '0'))

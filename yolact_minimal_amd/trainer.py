@@ -308,8 +308,26 @@ class Trainer:
             self.buffers_flat = flatten_buffers(self.net)
             self.reducer = FlatGradReducer(self.opt, world)
         self.step_idx = 0
+        self._timing = None
         self.net.mark_weights_changed()              # parameters were re-pointed at the flat buffer
         weights_changed()
+
+    def enable_timing(self):
+        """Bracket the collectives of every following step with HIP events on the step's stream (bench.py `extra.ddp`)."""
+        self._timing = []
+
+    def timing_summary(self):
+        """Means over the timed steps, in ms (synchronises): `buffer_broadcast_ms` (the one-message BN running-stat broadcast),
+        `backward_ms`, `allreduce_exposed_ms` = end of backward on the device (main and weight-gradient streams joined) -> every
+        bucket reduced, i.e. what the overlap with backward did NOT hide."""
+        tm, self._timing = self._timing or [], None
+        if not tm:
+            return {}
+        torch.cuda.synchronize(self.device)
+        n = len(tm)
+        return dict(steps=n, buffer_broadcast_ms=round(sum(e[0].elapsed_time(e[1]) for e in tm) / n, 4),
+                    backward_ms=round(sum(e[2].elapsed_time(e[3]) for e in tm) / n, 4),
+                    allreduce_exposed_ms=round(sum(e[3].elapsed_time(e[4]) for e in tm) / n, 4))
 
     @property
     def module(self):
@@ -375,8 +393,14 @@ class Trainer:
 
     def step(self, images, targets, masks):
         self.opt.lr = lr_at(self.cfg, self.step_idx)
+        ev = None
+        if self._timing is not None:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+            ev[0].record()
         if self.buffers_flat is not None and self.world > 1:
             dist.broadcast(self.buffers_flat, 0)      # BN running stats follow rank 0, one 0.4 MB message
+        if ev is not None:
+            ev[1].record()
         self.opt.zero_grad()                          # before the forward: the host is ahead of the device here
         losses = self.model(images, targets, masks)
         if self.nbt_flat is not None:
@@ -388,10 +412,17 @@ class Trainer:
         from .loss import unit_loss_grads
         from .train_engine import wgrad_on_side_stream
         # weight gradients run on a side stream next to the data-gradient chain; the main stream waits for them at the block's end
+        if ev is not None:
+            ev[2].record()
         with unit_loss_grads(), wgrad_on_side_stream(self.device):   # d(total)/d(loss_i) = 1: stored loss gradients pass through unscaled
             total.backward()
+        if ev is not None:
+            ev[3].record()                            # backward done on the device: the weight-gradient stream was joined at the block's end
         if self.reducer is not None:
             self.reducer.finish()
+        if ev is not None:
+            ev[4].record()                            # ... and every bucket reduced (the step's stream waited for the RCCL stream)
+            self._timing.append(ev)
         self.opt.step()
         self.net.mark_weights_changed()
         self.step_idx += 1
