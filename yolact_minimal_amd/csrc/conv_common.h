@@ -84,6 +84,10 @@ struct ConvP {
                        // share the WEIGHT panel: chosen when the weights are the larger operand, so that the 8 XCD L2s partition them)
     FastDiv fd_tiles_m;
     long long* trace;  // debug builds (-DYM_TRACE, tools/conv_trace.py): per-workgroup s_memtime stamps [grid][4]
+    const int* trace_epoch;  // debug builds: stamps go to region (*trace_epoch % trace_ring) of `trace` ([ring][grid][4]) so that the last
+    int trace_ring;          // `ring` replays of a captured launch stay readable (tools/overlap_trace.py); null / 0: one region
+    int trace_stride;        // workgroup slots per region (0: gridDim.x)
+    int* trace_hw;           // debug builds: HW_REG_HW_ID of each workgroup's first wave ([ring][grid]: CU / SE / pipe / queue ids)
     unsigned in_bytes, w_bytes, ws_bytes;   // sizes of `in` / `w` for the raw-buffer descriptors (out-of-range reads return 0)
     int total_items;   // persistent kernel (conv_persist.hip): (tile, K slice) work items = main_blocks + tail tiles * tail_split
     int nseg;

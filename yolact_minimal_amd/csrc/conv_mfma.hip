@@ -32,8 +32,20 @@ constexpr int PITCH = 36;  // floats
 // Phase stamps for tools/conv_trace.py (only in the -DYM_TRACE debug build: `make -C yolact_minimal_amd/csrc trace`).
 #ifdef YM_TRACE
 // stamp 0 carries the XCC id (HW_REG_XCC_ID[3:0]) in bits 60..63: every XCD has its own counter base, and in a chain of launches
-// block b is NOT always on XCD b % 8
-#define YM_STAMP(i) do { if ((i) == 3) __builtin_amdgcn_s_waitcnt(0); if (p.trace && threadIdx.x == 0) p.trace[(size_t)blockIdx.x * 4 + (i)] = (long long)__builtin_amdgcn_s_memtime() | ((i) == 0 ? (long long)(__builtin_amdgcn_s_getreg(0x1814) & 15) << 60 : 0ll); } while (0)
+// block b is NOT always on XCD b % 8.  With `trace_epoch` the stamps of replay e of a captured launch go to region e % trace_ring
+// (tools/overlap_trace.py: the last few replays of every request slot stay readable); `trace_hw` receives HW_REG_HW_ID (CU,
+// shader engine, compute pipe and queue of the workgroup's first wave).
+// In that mode the stamps are s_memrealtime (the constant-rate counter every CU shares): s_memtime, the shader-clock counter of
+// the phase stamps, has a different base on every shader engine / CU group (measured: up to 16 ms apart inside one XCD), so it
+// orders nothing across CUs.
+// (the epoch word is read with an agent-scope load by the stamping lane: between the kernel nodes of a captured graph the scalar
+//  cache is not invalidated, and a plain `*p.trace_epoch` -- a scalar load -- returned epochs of earlier replays on some CUs)
+__device__ __forceinline__ size_t ym_trace_region(const ymk::ConvP& p) {
+    if (!p.trace_epoch) return 0;
+    const unsigned e = (unsigned)__hip_atomic_load(p.trace_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (size_t)(e % (unsigned)p.trace_ring) * (p.trace_stride ? (unsigned)p.trace_stride : gridDim.x);
+}
+#define YM_STAMP(i) do { if ((i) == 3) __builtin_amdgcn_s_waitcnt(0); if (p.trace && threadIdx.x == 0) { const size_t reg_ = ym_trace_region(p); p.trace[(reg_ + blockIdx.x) * 4 + (i)] = (long long)(p.trace_epoch ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime()) | ((i) == 0 ? (long long)(__builtin_amdgcn_s_getreg(0x1814) & 15) << 60 : 0ll); if ((i) == 0 && p.trace_hw) p.trace_hw[reg_ + blockIdx.x] = (int)__builtin_amdgcn_s_getreg(0xF804); } } while (0)
 #else
 #define YM_STAMP(i) do { } while (0)
 #endif
@@ -987,9 +999,14 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
     p.bn_sum = d->bn_sum; p.bn_sumsq = d->bn_sumsq;
     p.bnb_y = d->bnb_y; p.bnb_out = d->bnb_out; p.bnb_mean = d->bnb_mean; p.bnb_invstd = d->bnb_invstd;
     p.bnb_gamma = d->bnb_gamma; p.bnb_beta = d->bnb_beta; p.bnb_relu = d->bnb_relu;
-    p.trace = nullptr;
+    p.trace = nullptr; p.trace_epoch = nullptr; p.trace_ring = 0; p.trace_stride = 0; p.trace_hw = nullptr;
 #ifdef YM_TRACE
     if (const char* e = getenv("YM_TRACE_PTR")) p.trace = (long long*)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("YM_TRACE_EPOCH_PTR")) p.trace_epoch = (const int*)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("YM_TRACE_RING")) p.trace_ring = atoi(e);
+    if (const char* e = getenv("YM_TRACE_GRID")) p.trace_stride = atoi(e);
+    if (const char* e = getenv("YM_TRACE_HW_PTR")) p.trace_hw = (int*)strtoull(e, nullptr, 10);
+    if (p.trace_ring <= 0) p.trace_epoch = nullptr;
     if (const char* e = getenv("YM_PERS_ABL")) { if (!d->bn_sum) p.bnb_relu = atoi(e); }      // conv_persist.hip ablations (trace build only)
 #endif
     p.counters = (p.vec && pl.slots() > 1 && d->kwaves == 0 && need < 0xFFFFFFF0ull) ? d->tile_counters : nullptr;
