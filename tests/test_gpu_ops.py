@@ -296,6 +296,58 @@ def test_conv_wave_kernel_parity(case):
     assert torch.equal(got, again)
 
 
+WAVE_DMA_CASES = [
+    # b, cin, h, w, cout, k, stride, pad, act, residual, wave tile, kwaves, ring (stages 22 / 23 / 24)
+    (1, 64, 17, 17, 64, 1, 1, 0, 1, False, (32, 32), 1, 22),
+    (1, 256, 34, 34, 256, 3, 1, 1, 1, False, (32, 32), 4, 22),        # layer3's 3x3 at batch 1: the tuned choice
+    (1, 1024, 34, 34, 256, 1, 1, 0, 1, True, (32, 32), 4, 22),        # layer3's conv1
+    (1, 256, 34, 34, 1024, 1, 1, 0, 1, True, (32, 32), 1, 22),        # layer3's conv3 (+ residual): four tiles per workgroup
+    (1, 1024, 9, 11, 256, 1, 1, 0, 1, True, (32, 32), 2, 24),         # ring of 4
+    (2, 128, 19, 19, 128, 3, 2, 1, 1, False, (64, 32), 2, 23),        # stride 2, padding taps, ring of 3
+    (1, 256, 13, 13, 1024, 1, 1, 0, 1, True, (32, 64), 1, 22),
+    (1, 512, 7, 7, 512, 3, 1, 1, 0, False, (32, 64), 4, 23),
+    (2, 64, 20, 23, 96, 1, 1, 0, 2, False, (64, 32), 1, 22),          # tanh epilogue, K = 2 tiles
+    (1, 256, 5, 5, 255, 3, 2, 1, 1, False, (32, 32), 4, 22),          # Cout % 4 != 0 -> scalar epilogue, weight rows past Cout
+    (1, 32, 6, 6, 64, 1, 1, 0, 1, False, (32, 32), 4, 22),            # ONE K tile for four K waves: three waves hold nothing
+    (1, 96, 9, 9, 64, 3, 1, 1, 1, False, (64, 32), 4, 23),            # Cin = 96: a filter tap is three K tiles, ranges cut inside taps
+]
+
+
+@pytest.mark.parametrize('case', WAVE_DMA_CASES)
+def test_conv_wave_dma_ring_kernel_parity(case):
+    """conv_wdma_f32 (round 4): a wave owns a tile and a share of K, its operands stream through a wave-private LDS ring filled
+    by global->LDS DMA, the K waves of a tile combine through LDS in a fixed order.  fp64 reference; bit-reproducible run to run
+    (a ring hazard -- a stage re-filled while its fragments are still being read -- would show as run-to-run differences)."""
+    b, cin, h, w, cout, k, stride, pad, act, use_res, tile, kwaves, stages = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    res = torch.randn(b, cout, ho, wo, generator=g) if use_res else None
+    got = run_conv(x, wt, scale, shift, res, stride, pad, act, tile, 0, kwaves, stages)
+    want = ref_conv(x, wt, scale, shift, res, stride, pad, act)
+    assert not torch.isnan(got).any()
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5)
+    for _ in range(3):
+        again = run_conv(x, wt, scale, shift, res, stride, pad, act, tile, 0, kwaves, stages, repeat=20)
+        assert torch.equal(got, again)
+
+
+def test_conv_wave_dma_ring_rejects_what_it_does_not_cover():
+    """The DMA-ring variant needs Cin % 32 == 0 and a 32x32 / 64x32 / 32x64 wave tile; anything else is an error, not a silent
+    fallback."""
+    x = torch.randn(1, 3, 32, 32)
+    w = torch.randn(64, 3, 7, 7)
+    with pytest.raises(RuntimeError):
+        run_conv(x, w, stride=2, pad=3, tile=(32, 32), kwaves=1, stages=22)          # stem (Cin = 4)
+    x = torch.randn(1, 64, 8, 8)
+    w = torch.randn(64, 64, 1, 1)
+    with pytest.raises(RuntimeError):
+        run_conv(x, w, tile=(64, 64), kwaves=1, stages=22)
+
+
 def test_conv_identity_asymmetric():
     """Transpose-detecting check (cdna guide G9): identity 1x1 weight must return the input exactly."""
     x = torch.arange(2 * 64 * 5 * 7, dtype=torch.float32).reshape(2, 64, 5, 7) * 0.01
@@ -455,3 +507,38 @@ def test_conv_launches_are_race_free(tile, ksplit, stages, tail):
     assert bad == 0, f'{bad} launches differed from the first one'
     assert int(counters.abs().sum()) == 0                                     # arrival counters left at zero
     torch.testing.assert_close(first, want, rtol=1e-5, atol=1e-5 if d.mma != 3 else 1e-4)
+
+
+@pytest.mark.parametrize('tile,kwaves,stages', [((32, 32), 4, 22), ((32, 32), 1, 24), ((64, 32), 2, 23), ((32, 64), 4, 22)])
+def test_conv_wave_dma_ring_launches_are_race_free(tile, kwaves, stages):
+    """The same stress as `test_conv_launches_are_race_free` for conv_wdma_f32: 400 launches of a chip-filling shape (M9248_N1152_C384,
+    10 k+ wave tiles) must be bit-identical -- the wave-private rings have no barrier, only counted vmcnt waits, so a stage
+    re-filled too early or a fragment read before its tile landed would show up here -- and equal to the LDS-tiled kernel up to
+    the association of the K sum."""
+    from yolact_minimal_amd import hip
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    b, h, w, cin, cout = 8, 34, 34, 384, 1152
+    x = torch.randn(b, h, w, cin, generator=g).to(dev)
+    wt = (torch.randn(cout, cin, 1, 1, generator=g) * 0.05).to(dev)
+    wp = hip.pack_conv_weight(wt, cin, cin)
+    out = torch.empty(b, h, w, cout, device=dev)
+    d = hip.ConvDesc()
+    d.inp, d.weight = x.data_ptr(), wp.data_ptr()
+    d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW = b, h, w, cin, cout, 1, 1
+    d.stride, d.pad, d.Ho, d.Wo, d.k_pad, d.nseg = 1, 0, h, w, cin, 1
+    d.seg[0].n_begin, d.seg[0].n_end, d.seg[0].out = 0, cout, out.data_ptr()
+    d.seg[0].batch_stride, d.seg[0].pitch, d.seg[0].act = h * w * cout, cout, 0
+    d.tile_m, d.tile_n = 64, 64
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device=dev)
+    hip.conv2d_fwd(d, ws)
+    want = out.clone()
+    d.tile_m, d.tile_n, d.kwaves, d.stages = tile[0], tile[1], kwaves, stages
+    hip.conv2d_fwd(d, ws)
+    first = out.clone()
+    bad_t = torch.zeros((), device=dev, dtype=torch.int64)
+    for it in range(400):
+        hip.conv2d_fwd(d, ws)
+        bad_t += (out != first).any()
+    assert int(bad_t) == 0, f'{int(bad_t)} launches differed from the first one'
+    torch.testing.assert_close(first, want, rtol=1e-5, atol=1e-5)

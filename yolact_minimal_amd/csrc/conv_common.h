@@ -87,6 +87,7 @@ struct ConvP {
     const int* trace_epoch;  // debug builds: stamps go to region (*trace_epoch % trace_ring) of `trace` ([ring][grid][4]) so that the last
     int trace_ring;          // `ring` replays of a captured launch stay readable (tools/overlap_trace.py); null / 0: one region
     int trace_stride;        // workgroup slots per region (0: gridDim.x)
+    int trace_rt;            // stamp s_memrealtime (100 MHz, one counter for the chip) instead of s_memtime (shader clock, per-CU-group base)
     int* trace_hw;           // debug builds: HW_REG_HW_ID of each workgroup's first wave ([ring][grid]: CU / SE / pipe / queue ids)
     unsigned in_bytes, w_bytes, ws_bytes;   // sizes of `in` / `w` for the raw-buffer descriptors (out-of-range reads return 0)
     int total_items;   // persistent kernel (conv_persist.hip): (tile, K slice) work items = main_blocks + tail tiles * tail_split
@@ -129,8 +130,8 @@ __device__ __forceinline__ void epilogue_store(const ConvP& p, int m, int n, flo
 
 }  // namespace ymk
 
-// conv_wave.hip: wave-private kernel; returns YM_OK / YM_EINVAL (unsupported variant)
-int ym_launch_conv_wave(const ymk::ConvP& p, int tm, int tn, int kwaves, hipStream_t st);
+// conv_wave.hip: wave-private kernels (stages 22 / 23 / 24: the DMA-ring variant); returns YM_OK / YM_EINVAL (unsupported variant)
+int ym_launch_conv_wave(const ymk::ConvP& p, int tm, int tn, int kwaves, int stages, hipStream_t st);
 // conv_persist.hip: persistent direct-to-LDS kernel (ring of `ns` K tiles, `grid` workgroups walk p.total_items work items);
 // mode 0 = convolution, 2 = data gradient; launches with fused BatchNorm sums are not covered.  YM_EINVAL: no such variant.
 // defer: the un-split item's stores are issued under the next item's MFMAs (costs a dedicated 16 KB accumulator tile in LDS).

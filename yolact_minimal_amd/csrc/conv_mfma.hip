@@ -45,7 +45,7 @@ __device__ __forceinline__ size_t ym_trace_region(const ymk::ConvP& p) {
     const unsigned e = (unsigned)__hip_atomic_load(p.trace_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return (size_t)(e % (unsigned)p.trace_ring) * (p.trace_stride ? (unsigned)p.trace_stride : gridDim.x);
 }
-#define YM_STAMP(i) do { if ((i) == 3) __builtin_amdgcn_s_waitcnt(0); if (p.trace && threadIdx.x == 0) { const size_t reg_ = ym_trace_region(p); p.trace[(reg_ + blockIdx.x) * 4 + (i)] = (long long)(p.trace_epoch ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime()) | ((i) == 0 ? (long long)(__builtin_amdgcn_s_getreg(0x1814) & 15) << 60 : 0ll); if ((i) == 0 && p.trace_hw) p.trace_hw[reg_ + blockIdx.x] = (int)__builtin_amdgcn_s_getreg(0xF804); } } while (0)
+#define YM_STAMP(i) do { if ((i) == 3) __builtin_amdgcn_s_waitcnt(0); if (p.trace && threadIdx.x == 0) { const size_t reg_ = ym_trace_region(p); p.trace[(reg_ + blockIdx.x) * 4 + (i)] = (long long)((p.trace_epoch || p.trace_rt) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime()) | ((i) == 0 ? (long long)(__builtin_amdgcn_s_getreg(0x1814) & 15) << 60 : 0ll); if ((i) == 0 && p.trace_hw) p.trace_hw[reg_ + blockIdx.x] = (int)__builtin_amdgcn_s_getreg(0xF804); } } while (0)
 #else
 #define YM_STAMP(i) do { } while (0)
 #endif
@@ -999,12 +999,13 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
     p.bn_sum = d->bn_sum; p.bn_sumsq = d->bn_sumsq;
     p.bnb_y = d->bnb_y; p.bnb_out = d->bnb_out; p.bnb_mean = d->bnb_mean; p.bnb_invstd = d->bnb_invstd;
     p.bnb_gamma = d->bnb_gamma; p.bnb_beta = d->bnb_beta; p.bnb_relu = d->bnb_relu;
-    p.trace = nullptr; p.trace_epoch = nullptr; p.trace_ring = 0; p.trace_stride = 0; p.trace_hw = nullptr;
+    p.trace = nullptr; p.trace_epoch = nullptr; p.trace_ring = 0; p.trace_stride = 0; p.trace_rt = 0; p.trace_hw = nullptr;
 #ifdef YM_TRACE
     if (const char* e = getenv("YM_TRACE_PTR")) p.trace = (long long*)strtoull(e, nullptr, 10);
     if (const char* e = getenv("YM_TRACE_EPOCH_PTR")) p.trace_epoch = (const int*)strtoull(e, nullptr, 10);
     if (const char* e = getenv("YM_TRACE_RING")) p.trace_ring = atoi(e);
     if (const char* e = getenv("YM_TRACE_GRID")) p.trace_stride = atoi(e);
+    if (const char* e = getenv("YM_TRACE_REALTIME")) p.trace_rt = atoi(e);
     if (const char* e = getenv("YM_TRACE_HW_PTR")) p.trace_hw = (int*)strtoull(e, nullptr, 10);
     if (p.trace_ring <= 0) p.trace_epoch = nullptr;
     if (const char* e = getenv("YM_PERS_ABL")) { if (!d->bn_sum) p.bnb_relu = atoi(e); }      // conv_persist.hip ablations (trace build only)
@@ -1034,7 +1035,12 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
                    "conv: bnb_y / bnb_out must be 16-byte aligned [M][Cout] tensors");
     }
     hipStream_t st = (hipStream_t)s;
-    if (d->kwaves > 0) return ym_launch_conv_wave(p, pl.bm, pl.bn, d->kwaves, st);
+    if (d->kwaves > 0) {
+        const bool dma = d->stages >= 22 && d->stages <= 24;
+        YM_REQUIRE(!dma || (d->Cin % 32 == 0 && d->nlevels == 0 && !d->transposed && (size_t)pl.M * d->Cout * 4 < 0xFFFFFFF0ull),
+                   "conv(wave, DMA ring): needs Cin %% 32 == 0, one input size, a forward convolution");
+        return ym_launch_conv_wave(p, pl.bm, pl.bn, d->kwaves, d->stages, st);
+    }
     const int grid = pl.grid();
     p.total_items = grid;
     int stages = d->stages;

@@ -23,6 +23,63 @@ struct Frag {
     f32x4 v[N][4];   // [tile row-block][k group] : lane holds k = 8g + 4h .. +3 of its row
 };
 
+// Stage a wave's partial (32 TM) x (32 TN) tile in LDS, combine the KW K slices of a tile in a fixed order (deterministic), fused
+// epilogue.  `slabs`: [WPB][32 TM][32 TN + 4] floats of LDS that no DMA targets any more.
+template <int TM, int TN, int KW, int WPB>
+__device__ __forceinline__ void wave_tile_finish(const ConvP& p, float* slabs, f32x16 (&acc)[TM][TN], int wave, int lane, bool tile_ok,
+                                                 int tile_local, int kslice, int m0, int n0) {
+    constexpr int WM = 32 * TM, WN = 32 * TN;
+    constexpr int CP = WN + 4;               // LDS pitch of a staged tile (floats)
+    const int frag_row = lane & 31, khalf = lane >> 5;
+    float* mine = slabs + (size_t)wave * WM * CP;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                mine[(i * 32 + 4 * khalf + (r & 3) + 8 * (r >> 2)) * CP + j * 32 + frag_row] = acc[i][j][r];
+    __syncthreads();
+    if (!tile_ok) return;
+    const float* slab0 = slabs + (size_t)(tile_local * KW) * WM * CP;
+    constexpr int C4 = WN / 4;                 // float4 per tile row
+    constexpr int LANES = KW * 64;             // lanes cooperating on this tile
+    const int lt = kslice * 64 + lane;         // 0 .. LANES-1
+    if (p.vec) {
+        const int col4 = lt % C4, row0 = lt / C4;
+        const int n = n0 + col4 * 4;
+        if (n < p.Cout) {
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+            if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+            const int act = p.seg[0].act;
+            for (int row = row0; row < WM; row += LANES / C4) {
+                const int m = m0 + row;
+                if (m >= p.M) break;
+                f32x4 v = *reinterpret_cast<const f32x4*>(slab0 + row * CP + col4 * 4);
+#pragma unroll
+                for (int s = 1; s < KW; ++s) v += *reinterpret_cast<const f32x4*>(slab0 + (size_t)s * WM * CP + row * CP + col4 * 4);
+                v = __builtin_elementwise_fma(v, sc, sh);
+                if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.Cout + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ym_apply_act(v[e], act);
+                *reinterpret_cast<f32x4*>(p.seg[0].out + (size_t)m * p.Cout + n) = v;
+            }
+        }
+    } else {
+        for (int e = lt; e < WM * WN; e += LANES) {
+            const int row = e / WN, col = e - row * WN;
+            const int m = m0 + row, n = n0 + col;
+            if (m < p.M && n < p.Cout) {
+                float v = slab0[row * CP + col];
+#pragma unroll
+                for (int s = 1; s < KW; ++s) v += slab0[(size_t)s * WM * CP + row * CP + col];
+                epilogue_store(p, m, n, v);
+            }
+        }
+    }
+}
+
 // TM,TN: 32x32 MFMA tiles per wave; KW: waves sharing one output tile (K split); WPB: waves per block
 template <int TM, int TN, int KW, int WPB>
 __global__ __launch_bounds__(WPB * 64) void conv_wave_f32(const ConvP p) {
@@ -148,54 +205,189 @@ __global__ __launch_bounds__(WPB * 64) void conv_wave_f32(const ConvP p) {
         }
     }
 
-    // ---- stage partial tiles in LDS, combine the KW slices in fixed order, fused epilogue ------------
-    float* mine = smem + (size_t)wave * WM * CP;
+    wave_tile_finish<TM, TN, KW, WPB>(p, smem, acc, wave, lane, tile_ok, tile_local, kslice, m0, n0);
+}
+
+// ---- wave-private DMA rings (round 4) -----------------------------------------------------------------------------------------
+// The same decomposition (a wave owns a (32 TM) x (32 TN) tile and a 1/KW share of K; the KW waves of a tile combine through LDS),
+// but the operands no longer travel through registers in fragment shape (lane = row: 16 bytes of 32 different rows per load
+// instruction, a quarter of every cache line it touches).  Each wave owns a ring of NS K-tile stages in LDS and fills it with
+// `buffer_load_dwordx4 ... lds` (64 lanes x 16 B = 8 rows x 128 B per instruction: whole lines, no staging registers), D = NS - 1
+// tiles ahead; the fragments are ds_read_b128 out of the XOR-swizzled rows exactly as in conv_igemm_f32<.., DL = true> (slot =
+// chunk ^ ((row >> 1) & 7): the 16 rows of a read phase fall into 16 distinct bank groups).  A ring is private to its wave: the K
+// loop has NO workgroup barrier -- `s_waitcnt vmcnt(n)` on the wave's own loads is the only synchronisation -- and a stage is
+// re-filled one iteration after its last ds_read returned.
+// Why (tools/chain_trace_rt.py, batch 1): a layer3 conv split 3-6 ways over workgroups spends 6-7.4 us of every launch in the
+// K-slice exchange of its last arriver (publish through the fabric, arrival atomic, read everything back) behind a K loop of
+// 8-16 us; with the K split INSIDE the workgroup the exchange is an LDS hand-off.
+template <int TM, int TN, int KW, int NS>
+__global__ __launch_bounds__(256) void conv_wdma_f32(const ConvP p) {
+    constexpr int WPB = 4, TPB = WPB / KW;   // waves per block, output tiles per block
+    constexpr int WM = 32 * TM, WN = 32 * TN;
+    constexpr int AR = 4 * TM, BR = 4 * TN;  // DMA instructions per K tile: 8 rows of 128 B each
+    constexpr int RP = 32;                   // LDS floats per tile row (unpadded: the DMA places lane l's 16 bytes at base + 16 l)
+    constexpr int STAGE = (WM + WN) * RP;    // floats per ring stage of ONE wave: [WM rows of A | WN rows of W]
+    constexpr int D = NS - 1;
+    static_assert(NS >= 2 && NS <= 4 && (AR + BR) * D < 64, "ring depth / vmcnt field");
+    static_assert((size_t)STAGE >= (size_t)WM * (WN + 4), "the finished tile is staged in the wave's first ring stage");
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [WPB][NS][STAGE]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile_local = wave / KW, kslice = wave - tile_local * KW;
+    const int frag_row = lane & 31, khalf = lane >> 5;
+    const int bid = ym_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = bid * TPB + tile_local;
+    const bool tile_ok = tile < p.tiles_m * p.tiles_n;
+    int tile_m = 0, tile_n = 0;
+    if (tile_ok) { tile_m = (int)p.fd_tiles_n.div((unsigned)tile); tile_n = tile - tile_m * p.tiles_n; }
+    const int m0 = tile_m * WM, n0 = tile_n * WN;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+    // ---- DMA coordinates: instruction i of an operand covers its rows 8 i .. 8 i + 7, lane l fills slot l & 7 of row 8 i + (l >> 3),
+    // i.e. fetches chunk (l & 7) ^ ((row >> 1) & 7) = (l & 7) ^ ((4 i + (l >> 4)) & 7) -------------------------------------------------
+    const int drow = lane >> 3;
+    int a_pix[AR], a_ih0[AR], a_iw0[AR];
+    unsigned a_off[AR], wrow[BR];
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                mine[(i * 32 + 4 * khalf + (r & 3) + 8 * (r >> 2)) * CP + j * 32 + frag_row] = acc[i][j][r];
-    __syncthreads();
-    if (!tile_ok) return;
-    const float* slab0 = smem + (size_t)(tile_local * KW) * WM * CP;
-    constexpr int C4 = WN / 4;                 // float4 per tile row
-    constexpr int LANES = KW * 64;             // lanes cooperating on this tile
-    const int lt = kslice * 64 + lane;         // 0 .. LANES-1
-    if (p.vec) {
-        const int col4 = lt % C4, row0 = lt / C4;
-        const int n = n0 + col4 * 4;
-        if (n < p.Cout) {
-            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-            if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-            if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
-            const int act = p.seg[0].act;
-            for (int row = row0; row < WM; row += LANES / C4) {
-                const int m = m0 + row;
-                if (m >= p.M) break;
-                f32x4 v = *reinterpret_cast<const f32x4*>(slab0 + row * CP + col4 * 4);
-#pragma unroll
-                for (int s = 1; s < KW; ++s) v += *reinterpret_cast<const f32x4*>(slab0 + (size_t)s * WM * CP + row * CP + col4 * 4);
-                v = __builtin_elementwise_fma(v, sc, sh);
-                if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.Cout + n);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = ym_apply_act(v[e], act);
-                *reinterpret_cast<f32x4*>(p.seg[0].out + (size_t)m * p.Cout + n) = v;
-            }
-        }
-    } else {
-        for (int e = lt; e < WM * WN; e += LANES) {
-            const int row = e / WN, col = e - row * WN;
-            const int m = m0 + row, n = n0 + col;
-            if (m < p.M && n < p.Cout) {
-                float v = slab0[row * CP + col];
-#pragma unroll
-                for (int s = 1; s < KW; ++s) v += slab0[(size_t)s * WM * CP + row * CP + col];
-                epilogue_store(p, m, n, v);
-            }
+    for (int i = 0; i < AR; ++i) {
+        const int m = m0 + 8 * i + drow;
+        if (tile_ok && m < p.M) {
+            unsigned ub, urem, uoh, uow;
+            p.fd_howo.divmod((unsigned)m, ub, urem);
+            p.fd_wo.divmod(urem, uoh, uow);
+            a_ih0[i] = (int)uoh * p.stride - p.pad;
+            a_iw0[i] = (int)uow * p.stride - p.pad;
+            a_pix[i] = ((int)ub * p.H + a_ih0[i]) * p.W + a_iw0[i];
+        } else {
+            a_ih0[i] = -(1 << 20); a_iw0[i] = -(1 << 20); a_pix[i] = 0;
         }
     }
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+        const int n = n0 + 8 * j + drow;
+        const int c4 = (lane & 7) ^ ((4 * j + (lane >> 4)) & 7);
+        wrow[j] = (tile_ok && n < p.Cout) ? (unsigned)((n * p.Kpad + c4 * 4) * 4) : p.w_bytes;       // past Cout: parked at the buffer's end
+    }
+
+    // this wave's K tiles: a contiguous range (the filter-tap walker is wave-uniform)
+    const int per = (p.nkt + KW - 1) / KW;
+    const int kt_beg = kslice * per, kt_end = tile_ok ? min(p.nkt, kt_beg + per) : kt_beg;
+    const int nt = max(0, kt_end - kt_beg);
+    int kh, kw, c0;
+    {
+        unsigned tap, uc0, ukh, ukw;
+        p.fd_cin.divmod((unsigned)(kt_beg * BK), tap, uc0);
+        p.fd_kw.divmod(tap, ukh, ukw);
+        c0 = (int)uc0; kh = (int)ukh; kw = (int)ukw;
+    }
+    bool tap_dirty = true;
+    int ld_kt = kt_beg;
+    float* ring = smem + (size_t)wave * NS * STAGE;
+
+    // next K tile of this wave's stream -> ring stage `stage` (asynchronous, AR + BR loads per lane, always: tiles past the range
+    // are fetched like any other and never consumed, so the counted vmcnt waits stay valid)
+    auto dma_next = [&](int stage) __attribute__((always_inline)) {
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        if (tap_dirty) {                           // wave-uniform: the filter tap changed (never inside a 1x1 conv)
+            tap_dirty = false;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+                const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                const int c4 = (lane & 7) ^ ((4 * i + (lane >> 4)) & 7);
+                a_off[i] = (unsigned)(((a_pix[i] + kh * p.W + kw) * p.Cin + c4 * 4) * 4) | (ok ? 0u : OOB);
+            }
+        }
+        float* a = ring + stage * STAGE;           // wave-uniform; lane l lands at + 16 l bytes of each 1 KB block
+        float* b = a + WM * RP;
+#pragma unroll
+        for (int i = 0; i < AR; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr)(a + 8 * i * RP), 16, (int)a_off[i], c0 * 4, 0, 0);
+#pragma unroll
+        for (int j = 0; j < BR; ++j) {
+            const unsigned wo = wrow[j];           // (a local copy: hipcc drops the kernel's host stub for an array element here)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(b + 8 * j * RP), 16, (int)wo, ld_kt * BK * 4, 0, 0);
+        }
+        ++ld_kt;
+        c0 += BK;
+        if (c0 >= p.Cin) {
+            c0 = 0;
+            if (++kw == p.KW) { kw = 0; ++kh; }
+            tap_dirty = true;
+        }
+    };
+
+    // fragments: lane half h takes k = 8 g + 4 h + s of K group g (one ds_read_b128 per operand row feeds four MFMA steps)
+    typedef const __attribute__((address_space(3))) f32x4* lds_frag_ptr;
+    lds_frag_ptr pa[4], pb[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int goff = ((2 * g + khalf) ^ ((frag_row >> 1) & 7)) * 4;
+        pa[g] = (lds_frag_ptr)(ring + frag_row * RP + goff);
+        pb[g] = (lds_frag_ptr)(ring + WM * RP + frag_row * RP + goff);
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    constexpr bool DUAL = TM * TN == 1;      // a lone accumulator would chain every MFMA to the previous one (~88 instead of 64 cycles)
+    f32x16 acc_odd;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_odd[r] = 0.f;
+
+    auto compute = [&](auto S) __attribute__((always_inline)) {
+        constexpr int ST = decltype(S)::value;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = pa[g][(ST * STAGE + i * 32 * RP) / 4];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = pb[g][(ST * STAGE + j * 32 * RP) / 4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                if constexpr (DUAL) {
+                    if (s4 & 1) acc_odd = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][s4], fb[0][s4], acc_odd, 0, 0, 0);
+                    else acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][s4], fb[0][s4], acc[0][0], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s4], fb[j][s4], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // ---- the stream: tile t lives in stage t % NS (a literal below: the loop is unrolled by the ring depth) ---------------------------
+    // vmcnt((AR + BR) D): everything but the newest D tiles has landed = tile t.  lgkmcnt(0): the ds_reads of the previous tile have
+    // returned before the DMA issued below re-fills their stage (they fed MFMAs that were issued, but hipcc may sink the wait).
+    constexpr int WAIT = ((AR + BR) * D & 15) | ((((AR + BR) * D) >> 4) << 14) | (7 << 4) | (0 << 8);
+#pragma unroll
+    for (int d = 0; d < D; ++d) dma_next(d);
+    auto tile_step = [&](auto S) __attribute__((always_inline)) {
+        constexpr int ST = decltype(S)::value;
+        __builtin_amdgcn_sched_barrier(0);         // the re-fill of the stage read last stays behind the MFMAs that consumed its fragments
+        dma_next((ST + D) % NS);
+        __builtin_amdgcn_s_waitcnt(WAIT);
+        compute(S);
+    };
+    int t = 0;
+    for (; t + NS <= nt; t += NS) static_for<0, NS>([&](auto S) __attribute__((always_inline)) { tile_step(S); });
+    static_for<0, NS - 1>([&](auto S) __attribute__((always_inline)) { if (t + decltype(S)::value < nt) tile_step(S); });
+    if constexpr (DUAL) acc[0][0] += acc_odd;
+    // the run-ahead loads still target this wave's ring: drain them before the first stage becomes the tile's staging slab
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    // slabs: one per wave, WM x (WN + 4) floats, at the start of each wave's ring (ring pitch NS * STAGE >= slab size)
+    // -> wave_tile_finish expects them back to back: use a compact region at the start of the block's LDS instead (every ring is dead)
+    wave_tile_finish<TM, TN, KW, WPB>(p, smem, acc, wave, lane, tile_ok, tile_local, kslice, m0, n0);
 }
 
 template <int TM, int TN, int KW, int WPB>
@@ -229,9 +421,44 @@ int dispatch_kw(const ConvP& p, int kwaves, hipStream_t st) {
     }
 }
 
+template <int TM, int TN, int KW, int NS>
+int launch_dma(ConvP p, hipStream_t st) {
+    constexpr int TPB = 4 / KW;
+    p.tiles_m = ym_cdiv(p.M, 32 * TM);
+    p.tiles_n = ym_cdiv(p.Cout, 32 * TN);
+    p.fd_tiles_n = FastDiv::make((unsigned)p.tiles_n);
+    p.ksplit = 1;
+    const int grid = ym_cdiv(p.tiles_m * p.tiles_n, TPB);
+    const size_t lds = (size_t)4 * NS * (32 * TM + 32 * TN) * 32 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wdma_f32<TM, TN, KW, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_wdma_f32<TM, TN, KW, NS>), dim3(grid), dim3(256), lds, st, p);
+    return ym_check_launch("conv_wdma_f32");
+}
+
+template <int TM, int TN>
+int dispatch_dma(const ConvP& p, int kwaves, int ns, hipStream_t st) {
+#define YM_DMA_CASE(KW_, NS_) if (kwaves == KW_ && ns == NS_) return launch_dma<TM, TN, KW_, NS_>(p, st)
+    YM_DMA_CASE(1, 2); YM_DMA_CASE(1, 3); YM_DMA_CASE(2, 2); YM_DMA_CASE(2, 3); YM_DMA_CASE(4, 2); YM_DMA_CASE(4, 3);
+    if constexpr (TM * TN == 1) { YM_DMA_CASE(1, 4); YM_DMA_CASE(2, 4); YM_DMA_CASE(4, 4); }
+#undef YM_DMA_CASE
+    ym_set_error("conv(wave, DMA ring): kwaves %d with a ring of %d is not built for a %dx%d wave tile", kwaves, ns, 32 * TM, 32 * TN);
+    return YM_EINVAL;
+}
+
 }  // namespace
 
-int ym_launch_conv_wave(const ConvP& p, int tm, int tn, int kwaves, hipStream_t st) {
+int ym_launch_conv_wave(const ConvP& p, int tm, int tn, int kwaves, int stages, hipStream_t st) {
+    if (stages >= 22 && stages <= 24) {          // wave-private DMA rings of 2 / 3 / 4 K tiles (Cin % 32 == 0, one input size)
+        if (tm == 32 && tn == 32) return dispatch_dma<1, 1>(p, kwaves, stages - 20, st);
+        if (tm == 64 && tn == 32) return dispatch_dma<2, 1>(p, kwaves, stages - 20, st);
+        if (tm == 32 && tn == 64) return dispatch_dma<1, 2>(p, kwaves, stages - 20, st);
+        ym_set_error("conv(wave, DMA ring): tile must be 32x32, 64x32 or 32x64, got %dx%d", tm, tn);
+        return YM_EINVAL;
+    }
     if (tm == 32 && tn == 32) return dispatch_kw<1, 1>(p, kwaves, st);
     if (tm == 64 && tn == 32) return dispatch_kw<2, 1>(p, kwaves, st);
     if (tm == 32 && tn == 64) return dispatch_kw<1, 2>(p, kwaves, st);
