@@ -335,6 +335,37 @@ def test_conv_wave_dma_ring_kernel_parity(case):
         assert torch.equal(got, again)
 
 
+@pytest.mark.parametrize('case', [
+    # b, cin, h, w, cout, k, stride, pad, act, residual, tail tiles, tail split
+    (1, 256, 34, 34, 256, 3, 1, 1, 1, False, 40, 6),           # layer3's 3x3 at batch 1: 296 tiles = 256 whole + 40 in sixths
+    (1, 1024, 34, 34, 256, 1, 1, 0, 1, True, 40, 4),           # layer3's conv1 (+ residual in the last arriver's epilogue)
+    (1, 256, 34, 34, 256, 3, 1, 1, 1, False, 296, 3),          # every tile in the tail
+    (1, 64, 9, 9, 96, 3, 1, 1, 0, False, 5, 8),                # rows past M, 18 K tiles in 8 slices (the last ones short)
+    (2, 128, 19, 19, 128, 3, 2, 1, 1, False, 7, 16),           # more slices asked for than the gather takes: clamped to 8
+])
+def test_conv_wave_dma_ring_tail_split(case):
+    """conv_wdma_f32 with `tail_tiles`: the last tiles are computed as K slices by extra workgroups (second slot of every CU) whose
+    partial tiles meet through the workspace -- fp64 reference, bit-reproducible, counters left at zero."""
+    from yolact_minimal_amd import hip
+    b, cin, h, w, cout, k, stride, pad, act, use_res, tail_tiles, tail_split = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    res = torch.randn(b, cout, ho, wo, generator=g) if use_res else None
+    counters = torch.zeros(hip.TILE_COUNTERS, device=_dev(), dtype=torch.int32)
+    kw = dict(tile=(32, 32), kwaves=4, stages=22, counters=counters, tail=(tail_tiles, tail_split))
+    got = run_conv(x, wt, scale, shift, res, stride, pad, act, **kw)
+    want = ref_conv(x, wt, scale, shift, res, stride, pad, act)
+    assert not torch.isnan(got).any()
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5)
+    for _ in range(3):
+        assert torch.equal(got, run_conv(x, wt, scale, shift, res, stride, pad, act, repeat=30, **kw))
+    assert int(counters.abs().sum()) == 0
+
+
 def test_conv_wave_dma_ring_rejects_what_it_does_not_cover():
     """The DMA-ring variant needs Cin % 32 == 0 and a 32x32 / 64x32 / 32x64 wave tile; anything else is an error, not a silent
     fallback."""

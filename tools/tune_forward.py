@@ -100,22 +100,30 @@ for _, sig, t0 in sorted(order):
     cs = groups[sig]
     c, d = cs[0], cs[0].desc
     cur = get(c)
+    M = d.B * d.Ho * d.Wo
     cands = []
     for tm, tn in ((32, 32), (64, 32), (32, 64)):
         for kwv in (1, 2, 4):
             if kwv > d.k_pad // 32:
                 continue
-            v = [tm, tn, 1, kwv, 22, 0, 0, 0]
-            keep = (d.tile_m, d.tile_n, d.ksplit, d.kwaves, d.stages, d.tail_tiles, d.tail_ksplit, d.grid_wgs)
-            d.tile_m, d.tile_n, d.ksplit, d.kwaves, d.stages, d.tail_tiles, d.tail_ksplit, d.grid_wgs = v
-            t = launch_time(d)
-            d.tile_m, d.tile_n, d.ksplit, d.kwaves, d.stages, d.tail_tiles, d.tail_ksplit, d.grid_wgs = keep
-            if t is not None:
-                cands.append((t, v))
+            vs = [[tm, tn, 1, kwv, 22, 0, 0, 0]]
+            tiles = -(-M // 32) * -(-d.Cout // 32)
+            if (tm, tn, kwv) == (32, 32, 4) and tiles > 256 and d.nseg == 1 and d.tile_counters:
+                # tail split: the tiles past the last full round of 256 CUs are computed as K slices in the CUs' second slots
+                for ts in (4, 6, 8):
+                    if ts * 2 <= d.k_pad // 32:
+                        vs.append([tm, tn, 1, kwv, 22, tiles % 256 or 256, ts, 0])
+            for v in vs:
+                keep = (d.tile_m, d.tile_n, d.ksplit, d.kwaves, d.stages, d.tail_tiles, d.tail_ksplit, d.grid_wgs)
+                d.tile_m, d.tile_n, d.ksplit, d.kwaves, d.stages, d.tail_tiles, d.tail_ksplit, d.grid_wgs = v
+                t = launch_time(d)
+                d.tile_m, d.tile_n, d.ksplit, d.kwaves, d.stages, d.tail_tiles, d.tail_ksplit, d.grid_wgs = keep
+                if t is not None:
+                    cands.append((t, v))
     cands.sort()
     tried = 0
     for t, v in cands:
-        if v == cur or t > args.slack * min(t0, cands[0][0]) or tried >= 3:
+        if v == cur or t > args.slack * min(t0, cands[0][0]) or tried >= 4:
             continue
         tried += 1
         put(sig, v)

@@ -96,6 +96,28 @@ struct ConvP {
     SegDev seg[3];
 };
 
+// Phase stamps for tools/conv_trace.py (only in the -DYM_TRACE debug build: `make -C yolact_minimal_amd/csrc trace`).
+#ifdef YM_TRACE
+// stamp 0 carries the XCC id (HW_REG_XCC_ID[3:0]) in bits 60..63: every XCD has its own counter base, and in a chain of launches
+// block b is NOT always on XCD b % 8.  With `trace_epoch` the stamps of replay e of a captured launch go to region e % trace_ring
+// (tools/overlap_trace.py: the last few replays of every request slot stay readable); `trace_hw` receives HW_REG_HW_ID (CU,
+// shader engine, compute pipe and queue of the workgroup's first wave).
+// In that mode the stamps are s_memrealtime (the constant-rate counter every CU shares): s_memtime, the shader-clock counter of
+// the phase stamps, has a different base on every shader engine / CU group (measured: up to 16 ms apart inside one XCD), so it
+// orders nothing across CUs.
+// (the epoch word is read with an agent-scope load by the stamping lane: between the kernel nodes of a captured graph the scalar
+//  cache is not invalidated, and a plain `*p.trace_epoch` -- a scalar load -- returned epochs of earlier replays on some CUs)
+__device__ __forceinline__ size_t ym_trace_region(const ConvP& p) {
+    if (!p.trace_epoch) return 0;
+    const unsigned e = (unsigned)__hip_atomic_load(p.trace_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (size_t)(e % (unsigned)p.trace_ring) * (p.trace_stride ? (unsigned)p.trace_stride : gridDim.x);
+}
+#define YM_STAMP(i) do { if ((i) == 3) __builtin_amdgcn_s_waitcnt(0); if (p.trace && threadIdx.x == 0) { const size_t reg_ = ym_trace_region(p); p.trace[(reg_ + blockIdx.x) * 4 + (i)] = (long long)((p.trace_epoch || p.trace_rt) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime()) | ((i) == 0 ? (long long)(__builtin_amdgcn_s_getreg(0x1814) & 15) << 60 : 0ll); if ((i) == 0 && p.trace_hw) p.trace_hw[reg_ + blockIdx.x] = (int)__builtin_amdgcn_s_getreg(0xF804); } } while (0)
+#else
+#define YM_STAMP(i) do { } while (0)
+#endif
+
+
 // GEMM row m -> (image b, output pixel inside the image); pyramid inputs place level l's pixels after those of levels < l
 __device__ __forceinline__ void row_to_image_pixel(const ConvP& p, int m, int& b, int& pix) {
     if (p.nlev > 0) {

@@ -29,27 +29,6 @@ namespace {
 
 constexpr int PITCH = 36;  // floats
 
-// Phase stamps for tools/conv_trace.py (only in the -DYM_TRACE debug build: `make -C yolact_minimal_amd/csrc trace`).
-#ifdef YM_TRACE
-// stamp 0 carries the XCC id (HW_REG_XCC_ID[3:0]) in bits 60..63: every XCD has its own counter base, and in a chain of launches
-// block b is NOT always on XCD b % 8.  With `trace_epoch` the stamps of replay e of a captured launch go to region e % trace_ring
-// (tools/overlap_trace.py: the last few replays of every request slot stay readable); `trace_hw` receives HW_REG_HW_ID (CU,
-// shader engine, compute pipe and queue of the workgroup's first wave).
-// In that mode the stamps are s_memrealtime (the constant-rate counter every CU shares): s_memtime, the shader-clock counter of
-// the phase stamps, has a different base on every shader engine / CU group (measured: up to 16 ms apart inside one XCD), so it
-// orders nothing across CUs.
-// (the epoch word is read with an agent-scope load by the stamping lane: between the kernel nodes of a captured graph the scalar
-//  cache is not invalidated, and a plain `*p.trace_epoch` -- a scalar load -- returned epochs of earlier replays on some CUs)
-__device__ __forceinline__ size_t ym_trace_region(const ymk::ConvP& p) {
-    if (!p.trace_epoch) return 0;
-    const unsigned e = (unsigned)__hip_atomic_load(p.trace_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return (size_t)(e % (unsigned)p.trace_ring) * (p.trace_stride ? (unsigned)p.trace_stride : gridDim.x);
-}
-#define YM_STAMP(i) do { if ((i) == 3) __builtin_amdgcn_s_waitcnt(0); if (p.trace && threadIdx.x == 0) { const size_t reg_ = ym_trace_region(p); p.trace[(reg_ + blockIdx.x) * 4 + (i)] = (long long)((p.trace_epoch || p.trace_rt) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime()) | ((i) == 0 ? (long long)(__builtin_amdgcn_s_getreg(0x1814) & 15) << 60 : 0ll); if ((i) == 0 && p.trace_hw) p.trace_hw[reg_ + blockIdx.x] = (int)__builtin_amdgcn_s_getreg(0xF804); } } while (0)
-#else
-#define YM_STAMP(i) do { } while (0)
-#endif
-
 // MODE 0: Cin % 32 == 0 (every K tile lies inside one filter tap).  MODE 1: Cin == 4 (stem; one tap per float4).
 // MODE 2: data gradient (transposed conv): output pixel (ih,iw) gathers dY[(ih+pad-kh)/s][(iw+pad-kw)/s] where divisible.
 // NS: LDS ring depth.  2 = load(t+1) overlaps compute(t).  3 = loads run TWO tiles ahead (small tiles with one workgroup per
@@ -869,6 +848,16 @@ int make_plan(const ym_conv_desc* d, Plan* pl) {
         YM_REQUIRE((bm == 32 || bm == 64) && (bn == 32 || bn == 64), "conv(wave): tile must be 32/64, got %dx%d", bm, bn);
         pl->bm = bm; pl->bn = bn; pl->tiles_m = ym_cdiv(pl->M, bm); pl->tiles_n = ym_cdiv(d->Cout, bn);
         pl->ksplit = 1; pl->kt_per_split = pl->nkt;
+        // tail split of the wave-private DMA-ring kernel (conv_wave.hip): 32x32 tile with four K waves, plain NHWC output, counters
+        if (d->tail_tiles > 0 && d->tail_ksplit > 1 && d->stages >= 22 && d->stages <= 24 && bm == 32 && bn == 32 && d->kwaves == 4 &&
+            d->tile_counters && vec_epilogue(d)) {
+            YM_REQUIRE(d->tail_tiles <= pl->tiles_m * pl->tiles_n, "conv(wave): tail_tiles %d > %d output tiles", d->tail_tiles, pl->tiles_m * pl->tiles_n);
+            int ts = d->tail_ksplit > pl->nkt ? pl->nkt : d->tail_ksplit;
+            if (ts > 8) ts = 8;                                    // (the last arriver gathers up to 8 slices at once)
+            pl->tail_ktps = ym_cdiv(pl->nkt, ts);
+            pl->tail_split = ym_cdiv(pl->nkt, pl->tail_ktps);
+            pl->tail_tiles = pl->tail_split > 1 ? d->tail_tiles : 0;
+        }
         return YM_OK;
     }
     YM_REQUIRE((bm == 128 || bm == 64) && (bn == 128 || bn == 64), "conv: tile must be 64/128");
@@ -942,7 +931,7 @@ extern "C" size_t ym_conv2d_workspace_bytes(const ym_conv_desc* d) {
 
 extern "C" int ym_conv2d_tile_counters(const ym_conv_desc* d) {
     Plan pl;
-    if (make_plan(d, &pl) != YM_OK || d->kwaves > 0) return 0;
+    if (make_plan(d, &pl) != YM_OK) return 0;
     return pl.slots() > 1 ? pl.tiles_m * pl.tiles_n : 0;
 }
 
@@ -1010,7 +999,7 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
     if (p.trace_ring <= 0) p.trace_epoch = nullptr;
     if (const char* e = getenv("YM_PERS_ABL")) { if (!d->bn_sum) p.bnb_relu = atoi(e); }      // conv_persist.hip ablations (trace build only)
 #endif
-    p.counters = (p.vec && pl.slots() > 1 && d->kwaves == 0 && need < 0xFFFFFFF0ull) ? d->tile_counters : nullptr;
+    p.counters = (p.vec && pl.slots() > 1 && (d->kwaves == 0 || pl.tail_tiles > 0) && need < 0xFFFFFFF0ull) ? d->tile_counters : nullptr;
     YM_REQUIRE(pl.tail_tiles == 0 || p.counters, "conv: tail_tiles needs a plain NHWC output (vector epilogue) and a workspace < 4 GiB");
     p.main_tiles = pl.tiles_m * pl.tiles_n - pl.tail_tiles;
     p.main_blocks = p.main_tiles * pl.ksplit;

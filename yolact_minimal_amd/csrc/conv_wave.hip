@@ -18,6 +18,9 @@ using namespace ymk;
 
 namespace {
 
+// s_waitcnt immediate for gfx9 with only vmcnt counted: vmcnt[3:0] = bits 3:0, vmcnt[5:4] = bits 15:14 (expcnt / lgkmcnt: no wait)
+constexpr int waitcnt_vm(int vm) { return (vm & 15) | ((vm >> 4) << 14) | (7 << 4) | (15 << 8); }
+
 template <int N>
 struct Frag {
     f32x4 v[N][4];   // [tile row-block][k group] : lane holds k = 8g + 4h .. +3 of its row
@@ -85,7 +88,6 @@ template <int TM, int TN, int KW, int WPB>
 __global__ __launch_bounds__(WPB * 64) void conv_wave_f32(const ConvP p) {
     constexpr int TPB = WPB / KW;            // output tiles per block
     constexpr int WM = 32 * TM, WN = 32 * TN;
-    constexpr int CP = WN + 4;               // LDS pitch of a staged tile (floats)
     constexpr int D = 3;                     // register ring depth
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [WPB][WM][CP]
 
@@ -236,8 +238,22 @@ __global__ __launch_bounds__(256) void conv_wdma_f32(const ConvP p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tile_local = wave / KW, kslice = wave - tile_local * KW;
     const int frag_row = lane & 31, khalf = lane >> 5;
-    const int bid = ym_xcd_remap(blockIdx.x, gridDim.x);
-    const int tile = bid * TPB + tile_local;
+    YM_STAMP(0);
+    // Tail split (ym_conv_desc.tail_tiles, KW == 4 and a 32x32 tile only): 296 tiles on 256 CUs leave 40 CUs with two workgroups, and
+    // the launch lasts as long as those (tools/chain_trace_rt.py: layer3's 3x3 at batch 1, median workgroup exit 14.7 us, last 22.7).
+    // The LAST tail_tiles tiles are therefore computed as tail_split K slices each, by workgroups that fill the second slot of
+    // every CU with a fraction of a tile; their partial tiles meet through the workspace (sc1 stores, arrival counter, the last
+    // arriver sums in slice order and runs the epilogue: conv_igemm_f32's exchange) while the whole tiles are still in their K loops.
+    constexpr bool TAIL = TM * TN == 1 && KW == 4;
+    const bool in_tail = TAIL && (int)blockIdx.x >= p.main_blocks;
+    int tile, tslice = 0, tsplit = 1;
+    if (in_tail) {
+        unsigned q, r;
+        p.fd_tail.divmod(blockIdx.x - (unsigned)p.main_blocks, q, r);
+        tile = p.main_tiles + (int)q; tslice = (int)r; tsplit = p.tail_split;
+    } else {
+        tile = ym_xcd_remap(blockIdx.x, TAIL ? p.main_blocks : (int)gridDim.x) * TPB + tile_local;
+    }
     const bool tile_ok = tile < p.tiles_m * p.tiles_n;
     int tile_m = 0, tile_n = 0;
     if (tile_ok) { tile_m = (int)p.fd_tiles_n.div((unsigned)tile); tile_n = tile - tile_m * p.tiles_n; }
@@ -272,8 +288,10 @@ __global__ __launch_bounds__(256) void conv_wdma_f32(const ConvP p) {
     }
 
     // this wave's K tiles: a contiguous range (the filter-tap walker is wave-uniform)
-    const int per = (p.nkt + KW - 1) / KW;
-    const int kt_beg = kslice * per, kt_end = tile_ok ? min(p.nkt, kt_beg + per) : kt_beg;
+    // (a tail workgroup owns K slice `tslice` of its tile, [tslice * tail_ktps, ...), and splits THAT among its waves)
+    const int k_lo = in_tail ? tslice * p.tail_ktps : 0, k_hi = in_tail ? min(p.nkt, k_lo + p.tail_ktps) : p.nkt;
+    const int per = (k_hi - k_lo + KW - 1) / KW;
+    const int kt_beg = k_lo + kslice * per, kt_end = tile_ok ? min(k_hi, kt_beg + per) : kt_beg;
     const int nt = max(0, kt_end - kt_beg);
     int kh, kw, c0;
     {
@@ -302,13 +320,17 @@ __global__ __launch_bounds__(256) void conv_wdma_f32(const ConvP p) {
         }
         float* a = ring + stage * STAGE;           // wave-uniform; lane l lands at + 16 l bytes of each 1 KB block
         float* b = a + WM * RP;
+        // (tiles past this wave's K range are fetched like any other and never consumed: the load count per step must not change.  An
+        //  SGPR offset beyond the buffer was tried to make them return at once -- 17.6 -> 21.1 us per launch in the layer3 chain: such
+        //  an access is not an early-out.)
+        const int soff_a = c0 * 4, soff_b = ld_kt * BK * 4;
 #pragma unroll
         for (int i = 0; i < AR; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr)(a + 8 * i * RP), 16, (int)a_off[i], c0 * 4, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr)(a + 8 * i * RP), 16, (int)a_off[i], soff_a, 0, 0);
 #pragma unroll
         for (int j = 0; j < BR; ++j) {
             const unsigned wo = wrow[j];           // (a local copy: hipcc drops the kernel's host stub for an array element here)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(b + 8 * j * RP), 16, (int)wo, ld_kt * BK * 4, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(b + 8 * j * RP), 16, (int)wo, soff_b, 0, 0);
         }
         ++ld_kt;
         c0 += BK;
@@ -368,9 +390,12 @@ __global__ __launch_bounds__(256) void conv_wdma_f32(const ConvP p) {
     // ---- the stream: tile t lives in stage t % NS (a literal below: the loop is unrolled by the ring depth) ---------------------------
     // vmcnt((AR + BR) D): everything but the newest D tiles has landed = tile t.  lgkmcnt(0): the ds_reads of the previous tile have
     // returned before the DMA issued below re-fills their stage (they fed MFMAs that were issued, but hipcc may sink the wait).
-    constexpr int WAIT = ((AR + BR) * D & 15) | ((((AR + BR) * D) >> 4) << 14) | (7 << 4) | (0 << 8);
+    constexpr int WAIT = waitcnt_vm((AR + BR) * D) & ~(15 << 8);       // + lgkmcnt(0)
 #pragma unroll
     for (int d = 0; d < D; ++d) dma_next(d);
+#ifdef YM_TRACE
+    if (p.trace) { __builtin_amdgcn_s_waitcnt(waitcnt_vm((AR + BR) * (D - 1))); YM_STAMP(1); }      // (first tile landed)
+#endif
     auto tile_step = [&](auto S) __attribute__((always_inline)) {
         constexpr int ST = decltype(S)::value;
         __builtin_amdgcn_sched_barrier(0);         // the re-fill of the stage read last stays behind the MFMAs that consumed its fragments
@@ -382,12 +407,63 @@ __global__ __launch_bounds__(256) void conv_wdma_f32(const ConvP p) {
     for (; t + NS <= nt; t += NS) static_for<0, NS>([&](auto S) __attribute__((always_inline)) { tile_step(S); });
     static_for<0, NS - 1>([&](auto S) __attribute__((always_inline)) { if (t + decltype(S)::value < nt) tile_step(S); });
     if constexpr (DUAL) acc[0][0] += acc_odd;
+    YM_STAMP(2);
     // the run-ahead loads still target this wave's ring: drain them before the first stage becomes the tile's staging slab
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     // slabs: one per wave, WM x (WN + 4) floats, at the start of each wave's ring (ring pitch NS * STAGE >= slab size)
     // -> wave_tile_finish expects them back to back: use a compact region at the start of the block's LDS instead (every ring is dead)
+    if constexpr (TAIL) {
+        if (in_tail) {
+            // 32x32 tile, 256 lanes: every lane owns ONE float4 of the tile.  Combine the four K waves through LDS, publish the partial
+            // tile of this K slice, arrive; the last arriver of the tile sums the slices in slice order and runs the epilogue.
+            constexpr int CP = WN + 4;
+            float* mine = smem + (size_t)wave * WM * CP;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[(4 * khalf + (r & 3) + 8 * (r >> 2)) * CP + frag_row] = acc[0][0][r];
+            __syncthreads();
+            const int lt = threadIdx.x, col4 = lt & 7, row = lt >> 3;
+            const int n = n0 + col4 * 4, m = m0 + row;
+            f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * CP + col4 * 4);
+#pragma unroll
+            for (int w2 = 1; w2 < KW; ++w2) v += *reinterpret_cast<const f32x4*>(smem + (size_t)w2 * WM * CP + row * CP + col4 * 4);
+            const __amdgpu_buffer_rsrc_t rs_ws = __builtin_amdgcn_make_buffer_rsrc((void*)p.ws, 0, p.ws_bytes, 0x00020000);
+            const unsigned sb = WM * WN * 4;                                              // bytes between the slices of a tile
+            const unsigned ws0 = (unsigned)(tile - p.main_tiles) * (unsigned)tsplit * sb + (unsigned)(row * WN + col4 * 4) * 4;
+            buf_st16_sc1(rs_ws, ws0 + (unsigned)tslice * sb, v);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // EVERY writing wave drains its slice stores before the arrival
+            __syncthreads();
+            int* s_last = reinterpret_cast<int*>(smem);            // (the slabs were consumed before the barrier above)
+            if (lt == 0) {
+                int* cnt = p.counters + tile;
+                const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *s_last = old == tsplit - 1;
+                if (old == tsplit - 1) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            }
+            __syncthreads();
+            if (*s_last && m < p.M && n < p.Cout) {
+                f32x4 part[8];
+#pragma unroll
+                for (int s2 = 0; s2 < 8; ++s2) part[s2] = buf_ld16_sc1(rs_ws, s2 < tsplit ? ws0 + (unsigned)s2 * sb : OOB);
+                f32x4 sum = part[0];
+#pragma unroll
+                for (int s2 = 1; s2 < 8; ++s2) if (s2 < tsplit) sum += part[s2];
+                f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+                if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+                if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+                sum = __builtin_elementwise_fma(sum, sc, sh);
+                if (p.residual) sum += *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.Cout + n);
+                const int act = p.seg[0].act;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sum[e] = ym_apply_act(sum[e], act);
+                *reinterpret_cast<f32x4*>(p.seg[0].out + (size_t)m * p.Cout + n) = sum;
+            }
+            YM_STAMP(3);
+            return;
+        }
+    }
     wave_tile_finish<TM, TN, KW, WPB>(p, smem, acc, wave, lane, tile_ok, tile_local, kslice, m0, n0);
+    YM_STAMP(3);
 }
 
 template <int TM, int TN, int KW, int WPB>
@@ -428,7 +504,11 @@ int launch_dma(ConvP p, hipStream_t st) {
     p.tiles_n = ym_cdiv(p.Cout, 32 * TN);
     p.fd_tiles_n = FastDiv::make((unsigned)p.tiles_n);
     p.ksplit = 1;
-    const int grid = ym_cdiv(p.tiles_m * p.tiles_n, TPB);
+    int grid = ym_cdiv(p.tiles_m * p.tiles_n, TPB);
+    if (TM * TN == 1 && KW == 4) {                       // (the caller planned the tail: main_tiles / tail_split / tail_ktps / counters)
+        p.main_blocks = p.main_tiles;
+        grid = p.main_tiles + (p.tiles_m * p.tiles_n - p.main_tiles) * p.tail_split;
+    }
     const size_t lds = (size_t)4 * NS * (32 * TM + 32 * TN) * 32 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
