@@ -75,7 +75,10 @@ typedef struct {
     int32_t tile_m, tile_n;  /* workgroup kernel: 128/64 (workgroup tile); wave kernel: 64/32 (per-wave tile) */
     int32_t ksplit;          /* workgroup kernel: K slices across the grid (slices > 1 need workspace) */
     int32_t kwaves;          /* 0 = LDS-tiled workgroup kernel; 1/2/4/8 = wave-private kernel with that many
-                                waves of one workgroup splitting K for each output tile */
+                                waves of one workgroup splitting K for each output tile (tile_m x tile_n = the WAVE's tile, 32 / 64).
+                                With stages = 22 / 23 / 24: the DMA-ring variant (kwaves 1 / 2 / 4, tile 32x32, 64x32 or 32x64, Cin % 32
+                                == 0): every wave streams its operands through a private LDS ring of 2 / 3 / 4 K tiles filled by
+                                global->LDS DMA; with tile 32x32, kwaves 4 it also takes tail_tiles / tail_ksplit (<= 8 slices) */
     int32_t transposed;      /* 0 = convolution.  1 = DATA GRADIENT of that convolution (conv-transpose gather):
                                 `in` is dy NHWC [B][H][W][Cin] (H,W = the forward OUTPUT size, Cin = forward Cout
                                 padded to a multiple of 32), the result is dx [B][Ho][Wo][Cout] (Ho,Wo = forward
@@ -118,7 +121,8 @@ typedef struct {
     const float* bnb_beta;   /* forward pass computed it.  Same sums as the first pass of ym_bn_train_bwd, which                       */
                              /* ym_bn_train_bwd_apply then skips.  Needs ym_conv2d_fuses_bn_stats(desc) == 1.                          */
     int32_t grid_wgs;        /* persistent kernel (stages 4x): workgroups to launch; 0 = as many as the CUs hold (LDS-limited, at most  */
-                             /* 4 per CU), never more than there are work items                                                          */
+                             /* 4 per CU), never more than there are work items.  Wave kernel with DMA rings (kwaves > 0, stages 22-24):  */
+                             /* waves per workgroup, 0 = 4 (1 / 2 with kwaves <= that: single tiles are balanced over the CUs)            */
 } ym_conv_desc;
 
 /* y = act(conv(x, w) * scale + shift + residual), one launch (plus a reduce launch if K is split).

@@ -310,6 +310,11 @@ WAVE_DMA_CASES = [
     (1, 256, 5, 5, 255, 3, 2, 1, 1, False, (32, 32), 4, 22),          # Cout % 4 != 0 -> scalar epilogue, weight rows past Cout
     (1, 32, 6, 6, 64, 1, 1, 0, 1, False, (32, 32), 4, 22),            # ONE K tile for four K waves: three waves hold nothing
     (1, 96, 9, 9, 64, 3, 1, 1, 1, False, (64, 32), 4, 23),            # Cin = 96: a filter tap is three K tiles, ranges cut inside taps
+    # fewer waves per workgroup (ym_conv_desc.grid_wgs = 1 / 2): 13th field
+    (1, 256, 34, 34, 1024, 1, 1, 0, 1, True, (32, 32), 1, 22, 1),     # layer3's conv3: one wave = one tile = one workgroup
+    (1, 256, 34, 34, 1024, 1, 1, 0, 1, True, (32, 32), 1, 23, 2),
+    (2, 128, 19, 19, 128, 3, 2, 1, 1, False, (32, 64), 2, 22, 2),
+    (1, 256, 5, 5, 255, 3, 2, 1, 0, False, (64, 32), 1, 22, 1),
 ]
 
 
@@ -318,7 +323,8 @@ def test_conv_wave_dma_ring_kernel_parity(case):
     """conv_wdma_f32 (round 4): a wave owns a tile and a share of K, its operands stream through a wave-private LDS ring filled
     by global->LDS DMA, the K waves of a tile combine through LDS in a fixed order.  fp64 reference; bit-reproducible run to run
     (a ring hazard -- a stage re-filled while its fragments are still being read -- would show as run-to-run differences)."""
-    b, cin, h, w, cout, k, stride, pad, act, use_res, tile, kwaves, stages = case
+    b, cin, h, w, cout, k, stride, pad, act, use_res, tile, kwaves, stages = case[:13]
+    wpb = case[13] if len(case) > 13 else 0
     g = torch.Generator().manual_seed(hash(case) % 1000)
     x = torch.randn(b, cin, h, w, generator=g)
     wt = torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)
@@ -326,12 +332,12 @@ def test_conv_wave_dma_ring_kernel_parity(case):
     shift = torch.randn(cout, generator=g) * 0.1
     ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
     res = torch.randn(b, cout, ho, wo, generator=g) if use_res else None
-    got = run_conv(x, wt, scale, shift, res, stride, pad, act, tile, 0, kwaves, stages)
+    got = run_conv(x, wt, scale, shift, res, stride, pad, act, tile, 0, kwaves, stages, grid_wgs=wpb)
     want = ref_conv(x, wt, scale, shift, res, stride, pad, act)
     assert not torch.isnan(got).any()
     torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5)
     for _ in range(3):
-        again = run_conv(x, wt, scale, shift, res, stride, pad, act, tile, 0, kwaves, stages, repeat=20)
+        again = run_conv(x, wt, scale, shift, res, stride, pad, act, tile, 0, kwaves, stages, repeat=20, grid_wgs=wpb)
         assert torch.equal(got, again)
 
 

@@ -271,11 +271,13 @@ def _chained_net(golden_dir):
     return net.to(DEV), cfg, seed
 
 
-def _single_path(net, cfg, imgs, head=None):
+def _single_path(net, cfg, imgs, head=None, mode='latency'):
     """forward -> nms -> after_nms(480x640), one request at a time (the path of rounds 1-2): per image the four network outputs and
-    the four `after_nms` results."""
+    the four `after_nms` results.  `mode`: which tuned entries the engine reads (the slots of a pipeline with requests in flight
+    read the throughput-tuned ones: a different split of a K sum is a different rounding, so the reference runs the same plan)."""
+    from yolact_minimal_amd.engine import InferEngine
     from yolact_minimal_amd.utils.output_utils import nms_batch, after_nms_batch
-    eng = net._engine(imgs[0])
+    eng = InferEngine(net, imgs[0].shape[0], imgs[0].shape[2], imgs[0].shape[3], imgs[0].device, mode=mode)
     anchors = torch.tensor(net.anchors, dtype=torch.float32).reshape(-1, 4).to(DEV)
     fwd, post = [], []
     for img in imgs:
@@ -315,8 +317,12 @@ def test_headline_pipeline_matches_the_single_request_path_at_full_size(golden_d
     order = [(3 * i + i // 4) % 4 for i in range(n_req)]          # slot s = i % depth sees a different image every time round
     head = [t.to(dev).expand(batch, *t.shape[1:]).contiguous()
             for t in synth_head_outputs(len(net.anchors) // 4, num_classes=cfg.num_classes, proto_hw=136, seed=1)]
-    want_fwd, want_own = _single_path(net, cfg, imgs)
-    _, want_head = _single_path(net, cfg, imgs[:1], head)
+    want_fwd, want_own = _single_path(net, cfg, imgs, mode='throughput')
+    _, want_head = _single_path(net, cfg, imgs[:1], head, mode='throughput')
+    # ... and the throughput plan against the latency plan (other tile / split choices for some layers): the same network to 1e-5
+    lat_fwd, _ = _single_path(net, cfg, imgs[:1])
+    for a, b in zip(want_fwd[0], lat_fwd[0]):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5 * max(1.0, float(b.abs().max())))
     n_det = sum(int(r[0].shape[0]) for r in want_own[0] if r[0] is not None)
     assert n_det >= 50 * batch, 'the chained weights must give image-dependent detections'
 

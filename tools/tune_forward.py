@@ -26,12 +26,22 @@ ap.add_argument('--out', default='')
 ap.add_argument('--max-m', type=int, default=20000)
 ap.add_argument('--slack', type=float, default=1.2)
 ap.add_argument('--replays', type=int, default=40)
+ap.add_argument('--inflight', type=int, default=1, help='> 1: optimise the img/s of a RequestPipeline with that many requests in flight; winners are written as <sig>_tp')
 args = ap.parse_args()
 dev = torch.device('cuda:0')
+R3 = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuned_r03.json')))      # the table at the end of round 3
 net, cfg = bench.build_net(args.cfg, 544, dev)
 img = torch.randn(args.batch, 3, 544, 544, device=dev)
-eng = net._engine(img)
-eng.run(img)
+pipe = None
+if args.inflight > 1:
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+    from yolact_minimal_amd.pipeline import RequestPipeline
+    pipe = RequestPipeline(net, cfg, 544, 544, dev, depth=args.inflight, with_post=False, batch=args.batch, return_outputs=False)
+    pipe.warm_up(img)
+    eng = pipe.engines[0]
+else:
+    eng = net._engine(img)
+    eng.run(img)
 torch.cuda.synchronize()
 big = torch.empty(1 << 28, device=dev, dtype=torch.uint8)
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -58,6 +68,23 @@ def launch_time(d, iters=20):
 
 
 def forward_ms():
+    if pipe is not None:              # ms per request with `inflight` requests overlapped
+        import time
+        pipe.warm_up(img)
+        best = 1e30
+        n = args.replays * args.inflight
+        for _ in range(2):
+            for _ in range(2 * args.inflight):
+                pipe.submit(img)
+            pipe.drain()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                pipe.submit(img)
+            pipe.drain()
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) / n * 1e3)
+        return best
     eng.run(img)                      # (re)captures the graph after a retune
     torch.cuda.synchronize()
     best = 1e30
@@ -76,10 +103,11 @@ def get(c):
 
 
 def put(sig, v):
-    for c in eng.convs:
-        if c.sig == sig:
-            c.tile, c.ksplit, c.kwaves, c.stages, c.tail, c.grid_wgs = (v[0], v[1]), v[2], v[3], v[4], (v[5], v[6]), v[7]
-    eng.retune()
+    for e in (pipe.engines if pipe is not None else [eng]):
+        for c in e.convs:
+            if c.sig == sig:
+                c.tile, c.ksplit, c.kwaves, c.stages, c.tail, c.grid_wgs = (v[0], v[1]), v[2], v[3], v[4], (v[5], v[6]), v[7]
+        e.retune()
 
 
 groups = {}
@@ -107,6 +135,8 @@ for _, sig, t0 in sorted(order):
             if kwv > d.k_pad // 32:
                 continue
             vs = [[tm, tn, 1, kwv, 22, 0, 0, 0]]
+            if kwv < 4:                                   # fewer waves per workgroup: single tiles are balanced over the CUs
+                vs += [[tm, tn, 1, kwv, 22, 0, 0, wpb] for wpb in (1, 2) if wpb >= kwv]
             tiles = -(-M // 32) * -(-d.Cout // 32)
             if (tm, tn, kwv) == (32, 32, 4) and tiles > 256 and d.nseg == 1 and d.tile_counters:
                 # tail split: the tiles past the last full round of 256 CUs are computed as K slices in the CUs' second slots
@@ -120,10 +150,15 @@ for _, sig, t0 in sorted(order):
                 d.tile_m, d.tile_n, d.ksplit, d.kwaves, d.stages, d.tail_tiles, d.tail_ksplit, d.grid_wgs = keep
                 if t is not None:
                     cands.append((t, v))
+    if pipe is not None:              # the round-3 choice (LDS-tiled kernels, K split over workgroups) and the latency entry are candidates too
+        for alt in (E.tuned_table().get(sig), R3.get(sig)):
+            if alt:
+                cands.append((0.0, list(alt[:7]) + [alt[7] if len(alt) > 7 else 0]))
     cands.sort()
     tried = 0
+    t_ref = min([t0] + [t for t, _ in cands if t > 0])
     for t, v in cands:
-        if v == cur or t > args.slack * min(t0, cands[0][0]) or tried >= 4:
+        if v == cur or t > args.slack * t_ref or tried >= (7 if pipe is not None else 5):
             continue
         tried += 1
         put(sig, v)
@@ -132,11 +167,13 @@ for _, sig, t0 in sorted(order):
         if ms < cur_ms * 0.998:
             ms2 = forward_ms()
             if max(ms, ms2) < cur_ms * 0.998:
-                cur_ms, cur, kept[sig], tag = max(ms, ms2), v, v[:7], '  <-- kept'
-        print(f'{sig:42s} x{len(cs):2d} launch {t0:6.2f} -> {t:6.2f} us {v[:5]} forward {ms:.4f} ms{tag}', flush=True)
+                cur_ms, cur, kept[sig], tag = max(ms, ms2), v, (v if v[7] else v[:7]), '  <-- kept'
+        print(f'{sig:42s} x{len(cs):2d} launch {t0:6.2f} -> {t:6.2f} us {v} forward {ms:.4f} ms{tag}', flush=True)
         put(sig, cur)
 final = forward_ms()
 print(f'final: forward {base_ms:.4f} -> {final:.4f} ms; {len(kept)} entries change', flush=True)
+if pipe is not None:
+    kept = {k + '_tp': v for k, v in kept.items()}
 if args.out:
     json.dump(kept, open(args.out, 'w'), indent=0, sort_keys=True)
 if args.write:

@@ -153,7 +153,7 @@ __device__ __forceinline__ void epilogue_store(const ConvP& p, int m, int n, flo
 }  // namespace ymk
 
 // conv_wave.hip: wave-private kernels (stages 22 / 23 / 24: the DMA-ring variant); returns YM_OK / YM_EINVAL (unsupported variant)
-int ym_launch_conv_wave(const ymk::ConvP& p, int tm, int tn, int kwaves, int stages, hipStream_t st);
+int ym_launch_conv_wave(const ymk::ConvP& p, int tm, int tn, int kwaves, int stages, int waves_per_block, hipStream_t st);
 // conv_persist.hip: persistent direct-to-LDS kernel (ring of `ns` K tiles, `grid` workgroups walk p.total_items work items);
 // mode 0 = convolution, 2 = data gradient; launches with fused BatchNorm sums are not covered.  YM_EINVAL: no such variant.
 // defer: the un-split item's stores are issued under the next item's MFMAs (costs a dedicated 16 KB accumulator tile in LDS).

@@ -850,7 +850,7 @@ int make_plan(const ym_conv_desc* d, Plan* pl) {
         pl->ksplit = 1; pl->kt_per_split = pl->nkt;
         // tail split of the wave-private DMA-ring kernel (conv_wave.hip): 32x32 tile with four K waves, plain NHWC output, counters
         if (d->tail_tiles > 0 && d->tail_ksplit > 1 && d->stages >= 22 && d->stages <= 24 && bm == 32 && bn == 32 && d->kwaves == 4 &&
-            d->tile_counters && vec_epilogue(d)) {
+            (d->grid_wgs == 0 || d->grid_wgs == 4) && d->tile_counters && vec_epilogue(d)) {
             YM_REQUIRE(d->tail_tiles <= pl->tiles_m * pl->tiles_n, "conv(wave): tail_tiles %d > %d output tiles", d->tail_tiles, pl->tiles_m * pl->tiles_n);
             int ts = d->tail_ksplit > pl->nkt ? pl->nkt : d->tail_ksplit;
             if (ts > 8) ts = 8;                                    // (the last arriver gathers up to 8 slices at once)
@@ -1028,7 +1028,7 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
         const bool dma = d->stages >= 22 && d->stages <= 24;
         YM_REQUIRE(!dma || (d->Cin % 32 == 0 && d->nlevels == 0 && !d->transposed && (size_t)pl.M * d->Cout * 4 < 0xFFFFFFF0ull),
                    "conv(wave, DMA ring): needs Cin %% 32 == 0, one input size, a forward convolution");
-        return ym_launch_conv_wave(p, pl.bm, pl.bn, d->kwaves, d->stages, st);
+        return ym_launch_conv_wave(p, pl.bm, pl.bn, d->kwaves, d->stages, d->grid_wgs, st);
     }
     const int grid = pl.grid();
     p.total_items = grid;

@@ -34,6 +34,20 @@ __device__ __forceinline__ void wave_tile_finish(const ConvP& p, float* slabs, f
     constexpr int WM = 32 * TM, WN = 32 * TN;
     constexpr int CP = WN + 4;               // LDS pitch of a staged tile (floats)
     const int frag_row = lane & 31, khalf = lane >> 5;
+    // the residual rows of this lane are requested before the tile is staged (a wave with a tile of its own makes up to four
+    // passes over it: four dependent global loads took 3.3 us of a 14.5 us launch, tools/chain_trace_rt.py)
+    constexpr int C4_ = WN / 4, LANES_ = KW * 64, NPASS = (WM * C4_ + LANES_ - 1) / LANES_;
+    f32x4 pre_res[NPASS];
+    const bool pre = p.vec && p.residual != nullptr && tile_ok;
+    if (pre) {
+        const int lt_ = kslice * 64 + lane, col4_ = lt_ % C4_, row0_ = lt_ / C4_;
+        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, (unsigned)((size_t)p.M * p.Cout * 4), 0x00020000);
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) {
+            const int m = m0 + row0_ + k * (LANES_ / C4_), n = n0 + col4_ * 4;
+            pre_res[k] = buf_ld16(rs_res, (row0_ + k * (LANES_ / C4_) < WM && m < p.M && n < p.Cout) ? (unsigned)(((size_t)m * p.Cout + n) * 4) : OOB);
+        }
+    }
     float* mine = slabs + (size_t)wave * WM * CP;
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -56,14 +70,16 @@ __device__ __forceinline__ void wave_tile_finish(const ConvP& p, float* slabs, f
             if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
             if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
             const int act = p.seg[0].act;
-            for (int row = row0; row < WM; row += LANES / C4) {
+#pragma unroll
+            for (int k = 0; k < NPASS; ++k) {
+                const int row = row0 + k * (LANES / C4);
                 const int m = m0 + row;
-                if (m >= p.M) break;
+                if (row >= WM || m >= p.M) break;
                 f32x4 v = *reinterpret_cast<const f32x4*>(slab0 + row * CP + col4 * 4);
 #pragma unroll
                 for (int s = 1; s < KW; ++s) v += *reinterpret_cast<const f32x4*>(slab0 + (size_t)s * WM * CP + row * CP + col4 * 4);
                 v = __builtin_elementwise_fma(v, sc, sh);
-                if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.Cout + n);
+                if (p.residual) v += pre_res[k];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = ym_apply_act(v[e], act);
                 *reinterpret_cast<f32x4*>(p.seg[0].out + (size_t)m * p.Cout + n) = v;
@@ -222,9 +238,13 @@ __global__ __launch_bounds__(WPB * 64) void conv_wave_f32(const ConvP p) {
 // Why (tools/chain_trace_rt.py, batch 1): a layer3 conv split 3-6 ways over workgroups spends 6-7.4 us of every launch in the
 // K-slice exchange of its last arriver (publish through the fabric, arrival atomic, read everything back) behind a K loop of
 // 8-16 us; with the K split INSIDE the workgroup the exchange is an LDS hand-off.
-template <int TM, int TN, int KW, int NS>
-__global__ __launch_bounds__(256) void conv_wdma_f32(const ConvP p) {
-    constexpr int WPB = 4, TPB = WPB / KW;   // waves per block, output tiles per block
+// WPB: waves per workgroup (>= KW).  Tiles whose waves share nothing (KW == 1) can be launched as one- or two-wave workgroups: the
+// dispatcher then balances single tiles over the CUs instead of groups of four (1184 tiles of layer3's conv3 = 296 four-wave
+// workgroups = two of them on 40 of the 256 CUs).
+template <int TM, int TN, int KW, int NS, int WPB = 4>
+__global__ __launch_bounds__(WPB * 64) void conv_wdma_f32(const ConvP p) {
+    static_assert(WPB % KW == 0 && WPB <= 4, "the K waves of a tile share a workgroup");
+    constexpr int TPB = WPB / KW;            // output tiles per block
     constexpr int WM = 32 * TM, WN = 32 * TN;
     constexpr int AR = 4 * TM, BR = 4 * TN;  // DMA instructions per K tile: 8 rows of 128 B each
     constexpr int RP = 32;                   // LDS floats per tile row (unpadded: the DMA places lane l's 16 bytes at base + 16 l)
@@ -244,7 +264,7 @@ __global__ __launch_bounds__(256) void conv_wdma_f32(const ConvP p) {
     // The LAST tail_tiles tiles are therefore computed as tail_split K slices each, by workgroups that fill the second slot of
     // every CU with a fraction of a tile; their partial tiles meet through the workspace (sc1 stores, arrival counter, the last
     // arriver sums in slice order and runs the epilogue: conv_igemm_f32's exchange) while the whole tiles are still in their K loops.
-    constexpr bool TAIL = TM * TN == 1 && KW == 4;
+    constexpr bool TAIL = TM * TN == 1 && KW == 4 && WPB == 4;
     const bool in_tail = TAIL && (int)blockIdx.x >= p.main_blocks;
     int tile, tslice = 0, tsplit = 1;
     if (in_tail) {
@@ -497,45 +517,47 @@ int dispatch_kw(const ConvP& p, int kwaves, hipStream_t st) {
     }
 }
 
-template <int TM, int TN, int KW, int NS>
+template <int TM, int TN, int KW, int NS, int WPB>
 int launch_dma(ConvP p, hipStream_t st) {
-    constexpr int TPB = 4 / KW;
+    constexpr int TPB = WPB / KW;
     p.tiles_m = ym_cdiv(p.M, 32 * TM);
     p.tiles_n = ym_cdiv(p.Cout, 32 * TN);
     p.fd_tiles_n = FastDiv::make((unsigned)p.tiles_n);
     p.ksplit = 1;
     int grid = ym_cdiv(p.tiles_m * p.tiles_n, TPB);
-    if (TM * TN == 1 && KW == 4) {                       // (the caller planned the tail: main_tiles / tail_split / tail_ktps / counters)
+    if (TM * TN == 1 && KW == 4 && WPB == 4) {           // (the caller planned the tail: main_tiles / tail_split / tail_ktps / counters)
         p.main_blocks = p.main_tiles;
         grid = p.main_tiles + (p.tiles_m * p.tiles_n - p.main_tiles) * p.tail_split;
     }
-    const size_t lds = (size_t)4 * NS * (32 * TM + 32 * TN) * 32 * sizeof(float);
+    const size_t lds = (size_t)WPB * NS * (32 * TM + 32 * TN) * 32 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wdma_f32<TM, TN, KW, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wdma_f32<TM, TN, KW, NS, WPB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_wdma_f32<TM, TN, KW, NS>), dim3(grid), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv_wdma_f32<TM, TN, KW, NS, WPB>), dim3(grid), dim3(WPB * 64), lds, st, p);
     return ym_check_launch("conv_wdma_f32");
 }
 
 template <int TM, int TN>
-int dispatch_dma(const ConvP& p, int kwaves, int ns, hipStream_t st) {
-#define YM_DMA_CASE(KW_, NS_) if (kwaves == KW_ && ns == NS_) return launch_dma<TM, TN, KW_, NS_>(p, st)
-    YM_DMA_CASE(1, 2); YM_DMA_CASE(1, 3); YM_DMA_CASE(2, 2); YM_DMA_CASE(2, 3); YM_DMA_CASE(4, 2); YM_DMA_CASE(4, 3);
-    if constexpr (TM * TN == 1) { YM_DMA_CASE(1, 4); YM_DMA_CASE(2, 4); YM_DMA_CASE(4, 4); }
+int dispatch_dma(const ConvP& p, int kwaves, int ns, int wpb, hipStream_t st) {
+    if (wpb <= 0) wpb = 4;
+#define YM_DMA_CASE(KW_, NS_, WPB_) if (kwaves == KW_ && ns == NS_ && wpb == WPB_) return launch_dma<TM, TN, KW_, NS_, WPB_>(p, st)
+    YM_DMA_CASE(1, 2, 4); YM_DMA_CASE(1, 3, 4); YM_DMA_CASE(2, 2, 4); YM_DMA_CASE(2, 3, 4); YM_DMA_CASE(4, 2, 4); YM_DMA_CASE(4, 3, 4);
+    YM_DMA_CASE(1, 2, 1); YM_DMA_CASE(1, 3, 1); YM_DMA_CASE(1, 2, 2); YM_DMA_CASE(1, 3, 2); YM_DMA_CASE(2, 2, 2); YM_DMA_CASE(2, 3, 2);
+    if constexpr (TM * TN == 1) { YM_DMA_CASE(1, 4, 4); YM_DMA_CASE(2, 4, 4); YM_DMA_CASE(4, 4, 4); YM_DMA_CASE(1, 4, 1); YM_DMA_CASE(1, 4, 2); }
 #undef YM_DMA_CASE
-    ym_set_error("conv(wave, DMA ring): kwaves %d with a ring of %d is not built for a %dx%d wave tile", kwaves, ns, 32 * TM, 32 * TN);
+    ym_set_error("conv(wave, DMA ring): kwaves %d, ring of %d, %d waves per workgroup is not built for a %dx%d wave tile", kwaves, ns, wpb, 32 * TM, 32 * TN);
     return YM_EINVAL;
 }
 
 }  // namespace
 
-int ym_launch_conv_wave(const ConvP& p, int tm, int tn, int kwaves, int stages, hipStream_t st) {
+int ym_launch_conv_wave(const ConvP& p, int tm, int tn, int kwaves, int stages, int wpb, hipStream_t st) {
     if (stages >= 22 && stages <= 24) {          // wave-private DMA rings of 2 / 3 / 4 K tiles (Cin % 32 == 0, one input size)
-        if (tm == 32 && tn == 32) return dispatch_dma<1, 1>(p, kwaves, stages - 20, st);
-        if (tm == 64 && tn == 32) return dispatch_dma<2, 1>(p, kwaves, stages - 20, st);
-        if (tm == 32 && tn == 64) return dispatch_dma<1, 2>(p, kwaves, stages - 20, st);
+        if (tm == 32 && tn == 32) return dispatch_dma<1, 1>(p, kwaves, stages - 20, wpb, st);
+        if (tm == 64 && tn == 32) return dispatch_dma<2, 1>(p, kwaves, stages - 20, wpb, st);
+        if (tm == 32 && tn == 64) return dispatch_dma<1, 2>(p, kwaves, stages - 20, wpb, st);
         ym_set_error("conv(wave, DMA ring): tile must be 32x32, 64x32 or 32x64, got %dx%d", tm, tn);
         return YM_EINVAL;
     }

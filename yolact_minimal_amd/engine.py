@@ -61,6 +61,22 @@ def tuned_table():
     return _tuned
 
 
+_build_mode = ['latency']
+
+
+def _entry(sig):
+    """Tuned entry of a conv shape for the engine being built.  'latency' (one request at a time: the default) reads `sig`;
+    'throughput' (the slots of a RequestPipeline with several requests in flight) reads `sig + '_tp'` first: choices that spread a
+    launch over every CU (tail splits, one-wave workgroups) shorten a lone request and cost throughput when other requests want
+    those CUs -- tools/tune_forward.py --inflight N measures them on the pipeline's own img/s."""
+    t = tuned_table()
+    if _build_mode[0] == 'throughput':
+        hit = t.get(sig + '_tp')
+        if hit is not None:
+            return hit
+    return t.get(sig)
+
+
 class _LinearAsConv:
     """nn.Linear viewed as a 1x1 convolution of the [tokens][C] (= NHWC) tensor."""
 
@@ -156,7 +172,7 @@ class _Conv:
         self.out_hw = (ho, wo)
         self.flops = 2.0 * b * ho * wo * self.cout * self.kh * self.kw * self.cin
         self.sig = f'M{b * ho * wo}_N{self.cout}_C{cin}_k{self.kh}_s{self.stride}_seg{len(segs)}_r{int(residual is not None)}'
-        hit = tuned_table().get(self.sig)
+        hit = _entry(self.sig)
         if hit and self.tile == (0, 0) and self.ksplit == 0 and self.kwaves == 0:
             self.tile, self.ksplit, self.kwaves = (hit[0], hit[1]), hit[2], (hit[3] if len(hit) > 3 else 0)
             self.stages = hit[4] if len(hit) > 4 else 0
@@ -181,7 +197,7 @@ class _Conv:
         self.mma = mma if ok else 0
         hit = tuned_table().get(self.tuned_key()) if self.mma else None
         if hit is None:
-            hit = tuned_table().get(self.sig)          # (no entry for this pipe: the f32 choice, incl. its wave kernel for tiny layers)
+            hit = _entry(self.sig)          # (no entry for this pipe: the f32 choice, incl. its wave kernel for tiny layers)
         d.mma = self.mma
         if hit and os.environ.get('YM_NO_TUNED', '0') != '1':     # each matrix pipe has its own measured tile / split-K / tail choice
             self.tile, self.ksplit, self.kwaves = (hit[0], hit[1]), hit[2], (hit[3] if len(hit) > 3 else 0)
@@ -227,7 +243,7 @@ def _bind_pyramid(layer, pyr, batch, shapes, segs):
     layer.out_hw = shapes[0]
     layer.flops = 2.0 * rows * layer.cout * layer.kh * layer.kw * layer.cin
     layer.sig = f'M{rows}_N{layer.cout}_C{cin}_k{layer.kh}_s1_seg{len(segs)}_r0_L{len(shapes)}'
-    hit = tuned_table().get(layer.sig)
+    hit = _entry(layer.sig)
     if hit:
         layer.tile, layer.ksplit, layer.kwaves = (hit[0], hit[1]), hit[2], 0
         layer.stages = 0
@@ -238,8 +254,9 @@ def _bind_pyramid(layer, pyr, batch, shapes, segs):
 
 
 class InferEngine:
-    def __init__(self, net, batch, height, width, device, use_graph=None):
+    def __init__(self, net, batch, height, width, device, use_graph=None, mode='latency'):
         self.net = net
+        self.mode = mode                   # which tuned entries the plan reads: see _entry
         self.device = device
         self.B, self.H, self.W = batch, height, width
         self.num_classes = net.cfg.num_classes
@@ -261,8 +278,12 @@ class InferEngine:
         self._weights_epoch = -1
         self._bufs = []
         hip.lib()              # fail loudly here if the .so is missing
-        with torch.cuda.device(device):
-            self._build()
+        prev, _build_mode[0] = _build_mode[0], mode
+        try:
+            with torch.cuda.device(device):
+                self._build()
+        finally:
+            _build_mode[0] = prev
 
     # ---- construction ------------------------------------------------------------------------
     def _buf(self, *shape):
@@ -522,8 +543,12 @@ class InferEngine:
 
     def set_mma(self, mma):
         """Switch every eligible conv of the plan between the f32 MFMA (0) and the split-bf16 modes (3 / 6)."""
-        for c in self.convs:
-            c.apply_mma(mma)
+        prev, _build_mode[0] = _build_mode[0], self.mode
+        try:
+            for c in self.convs:
+                c.apply_mma(mma)
+        finally:
+            _build_mode[0] = prev
         self.retune()
 
     def autotune(self, iters=10, verbose=False, mma=0, concurrent=False):

@@ -60,7 +60,8 @@ class RequestPipeline:
             warnings.warn(f'RequestPipeline(depth={depth}): GPU_MAX_HW_QUEUES={os.environ.get("GPU_MAX_HW_QUEUES", "unset (4)")} < '
                           f'{depth + 1}; HIP streams that share a hardware queue do not overlap -- export GPU_MAX_HW_QUEUES=8 before the '
                           f'first HIP call', RuntimeWarning, stacklevel=2)
-        self.engines = [InferEngine(net, batch, height, width, device) for _ in range(depth)]
+        # slots of a pipeline with requests in flight read the throughput-tuned entries of the table (engine._entry)
+        self.engines = [InferEngine(net, batch, height, width, device, mode='throughput' if depth > 1 else 'latency') for _ in range(depth)]
         self.streams = _stream_set(device, depth)
         self.counts_host = [torch.zeros(batch, dtype=torch.int32).pin_memory() for _ in range(depth)]
         self.events = [torch.cuda.Event() for _ in range(depth)]
