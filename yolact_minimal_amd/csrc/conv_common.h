@@ -80,6 +80,18 @@ struct ConvP {
     FastDiv fd_ksplit, fd_tail, fd_tiles_n, fd_howo, fd_wo, fd_cin, fd_kw;
     int nlev;          // pyramid input (ym_conv_desc.nlevels): per level its size, first GEMM row, first output pixel of an image
     int lev_h[5], lev_w[5], lev_m[6], lev_pix[6];
+    // Stride-2 DATA GRADIENT by output-pixel parity class (conv_mfma.hip, MODE 2): dx pixel (ih, iw) only receives the filter taps with
+    // kh = (ih + pad) mod 2 (mod 2), kw likewise; gathering all KH x KW taps for every pixel multiplies zeros in 3 of 4 MFMAs.  The
+    // GEMM rows are therefore grouped by class (c = 2 (ih & 1) + (iw & 1); M tile t holds rows of class t & 3, every class padded to
+    // the same number of whole tiles, M = the padded total) and a tile walks its class's taps only: 1 + 2 + 2 + 4 taps instead of 4 x 9 for a 3x3, 1 + 0 + 0 + 0 instead of 4 for 1x1.
+    int cls;                       // 1 = class mode
+    int M_pix;                     // real number of dx pixels (p.M counts the padded class rows)
+    int cls_tile0[5];              // (tiles of class c if the classes were laid out one after the other; informational)
+    int cls_rows[4];               // dx pixels of class c = B * cls_h[c] * cls_w[c]
+    int cls_w[4];                  // pixels per image row of the class
+    FastDiv cls_fd_hw[4], cls_fd_w[4];
+    int cls_kh0[4], cls_kw0[4], cls_nkw[4];   // first tap (then every second one), taps per filter row
+    int cls_nkt[4], cls_ktps[4], cls_tail_ktps[4];   // K tiles of the class, per K slice of a main / tail tile
     int m_fastest;     // tile order inside an XCD's chunk: 0 = n fastest (neighbours share the input panel), 1 = m fastest (neighbours
                        // share the WEIGHT panel: chosen when the weights are the larger operand, so that the 8 XCD L2s partition them)
     FastDiv fd_tiles_m;

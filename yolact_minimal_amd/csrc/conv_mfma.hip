@@ -87,8 +87,51 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
     else { tile_m = (int)p.fd_tiles_n.div((unsigned)id); tile_n = id - tile_m * p.tiles_n; }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    const int kt_beg = ks * ktps;
-    const int kt_end = min(p.nkt, kt_beg + ktps);
+    // stride-2 data gradient: the parity class of this tile's rows (conv_common.h) -- its first GEMM row, its taps, its K range
+    int cls = 0, cls_base = 0, c_kh0 = 0, c_kw0 = 0, c_step = 1, c_nkw = 1;
+    bool cls_on = false;
+    int kt_beg = ks * ktps, kt_end = min(p.nkt, kt_beg + ktps);
+    if constexpr (MODE == 2) {
+        if (p.cls) {
+            cls_on = true;
+            // consecutive M tiles cycle through the four classes (every class is padded to the same number of tiles): an XCD's chunk
+            // of the tile space then holds every class in equal shares -- class by class, the two XCDs that owned class 0 did ALL the
+            // work of a 1x1 stride-2 data gradient (only that class has a tap) and the launch was no faster than before
+            cls = tile_m & 3;
+            cls_base = m0 - (tile_m >> 2) * BM;            // local row = m - cls_base = (tile_m >> 2) * BM + (m - m0)
+            c_kh0 = p.cls_kh0[cls]; c_kw0 = p.cls_kw0[cls]; c_nkw = p.cls_nkw[cls]; c_step = 2;
+            const int per = (int)blockIdx.x < p.main_blocks ? p.cls_ktps[cls] : p.cls_tail_ktps[cls];
+            kt_beg = ks * per;
+            kt_end = min(p.cls_nkt[cls], kt_beg + per);
+        }
+    }
+    // GEMM row -> dx pixel (b, oh, ow); false for the padding rows of a class / rows past M
+    auto row_coords = [&](int m, int& b, int& oh, int& ow) __attribute__((always_inline)) -> bool {
+        if (MODE == 2 && cls_on) {
+            const int local = m - cls_base;
+            if (local >= p.cls_rows[cls]) return false;
+            unsigned ub, urem, ui, uj;
+            p.cls_fd_hw[cls].divmod((unsigned)local, ub, urem);
+            p.cls_fd_w[cls].divmod(urem, ui, uj);
+            b = (int)ub; oh = 2 * (int)ui + (cls >> 1); ow = 2 * (int)uj + (cls & 1);
+            return true;
+        }
+        if (m >= p.M) return false;
+        unsigned ub, urem, uoh, uow;
+        p.fd_howo.divmod((unsigned)m, ub, urem);
+        p.fd_wo.divmod(urem, uoh, uow);
+        b = (int)ub; oh = (int)uoh; ow = (int)uow;
+        return true;
+    };
+    // tile row -> row of the output / residual / BatchNorm tensors ([pixel][Cout]); -1: a row that produces nothing
+    auto out_row = [&](int row) __attribute__((always_inline)) -> int {
+        const int m = m0 + row;
+        if (MODE == 2 && cls_on) {
+            int b, oh, ow;
+            return row_coords(m, b, oh, ow) ? (b * p.Ho + oh) * p.Wo + ow : -1;
+        }
+        return m < p.M ? m : -1;
+    };
 
     // ---- per-thread staging coordinates -------------------------------------------------------
     const int c4 = DL ? ((tid & 7) ^ ((tid >> 4) & 7)) : (tid & 7);   // which float4 of the 32-float K row (DL: swizzled)
@@ -99,6 +142,19 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
         const int m = m0 + rbase + 32 * i;
+        if constexpr (MODE == 2) {
+            int b, oh, ow;
+            if (row_coords(m, b, oh, ow)) {
+                a_ih0[i] = oh + p.pad;
+                a_iw0[i] = ow + p.pad;
+                a_pix[i] = b * p.H;
+            } else {
+                a_ih0[i] = -(1 << 20);
+                a_iw0[i] = -(1 << 20);
+                a_pix[i] = 0;
+            }
+            continue;
+        }
         if (m < p.M) {
             if constexpr (RG) {                          // which level does this GEMM row belong to?
                 int base = 0, h = p.lev_h[0], w = p.lev_w[0];
@@ -146,8 +202,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
     if (MODE == 0 || MODE == 2) {
         unsigned tap, uc0, ukh, ukw;
         p.fd_cin.divmod((unsigned)(kt_beg * BK), tap, uc0);
-        p.fd_kw.divmod(tap, ukh, ukw);
-        c0 = (int)uc0; kh = (int)ukh; kw = (int)ukw;
+        c0 = (int)uc0;
+        if (MODE == 2 && cls_on) {                 // the class's taps: kh0, kh0 + 2, ... x kw0, kw0 + 2, ...
+            const int a = (int)tap / c_nkw;
+            kh = c_kh0 + 2 * a; kw = c_kw0 + 2 * ((int)tap - a * c_nkw);
+        } else {
+            p.fd_kw.divmod(tap, ukh, ukw);
+            kh = (int)ukh; kw = (int)ukw;
+        }
     }
 
     // One K tile of both operands: `sink_a(i, lane_offset, block_offset)` / `sink_b(...)` receive the source of this lane's 16
@@ -159,6 +221,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
     // (the counted vmcnt waits need an unconditional load count) and never consumed — a buffer load cannot fault.
     unsigned a_off[AR];
     bool tap_dirty = true;
+    int w_koff = 0;              // MODE 2: byte offset of the K tile inside a weight row
     auto gather_tile = [&](int kt, auto&& sink_a, auto&& sink_b) __attribute__((always_inline)) {
         if (MODE == 0 || MODE == 2) {
             if (tap_dirty) {                                  // block-uniform
@@ -181,10 +244,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
             }
 #pragma unroll
             for (int i = 0; i < AR; ++i) sink_a(i, a_off[i], c0 * 4);
+            if constexpr (MODE == 2) w_koff = ((kh * p.KW + kw) * p.Cin + c0) * 4;      // (a class skips taps: the filter row is not walked contiguously)
             c0 += BK;
             if (c0 >= p.Cin) {
                 c0 = 0;
-                if (++kw == p.KW) { kw = 0; ++kh; }
+                if constexpr (MODE == 2) { kw += c_step; if (kw >= p.KW) { kw = c_kw0; kh += c_step; } }
+                else if (++kw == p.KW) { kw = 0; ++kh; }
                 tap_dirty = true;
             }
         } else {
@@ -200,7 +265,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < BR; ++i) sink_b(i, wrow[i], kt * BK * 4);
+        for (int i = 0; i < BR; ++i) sink_b(i, wrow[i], MODE == 2 ? w_koff : kt * BK * 4);
     };
     constexpr int NSET = (NS == 3 && !DL) ? 2 : 1;
     f32x4 rA[NSET][DL ? 1 : AR], rB[NSET][DL ? 1 : BR];
@@ -350,11 +415,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
         }
         if (PRE_RES) {
             const __amdgpu_buffer_rsrc_t rs_res =
-                __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, p.residual ? (unsigned)((size_t)p.M * p.Cout * 4) : 0u, 0x00020000);
+                __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, p.residual ? (unsigned)((size_t)p.M_pix * p.Cout * 4) : 0u, 0x00020000);
 #pragma unroll
             for (int k = 0; k < ENR; ++k) {
-                const int m = m0 + erow0 + k * ERPP;
-                pre_res[k] = buf_ld16(rs_res, (m < p.M && en < p.Cout) ? (unsigned)(((size_t)m * p.Cout + en) * 4) : OOB);
+                const int m = out_row(erow0 + k * ERPP);
+                pre_res[k] = buf_ld16(rs_res, (m >= 0 && en < p.Cout) ? (unsigned)(((size_t)m * p.Cout + en) * 4) : OOB);
             }
         }
     }
@@ -601,8 +666,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
 #pragma unroll
             for (int rk = 0; rk < BM / RPP; ++rk) {
                 const int row = row0 + rk * RPP;
-                const int m = m0 + row;
-                if (m < p.M) {
+                const int m = out_row(row);                  // row of the output tensors (MODE 2 by parity class: not m0 + row)
+                if (m >= 0) {
                     f32x4 v;
                     if (nks > 1) {
                         const unsigned off = ws0 + (unsigned)row * rs;
@@ -644,17 +709,18 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
 #pragma unroll 1
                 for (int rk0 = 0; rk0 < NR; rk0 += UR) {
                     f32x4 dv[UR], yy[UR], o[UR];
+                    int mrow[UR];
 #pragma unroll
                     for (int u = 0; u < UR; ++u) {
-                        const int m = m0 + row0 + (rk0 + u) * RPP;
-                        const size_t off = (size_t)(m < p.M ? m : p.M - 1) * p.Cout + n;       // (rows past the end: a valid address, value unused)
+                        const int m = mrow[u] = out_row(row0 + (rk0 + u) * RPP);
+                        const size_t off = (size_t)(m >= 0 ? m : 0) * p.Cout + n;       // (rows that produce nothing: a valid address, value unused)
                         dv[u] = *reinterpret_cast<const f32x4*>(p.seg[0].out + off);
                         yy[u] = *reinterpret_cast<const f32x4*>(p.bnb_y + off);
                         if (p.bnb_out) o[u] = *reinterpret_cast<const f32x4*>(p.bnb_out + off);
                     }
 #pragma unroll
                     for (int u = 0; u < UR; ++u) {
-                        if (m0 + row0 + (rk0 + u) * RPP >= p.M) continue;
+                        if (mrow[u] < 0) continue;
                         if (!p.bnb_out) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) o[u][e] = remask ? bn_affine(yy[u][e], b_mu[e], b_is[e], b_g[e], b_bt[e]) : 1.f;
@@ -789,6 +855,8 @@ bool vec_epilogue(const ym_conv_desc* d) {
 struct Plan {
     int bm, bn, ksplit, kt_per_split, tiles_m, tiles_n, nkt, M;
     int tail_tiles, tail_split, tail_ktps;     // 0 = no tail
+    // stride-2 data gradient by output-pixel parity class (ConvP::cls): M is then the class-padded row count
+    int cls, M_pix, cls_tile0[5], cls_rows[4], cls_w[4], cls_hw[4], cls_kh0[4], cls_kw0[4], cls_nkw[4], cls_nkt[4];
     int slots() const { return tail_tiles > 0 && tail_split > ksplit ? tail_split : ksplit; }
     size_t ws_bytes(int cout) const {          // uniform split: [ksplit][M][Cout]; tail: [tail_tiles][tail_split][bm][bn]
         const size_t u = ksplit > 1 ? (size_t)ksplit * M * cout * sizeof(float) : 0;
@@ -830,6 +898,8 @@ int make_plan(const ym_conv_desc* d, Plan* pl) {
     YM_REQUIRE(M * (long long)d->Cout < (1ll << 31) && (d->nlevels ? M : (long long)d->B * d->H * d->W) * d->Cin < (1ll << 31) * 1ll,
                "conv: tensor too large for 32-bit indexing");
     pl->M = (int)M;
+    pl->M_pix = (int)M;
+    pl->cls = 0;
     pl->nkt = d->k_pad / BK;
     pl->tail_tiles = 0; pl->tail_split = 0; pl->tail_ktps = 0;
     int bm = d->tile_m, bn = d->tile_n;
@@ -863,6 +933,34 @@ int make_plan(const ym_conv_desc* d, Plan* pl) {
     YM_REQUIRE((bm == 128 || bm == 64) && (bn == 128 || bn == 64), "conv: tile must be 64/128");
     YM_REQUIRE(d->Cin != 4 || (bm == 128 && bn == 64), "conv: stem mode supports the 128x64 tile only");
     pl->bm = bm; pl->bn = bn;
+    {
+        // Stride-2 data gradient: rows ordered by output-pixel parity class, every class padded to whole M tiles, and only the
+        // class's filter taps in its K range (ConvP::cls).  YM_DGRAD_CLASSES=0: the gather over all taps of rounds 1-3 (A/B).
+        static int on = -1;
+        if (on < 0) { const char* e = getenv("YM_DGRAD_CLASSES"); on = e ? atoi(e) : 1; }
+        if (on && d->transposed && d->stride == 2 && d->nlevels == 0 && vec_epilogue(d)) {
+            int t0 = 0, nkt_max = 0, nt_max = 0;
+            for (int c = 0; c < 4; ++c) {
+                const int ph = c >> 1, pw = c & 1;
+                const int hc = (d->Ho - ph + 1) / 2, wc = (d->Wo - pw + 1) / 2;          // dx rows / columns of this parity
+                const int kh0 = (ph + d->pad) & 1, kw0 = (pw + d->pad) & 1;
+                const int nkh = kh0 < d->KH ? (d->KH - kh0 + 1) / 2 : 0, nkw = kw0 < d->KW ? (d->KW - kw0 + 1) / 2 : 0;
+                pl->cls_tile0[c] = t0;
+                pl->cls_rows[c] = d->B * hc * wc;
+                pl->cls_w[c] = wc > 0 ? wc : 1;
+                pl->cls_hw[c] = hc * wc > 0 ? hc * wc : 1;
+                pl->cls_kh0[c] = kh0; pl->cls_kw0[c] = kw0; pl->cls_nkw[c] = nkw > 0 ? nkw : 1;
+                pl->cls_nkt[c] = nkh * nkw * (d->Cin / BK);
+                if (pl->cls_nkt[c] > nkt_max) nkt_max = pl->cls_nkt[c];
+                t0 += ym_cdiv(pl->cls_rows[c], bm);
+                if (ym_cdiv(pl->cls_rows[c], bm) > nt_max) nt_max = ym_cdiv(pl->cls_rows[c], bm);
+            }
+            pl->cls_tile0[4] = t0;
+            pl->cls = 1;
+            pl->M = 4 * nt_max * bm;                       // M tile t belongs to class t & 3 (its tile t >> 2): see the kernel
+            pl->nkt = nkt_max > 0 ? nkt_max : 1;
+        }
+    }
     pl->tiles_m = ym_cdiv(pl->M, bm);
     pl->tiles_n = ym_cdiv(d->Cout, bn);
     int ks = d->ksplit;
@@ -972,6 +1070,17 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
         p.lev_m[5] = m_acc; p.lev_pix[5] = pix_acc;
     }
     p.M = pl.M; p.HoWo = d->Ho * d->Wo; p.nkt = pl.nkt; p.ksplit = pl.ksplit; p.kt_per_split = pl.kt_per_split;
+    p.M_pix = pl.M_pix; p.cls = pl.cls;
+    for (int c = 0; c < 4; ++c) {
+        const bool on = pl.cls != 0;
+        p.cls_tile0[c] = on ? pl.cls_tile0[c] : 0; p.cls_rows[c] = on ? pl.cls_rows[c] : 0; p.cls_w[c] = on ? pl.cls_w[c] : 1;
+        p.cls_fd_hw[c] = FastDiv::make((unsigned)(on ? pl.cls_hw[c] : 1)); p.cls_fd_w[c] = FastDiv::make((unsigned)(on ? pl.cls_w[c] : 1));
+        p.cls_kh0[c] = on ? pl.cls_kh0[c] : 0; p.cls_kw0[c] = on ? pl.cls_kw0[c] : 0; p.cls_nkw[c] = on ? pl.cls_nkw[c] : 1;
+        p.cls_nkt[c] = on ? pl.cls_nkt[c] : 0;
+        p.cls_ktps[c] = on ? ym_cdiv(pl.cls_nkt[c], pl.ksplit) : 0;
+        p.cls_tail_ktps[c] = on && pl.tail_tiles > 0 ? ym_cdiv(pl.cls_nkt[c], pl.tail_split) : 0;
+    }
+    p.cls_tile0[4] = pl.cls ? pl.cls_tile0[4] : 0;
     p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.nseg = d->nseg;
     for (int i = 0; i < 3; ++i) {
         if (i < d->nseg) {
@@ -1037,7 +1146,7 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
         // persistent direct-to-LDS kernel (conv_persist.hip); what it does not cover runs on the non-persistent ring of the same depth
         const int ns = stages - 40;
         const int act = d->seg[0].act;
-        const bool ok = p.vec && pl.bm == 64 && pl.bn == 64 && d->Cin % 32 == 0 && d->nlevels == 0 && d->mma == 0 &&
+        const bool ok = p.vec && pl.bm == 64 && pl.bn == 64 && d->Cin % 32 == 0 && d->nlevels == 0 && d->mma == 0 && !pl.cls &&
                         (act == YM_ACT_NONE || act == YM_ACT_RELU) && (pl.slots() == 1 || p.counters) && d->bn_sum == nullptr &&
                         (ns == 2 || ns == 3 || ns == 4 || ns == 6 || ns == 8);
         if (ok) {
