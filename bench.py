@@ -57,6 +57,7 @@ def parse():
     ap.add_argument('--no-post', action='store_true', help='time the network forward only')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the bs=8 side measurements')
+    ap.add_argument('--lean', action='store_true', help='profiler runs (tools/profile_round.sh): no spread repeats, no latency leg')
     ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
                     help="what `value` reports; the other mode's numbers still appear under extra")
     ap.add_argument('--train-batch', type=int, default=8, help='images per GPU per training step')
@@ -539,13 +540,14 @@ def main():
     region_flops = wl.engine.total_flops * args.steps          # conv flops this rank executed inside the region `value` times
     # spread: the driver's sample is K steps (20 steps = 33 ms at bs=1) -> the same region five more times, and five regions of
     # >= 200 steps (this rank's own clock; every rank takes part so that the barriers match)
-    rep_k = [timed(wl, args.steps, 0, barrier) / args.steps * 1e3 for _ in range(5)]
-    long_steps = max(args.steps, 200 // max(1, args.batch))
-    rep_long = [timed(wl, long_steps, 0, barrier) / long_steps * 1e3 for _ in range(5)]
+    nrep = 1 if args.lean else 5
+    rep_k = [timed(wl, args.steps, 0, barrier) / args.steps * 1e3 for _ in range(nrep)]
+    long_steps = args.steps if args.lean else max(args.steps, 200 // max(1, args.batch))
+    rep_long = [timed(wl, long_steps, 0, barrier) / long_steps * 1e3 for _ in range(nrep)]
     spread = dict(unit='ms_per_step', region_steps=args.steps, first_region=round(elapsed_local / args.steps * 1e3, 4),
-                  repeats=[round(x, 4) for x in rep_k], min=round(min(rep_k), 4), median=round(sorted(rep_k)[2], 4), max=round(max(rep_k), 4),
+                  repeats=[round(x, 4) for x in rep_k], min=round(min(rep_k), 4), median=round(sorted(rep_k)[len(rep_k) // 2], 4), max=round(max(rep_k), 4),
                   long_region_steps=long_steps, long_repeats=[round(x, 4) for x in rep_long], long_min=round(min(rep_long), 4),
-                  long_median=round(sorted(rep_long)[2], 4), long_max=round(max(rep_long), 4))
+                  long_median=round(sorted(rep_long)[len(rep_long) // 2], 4), long_max=round(max(rep_long), 4))
     del wl
     train = None
     if not args.no_train:
@@ -583,7 +585,7 @@ def main():
             # overlapped, and the Little's-law check: requests in flight = throughput x latency must come out as `inflight` if the
             # requests really overlap (one at a time it would be 1)
             lat = Workload(net, cfg, args.batch, args.img_size, device, with_post=not args.no_post, inflight=inflight, timed=True)
-            n_lat = 400 // max(1, args.batch)
+            n_lat = (400 if not args.lean else 16) // max(1, args.batch) or 2
             t_lat = timed(lat, n_lat, 8, lambda: None) / n_lat
             ls = sorted(lat.pipe.latencies_ms[-n_lat:])
             del lat
@@ -625,7 +627,7 @@ def main():
         achieved_region = region_flops / elapsed_local / 1e12
         roofline = dict(bound='mfma', achieved=round(achieved_region, 2), peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
                         frac=round(achieved_region / F32_MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
-                        kernel='conv_igemm_f32 / conv_igemm_pers (all instantiations)', launches_per_step=launches,
+                        kernel='conv_igemm_f32 / conv_igemm_pers / conv_wdma_f32 (all instantiations)', launches_per_step=launches,
                         flops_per_launch=round(flops / launches), avg_launch_us=round(elapsed_local / args.steps / launches * 1e6, 2),
                         requests_in_flight=inflight,
                         definition=('algorithmic conv flops of the timed steps / wall time of the SAME region that `value` times '

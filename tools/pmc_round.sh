@@ -4,7 +4,7 @@ set -u
 TAG="${1:-rXX}"; R="$(pwd)"; OUT="$R/gpurun_out/profiles_$TAG"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 C="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
-BENCH="python $R/bench.py --no-extra --no-cpu-baseline --no-train --inflight 1"     # (one kernel at a time owns the counters)
+BENCH="python $R/bench.py --no-extra --no-cpu-baseline --no-train --lean --inflight 1"     # (one kernel at a time owns the counters)
 one() {   # name, env, args...
     local name="$1"; shift; local envs="$1"; shift
     rm -rf "$OUT/raw_$name"

@@ -13,6 +13,6 @@ one() {   # name, env, args...
     if [ -n "$f" ]; then python $R/tools/pmc_valu_summary.py "$f" "$OUT/${TAG}_pmc_valu_$name.txt"; else echo "$name: no counters"; fi
     rm -rf "/tmp/raw_$name"
 }
-one infer_bs8_res101 "YM_X=0" python $R/bench.py --no-extra --no-cpu-baseline --no-train --inflight 1 --batch 8 --steps 3 --warmup 1
-one infer_bs1_res101 "YM_X=0" python $R/bench.py --no-extra --no-cpu-baseline --no-train --inflight 1 --steps 5 --warmup 2
+one infer_bs8_res101 "YM_X=0" python $R/bench.py --no-extra --no-cpu-baseline --no-train --lean --inflight 1 --batch 8 --steps 3 --warmup 1
+one infer_bs1_res101 "YM_X=0" python $R/bench.py --no-extra --no-cpu-baseline --no-train --lean --inflight 1 --steps 5 --warmup 2
 one train_bs8_res101 "YM_WGRAD_STREAM=0" python $R/tools/train_profile.py --steps 2
