@@ -31,7 +31,7 @@ def main():
             res = eng.autotune(args.iters, verbose=True, mma=args.mma)
             for k, v in res.items():
                 if k not in table:
-                    table[k] = v[:7]
+                    table[k] = v if len(v) > 7 and v[7] else v[:7]      # (eighth field: grid_wgs / waves per workgroup, only when set)
                     detail[k] = list(v[:7]) + list(eng.autotune_detail[k])
             net._engines.clear()
             torch.cuda.empty_cache()

@@ -581,12 +581,12 @@ class InferEngine:
                     with torch.cuda.stream(side):
                         hip.conv2d_fwd(d2[i], big_ws2[i])
 
-        def time_cfg(c, tile, ks, kwv=0, stg=0, tail=(0, 0)):
+        def time_cfg(c, tile, ks, kwv=0, stg=0, tail=(0, 0), gw=0):
             d = c.desc
             d.tile_m, d.tile_n, d.ksplit, d.kwaves, d.stages = tile[0], tile[1], ks, kwv, stg
             d.mma = mma if (split_ok(c) and kwv == 0) else 0
             d.tail_tiles, d.tail_ksplit = tail
-            d.grid_wgs = 0                       # (never the previous table entry's grid)
+            d.grid_wgs = gw                      # (never the previous table entry's grid; wave kernel with DMA rings: waves per workgroup)
             need = hip.conv_workspace_bytes(d)
             if need > big_ws.numel():
                 return None
@@ -625,8 +625,7 @@ class InferEngine:
             if mma and not split_ok(c):
                 continue
             if c.sig in seen:
-                c.tile, c.ksplit, c.kwaves, c.stages, c.tail = seen[c.sig]
-                c.grid_wgs = 0
+                c.tile, c.ksplit, c.kwaves, c.stages, c.tail, c.grid_wgs = seen[c.sig]
                 c.mma = mma if (mma and c.kwaves == 0) else 0
                 continue
             d = c.desc
@@ -634,7 +633,7 @@ class InferEngine:
             if d.nlevels:
                 M = sum(d.B * d.level_h[l] * d.level_w[l] for l in range(d.nlevels))
             base = time_cfg(c, (0, 0), 0, 0)
-            cands = []
+            cands, wave_cands = [], []
             tiles = [(128, 64)] if c.stem else [(128, 128), (128, 64), (64, 128), (64, 64)]
             for tm, tn in tiles:
                 wgs = -(-M // tm) * -(-d.Cout // tn)
@@ -675,18 +674,31 @@ class InferEngine:
                         if waves * kwv > 65536:
                             continue
                         cands.append(((tm, tn), 1, kwv, 0, (0, 0)))
+                # the wave kernel with private DMA rings (conv_wdma_f32): K split inside the workgroup, no K-slice exchange; one- and
+                # two-wave workgroups where the waves share nothing; the tail split of a 32x32 / four-K-wave plan.  (A launch repeated
+                # back to back undervalues it against the kernels with a cross-workgroup exchange: tools/tune_forward.py judges the
+                # candidates by the plan's forward time.)
+                if d.Cin % 32 == 0 and d.nlevels == 0:
+                    for tm, tn in ((32, 32), (64, 32), (32, 64)):
+                        for kwv in (1, 2, 4):
+                            if kwv <= nkt:
+                                wave_cands.append(((tm, tn), 1, kwv, 22, (0, 0), 0))
+                                wave_cands += [((tm, tn), 1, kwv, 22, (0, 0), wpb) for wpb in (1, 2) if wpb >= kwv and kwv < 4]
+                    tiles32 = -(-M // 32) * -(-d.Cout // 32)
+                    if tiles32 > 256 and d.nseg == 1 and d.tile_counters:
+                        wave_cands += [((32, 32), 1, 4, 22, (tiles32 % 256 or 256, ts), 0) for ts in (4, 6, 8) if ts * 2 <= nkt]
             if mma:                                          # split-bf16: register staging with one (0) or two (3) register sets
                 cands = sorted({(tile, ks, kwv, st, tail) for tile, ks, kwv, stg, tail in cands for st in ((0, 3) if kwv == 0 else (0,))})
-            best = (base, (0, 0), 0, 0, 0, (0, 0))
-            for tile, ks, kwv, stg, tail in cands:
-                t = time_cfg(c, tile, ks, kwv, stg, tail)
+            best = (base, (0, 0), 0, 0, 0, (0, 0), 0)
+            for cand in [cd + (0,) for cd in cands] + ([] if mma else wave_cands):
+                tile, ks, kwv, stg, tail, gw = cand
+                t = time_cfg(c, tile, ks, kwv, stg, tail, gw)
                 if t is not None and t < best[0] * 0.98:
-                    best = (t, tile, ks, kwv, stg, tail)
-            c.tile, c.ksplit, c.kwaves, c.stages, c.tail = best[1], best[2], best[3], best[4], best[5]
-            c.grid_wgs = 0
+                    best = (t, tile, ks, kwv, stg, tail, gw)
+            c.tile, c.ksplit, c.kwaves, c.stages, c.tail, c.grid_wgs = best[1], best[2], best[3], best[4], best[5], best[6]
             c.mma = mma if (mma and c.kwaves == 0) else 0
-            seen[c.sig] = (c.tile, c.ksplit, c.kwaves, c.stages, c.tail)
-            results[c.sig + (f'_mma{mma}' if mma else '')] = [best[1][0], best[1][1], best[2], best[3], best[4], best[5][0], best[5][1], 0]
+            seen[c.sig] = (c.tile, c.ksplit, c.kwaves, c.stages, c.tail, c.grid_wgs)
+            results[c.sig + (f'_mma{mma}' if mma else '')] = [best[1][0], best[1][1], best[2], best[3], best[4], best[5][0], best[5][1], best[6]]
             self.autotune_detail[c.sig + (f'_mma{mma}' if mma else '')] = (round(best[0], 2), round(base, 2))
             if verbose:
                 print(f'{c.sig:44s} default {base:8.1f} us -> {best[1]} ks={best[2]} kw={best[3]} st={best[4]} tail={best[5]} {best[0]:8.1f} us', flush=True)
