@@ -533,6 +533,9 @@ def wgrad_stream_if_used(device):
 # nothing -> the default stays one.  Launches into a caller-owned destination (the shared head's accumulating gradients) always use
 # the first stream, which keeps them ordered.
 _N_SIDE = int(os.environ.get('YM_WGRAD_STREAMS', '1'))
+# YM_WGRAD_STREAM_PRIORITY=-1 creates the side stream(s) on a high-priority hardware queue (0 = like any other stream):
+# tools/train_prio.py measures both orders (the data-gradient chain ahead of the weight gradients and the reverse).
+_SIDE_PRIO = int(os.environ.get('YM_WGRAD_STREAM_PRIORITY', '0'))
 _extra_streams = {}
 _rr = [0]
 
@@ -541,10 +544,10 @@ def wgrad_stream(device, ordered=True):
     device = _dev_key(device)
     s = _side_streams.get(device)
     if s is None:
-        s = _side_streams[device] = torch.cuda.Stream(device=device)
+        s = _side_streams[device] = torch.cuda.Stream(device=device, priority=_SIDE_PRIO)
     if ordered or _N_SIDE <= 1:
         return s
-    ex = _extra_streams.setdefault(device, [torch.cuda.Stream(device=device) for _ in range(_N_SIDE - 1)])
+    ex = _extra_streams.setdefault(device, [torch.cuda.Stream(device=device, priority=_SIDE_PRIO) for _ in range(_N_SIDE - 1)])
     _rr[0] = (_rr[0] + 1) % _N_SIDE
     return s if _rr[0] == 0 else ex[_rr[0] - 1]
 
