@@ -1,8 +1,8 @@
-"""Serving with several independent requests in flight on one MI355X (batch 1: 338 -> 600 img/s; batch 8: 700 -> 760 forward-only).
+"""Serving with several independent requests in flight on one MI355X (batch 1: 400 -> 600-617 img/s; batch 8: 700 -> 760 forward-only).
 
 The reference evaluates one image at a time (`eval.py:36-69`: forward -> nms -> after_nms, a device synchronisation around each).
 On this part a bs=1 forward is a chain of ~190 dependent launches of 0.6-1.4 GFLOP each: every launch pays a kernel boundary, an
-address set-up + cold-L2 round trip and an epilogue (~9 us) around ~7 us of MFMA work, so ONE chain keeps the matrix pipe ~35 %
+address set-up + cold-L2 round trip and an epilogue (~9 us in round 3, ~6 us since round 4) around ~7 us of MFMA work, so ONE chain keeps the matrix pipe ~35-43 %
 busy whatever the kernels do.  Requests are independent, so the way to fill the chip at batch size 1 is to have several of them in
 flight: `RequestPipeline` owns `depth` complete engines (activations, split-K scratch, arrival counters, hipGraph: nothing shared
 but the read-only weights) and `depth` HIP streams, and runs request i on slot i % depth.  Each request is still ONE image through
@@ -11,7 +11,7 @@ the count is copied to pinned host memory behind the request and read when the s
 the request it has just enqueued.
 
 Measured mid-round 3 (res101_coco 544 px, MI355X, forward + nms + after_nms(480x640)): depth 1: 325 img/s, 2: 468, 3: 545, 4: 594, 5: 495,
-8: 479 -- the part schedules four compute pipes; GPU_MAX_HW_QUEUES must be >= depth + 1 (ROCm multiplexes HIP streams onto 4
+8: 479; with round 4's kernels 3: 580, 4: 603-617, 5: 499, 6: 527 -- the part schedules four compute pipes; GPU_MAX_HW_QUEUES must be >= depth + 1 (ROCm multiplexes HIP streams onto 4
 hardware queues by default and two streams that share a queue do not overlap): set it to 8 before the first HIP call
 (`RequestPipeline` warns when the variable is missing or too small: it cannot be changed once the runtime is up).
 """
