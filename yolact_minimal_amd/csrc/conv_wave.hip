@@ -416,12 +416,46 @@ __global__ __launch_bounds__(WPB * 64) void conv_wdma_f32(const ConvP p) {
 #ifdef YM_TRACE
     if (p.trace) { __builtin_amdgcn_s_waitcnt(waitcnt_vm((AR + BR) * (D - 1))); YM_STAMP(1); }      // (first tile landed)
 #endif
+#ifdef YM_TRACE
+    // ablations of the trace build (YM_PERS_ABL -> p.bnb_relu, tools/wave_ablation.py): 1 = operand stream only (DMA + its counted
+    // wait, no LDS reads, no MFMAs), 2 = LDS reads + MFMAs only (whatever the ring holds), 3 = MFMAs only (register operands)
+    const int abl = p.bnb_relu;
+#endif
     auto tile_step = [&](auto S) __attribute__((always_inline)) {
         constexpr int ST = decltype(S)::value;
         __builtin_amdgcn_sched_barrier(0);         // the re-fill of the stage read last stays behind the MFMAs that consumed its fragments
-        dma_next((ST + D) % NS);
-        __builtin_amdgcn_s_waitcnt(WAIT);
-        compute(S);
+#ifdef YM_TRACE
+        if (abl >= 1 && abl <= 3) {
+            if (abl == 1) {
+                dma_next((ST + D) % NS);
+                __builtin_amdgcn_s_waitcnt(WAIT);
+            } else if (abl == 2) {
+                compute(S);
+            } else {
+                const f32x4 ra = {1.f, 2.f, 3.f, 4.f}, rb = {.5f, .25f, .125f, 1.f};
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        if constexpr (DUAL) {
+                            if (s4 & 1) acc_odd = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[s4], rb[s4], acc_odd, 0, 0, 0);
+                            else acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[s4], rb[s4], acc[0][0], 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                                for (int j = 0; j < TN; ++j)
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[s4], rb[s4], acc[i][j], 0, 0, 0);
+                        }
+                    }
+            }
+        } else
+#endif
+        {
+            dma_next((ST + D) % NS);
+            __builtin_amdgcn_s_waitcnt(WAIT);
+            compute(S);
+        }
     };
     int t = 0;
     for (; t + NS <= nt; t += NS) static_for<0, NS>([&](auto S) __attribute__((always_inline)) { tile_step(S); });
