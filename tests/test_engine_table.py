@@ -26,6 +26,11 @@ def test_grid_wgs_field_is_validated():
     assert E._grid_wgs([64, 64, 1, 0, 2, 0, 0]) == 0
     with pytest.raises(ValueError):
         E._grid_wgs([64, 64, 1, 0, 43, 0, 0, 12.5])           # an old autotune detail row: a timing where grid_wgs belongs
+    with pytest.raises(ValueError):
+        E._grid_wgs([32, 32, 1, 4, 22, 0, 0, 768])            # a persistent-kernel grid on a wave-DMA row (there: waves per workgroup)
+    with pytest.raises(ValueError):
+        E._grid_wgs([32, 32, 1, 4, 22, 40, 4, 2])             # the wave kernel's tail split needs four-wave workgroups
+    assert E._grid_wgs([32, 32, 1, 4, 22, 40, 4, 4]) == 4 and E._grid_wgs([32, 32, 1, 2, 23, 0, 0, 2]) == 2
 
 
 def test_committed_table_is_well_formed():
@@ -127,3 +132,37 @@ def test_planner_accepts_every_forward_row_of_the_committed_table():
         split += int(nb > 0)
         checked += 1
     assert checked > 150 and wave >= 15 and split > 50, (checked, wave, split)
+
+
+def test_tuner_rows_reach_the_table_only_through_the_reference_digest_gate(tmp_path):
+    """tools/table_gate.py: rows a tuner proposes (`tune_forward.py --inflight N --write` writes `<sig>_tp` rows) are merged into the
+    table only after the 544 px reference-digest tests have run green against the CANDIDATE table; a red or missing run leaves
+    the table as it was."""
+    from tools import table_gate as G
+    path = tmp_path / 'table.json'
+    base = {'M1156_N256_C1024_k1_s1_seg1_r0': [32, 32, 1, 4, 22, 40, 4]}
+    path.write_text(json.dumps(base))
+    rows = {'M1156_N256_C1024_k1_s1_seg1_r0_tp': [32, 32, 1, 4, 22, 0, 0]}
+    seen = []
+
+    def red(candidate):
+        seen.append(json.load(open(candidate)))
+        return 1
+
+    with pytest.raises(G.GateRefused):
+        G.merge_rows(rows, str(path), runner=red)
+    assert json.loads(path.read_text()) == base                         # untouched
+    assert seen[0] == {**base, **rows}                                  # the tests saw the candidate, not the committed table
+    assert not list(tmp_path.parent.glob('tuned_candidate_*'))
+    merged = G.merge_rows(rows, str(path), runner=lambda candidate: 0)
+    assert merged == {**base, **rows} and json.loads(path.read_text()) == merged
+    # the gate's test list names tests that exist, parametrised over both plan modes
+    import ast
+    src = open(os.path.join(G.REPO, 'tests', 'test_gpu_forward.py')).read()
+    names = {n.name for n in ast.walk(ast.parse(src)) if isinstance(n, ast.FunctionDef)}
+    for t in G.GATE_TESTS:
+        assert t.split('::')[1] in names, t
+    assert "'throughput'" in src
+    # and the tuner goes through it
+    tool = open(os.path.join(G.REPO, 'tools', 'tune_forward.py')).read()
+    assert 'merge_rows' in tool and 'json.dump(table, open(E.TUNED_PATH' not in tool

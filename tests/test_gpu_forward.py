@@ -47,16 +47,29 @@ def test_forward_matches_golden_and_oracle(golden_dir, name, size, batch, graph,
     _close(eng.box_pred, feats[1], 'box', atol=1e-4, rtol=1e-4)
 
 
+def _tp_rows_in_plan(eng):
+    from yolact_minimal_amd.engine import tuned_table
+    return sum(1 for c in eng.convs if c.sig + '_tp' in tuned_table())
+
+
+@pytest.mark.parametrize('mode', ['latency', 'throughput'])
 @pytest.mark.parametrize('name', ['res50_coco', 'res101_coco'])
-def test_forward_544_digest(golden_dir, name):
-    """Full-size (the "550-class" config is really 544): sampled slices + sums from the reference."""
+def test_forward_544_digest(golden_dir, name, mode):
+    """Full-size (the "550-class" config is really 544): sampled slices + sums from the reference.
+    `mode`: the plan one request at a time runs, and the plan behind bench.py's `value` (the `<shape>_tp` rows the slots of a
+    RequestPipeline with requests in flight read) -- each against the REFERENCE's outputs, not against the other."""
     g = np.load(os.path.join(golden_dir, f'forward_{name}_544_digest.npz'))
     seed = int(g['seed'])
     net, cfg = make_net(name, 544, seed)
     img = torch.randn(1, 3, 544, 544, generator=torch.Generator().manual_seed(seed + 300))
     net = net.to(DEV)
+    net.set_plan_mode(mode)
     with torch.no_grad():
         cls, box, coef, proto = net(img.to(DEV))
+    eng = net._engine(img.to(DEV))
+    assert eng.mode == mode
+    if mode == 'throughput' and name == 'res101_coco':
+        assert _tp_rows_in_plan(eng) > 0, 'the throughput plan of the headline config reads no _tp row: this test must exercise them'
     assert cls.shape == (1, 18525, 81) and proto.shape == (1, 136, 136, 32)
     _close(cls[0, ::37], g['class_sample'], 'class sample')
     _close(box[0, ::37], g['box_sample'], 'box sample')
@@ -84,9 +97,9 @@ def check_bs8_digest(g, out, tuned_hits):
     assert tuned_hits > 0, 'the bs=8 plan did not pick anything from tuned_gfx950.json: this test must exercise the tuned kernels'
 
 
-@pytest.mark.parametrize('graph', ['0', '1'])
+@pytest.mark.parametrize('graph,mode', [('0', 'latency'), ('1', 'latency'), ('1', 'throughput')])
 @pytest.mark.parametrize('name', ['res50_coco', 'res101_coco'])
-def test_forward_544_bs8_digest_under_the_tuned_plan(golden_dir, name, graph, monkeypatch):
+def test_forward_544_bs8_digest_under_the_tuned_plan(golden_dir, name, graph, mode, monkeypatch):
     """BASELINE.json config 2 (res50 bs=8) and config 3's per-GPU forward shape (res101 bs=8) at 544 px, against the REAL
     reference's outputs (oracle/make_golden_fullsize.py).  Runs the plan bench.py times: tuned_gfx950.json tiles / split-K /
     tail splits / direct-to-LDS variants, per-level head launches, with and without hipGraph replay."""
@@ -96,12 +109,14 @@ def test_forward_544_bs8_digest_under_the_tuned_plan(golden_dir, name, graph, mo
     net, cfg = make_net(name, 544, seed)
     img = torch.randn(8, 3, 544, 544, generator=torch.Generator().manual_seed(seed + 300))
     net = net.to(DEV)
+    net.set_plan_mode(mode)          # 'throughput': what the slots of a batch-8 RequestPipeline with 2 / 4 batches in flight run
     with torch.no_grad():
         out = net(img.to(DEV))
         out2 = net(img.to(DEV))
     for a, b in zip(out, out2):
         assert torch.equal(a, b)
     eng = net._engine(img.to(DEV))
+    assert eng.mode == mode
     from yolact_minimal_amd.engine import tuned_table
     hits = sum(1 for c in eng.convs if c.sig in tuned_table())
     check_bs8_digest(g, out, hits)

@@ -112,9 +112,10 @@ def test_swin_forward_544_digest(golden_dir):
     _close(proto[0, ::5, ::5], g['proto_sample'], 'proto sample')
 
 
-@pytest.mark.parametrize('graph', ['0', '1'])
-def test_swin_forward_544_bs8_digest_under_the_tuned_plan(golden_dir, graph, monkeypatch):
-    """BASELINE.json config 5 (swin_tiny_coco 544 px bs=8) against the REAL reference's outputs, on the tuned bs=8 plan."""
+@pytest.mark.parametrize('graph,mode', [('0', 'latency'), ('1', 'latency'), ('1', 'throughput')])
+def test_swin_forward_544_bs8_digest_under_the_tuned_plan(golden_dir, graph, mode, monkeypatch):
+    """BASELINE.json config 5 (swin_tiny_coco 544 px bs=8) against the REAL reference's outputs, on the tuned bs=8 plan -- the one a
+    lone batch runs and the one the slots of a RequestPipeline with batches in flight run (`_tp` rows first)."""
     from tests.test_gpu_forward import check_bs8_digest
     from yolact_minimal_amd.engine import tuned_table
     monkeypatch.setenv('YM_GRAPH', graph)
@@ -123,9 +124,11 @@ def test_swin_forward_544_bs8_digest_under_the_tuned_plan(golden_dir, graph, mon
     net, cfg = _make_swin(544, seed)
     img = torch.randn(8, 3, 544, 544, generator=torch.Generator().manual_seed(seed + 300))
     net = net.to(DEV)
+    net.set_plan_mode(mode)
     with torch.no_grad():
         out = net(img.to(DEV))
     eng = net._engine(img.to(DEV))
+    assert eng.mode == mode
     check_bs8_digest(g, out, sum(1 for c in eng.convs if c.sig in tuned_table()))
 
 

@@ -860,6 +860,48 @@ def test_conv_dgrad_staging_variants_agree(cin, cout, k, stride, hw, b):
     assert torch.equal(outs['dl2_ks3'], outs['pers3_ks3'])
 
 
+@pytest.mark.parametrize('cin,cout,k,hw,b', [(64, 128, 3, 69, 1), (128, 256, 1, 23, 2), (64, 64, 3, 40, 2)])
+def test_stride2_dgrad_with_a_k_split_and_no_arrival_counters(cin, cout, k, hw, b, monkeypatch):
+    """Stride-2 data gradients order their GEMM rows by output-pixel parity class (make_plan: `cls`); only the fused split-K
+    finish knows how to map such a row back to its dx pixel.  Without arrival counters (`tile_counters` = NULL: the header calls
+    them optional; hip.conv2d_fwd drops them above 16384 tiles) a K split ends in `conv_splitk_reduce`, which reads plain
+    [M][Cout] slabs -- the planner must then fall back to the gather over all taps.  Odd sizes (69, 23: the four classes have
+    different row counts), with and without counters, with and without the K split: all equal to autograd of F.conv2d."""
+    from yolact_minimal_amd import train_engine as T
+    from yolact_minimal_amd.engine import tuned_table
+    g = torch.Generator().manual_seed(cin + cout + k + hw)
+    pad = k // 2
+    x = torch.randn(b, cin, hw, hw, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * (1 / (cin * k * k) ** 0.5)
+    ho = (hw + 2 * pad - k) // 2 + 1
+    dy = torch.randn(b, cout, ho, ho, generator=g)
+    add = torch.randn(b, hw, hw, cin, generator=g)
+    xr = x.double().requires_grad_()
+    (F.conv2d(xr, w.double(), None, 2, pad) * dy.double()).sum().backward()
+    want = xr.grad.permute(0, 2, 3, 1) + add.double()
+    dz = dy.permute(0, 2, 3, 1).contiguous()
+    key = f'T_M{b * hw * hw}_N{cin}_C{cout}_k{k}_s2'
+    table = tuned_table()
+    saved = table.get(key)
+    real_counters = T._tile_counters
+    outs = {}
+    try:
+        for counters in (True, False):
+            monkeypatch.setattr(T, '_tile_counters', real_counters if counters else (lambda device: None))
+            for name, row in (('ks1', [64, 64, 1, 0, 2, 0, 0]), ('ks3', [64, 64, 3, 0, 2, 0, 0]), ('ks2_dl_128x64', [128, 64, 2, 0, 22, 0, 0])):
+                table[key] = row
+                T.tuned_table_changed()
+                outs[(name, counters)] = T._conv_dgrad(dz.to(DEV), w.to(DEV), cout, (b, hw, hw, cin), 2, pad, add=add.to(DEV)).cpu()
+    finally:
+        if saved is None:
+            table.pop(key, None)
+        else:
+            table[key] = saved
+        T.tuned_table_changed()
+    for name, o in outs.items():
+        torch.testing.assert_close(o.double(), want, rtol=1e-4, atol=1e-5, msg=lambda m, name=name: f'{name}: {m}')
+
+
 @pytest.mark.parametrize('cfg_name', ['res50_coco', 'swin_tiny_coco'])
 def test_two_rank_training_keeps_replicas_identical(cfg_name):
     """Two real processes (torch.distributed.run, gloo so that both ranks may share this box's single GPU) run the HIP

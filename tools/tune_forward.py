@@ -29,7 +29,6 @@ ap.add_argument('--replays', type=int, default=40)
 ap.add_argument('--inflight', type=int, default=1, help='> 1: optimise the img/s of a RequestPipeline with that many requests in flight; winners are written as <sig>_tp')
 args = ap.parse_args()
 dev = torch.device('cuda:0')
-R3 = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuned_r03.json')))      # the table at the end of round 3
 net, cfg = bench.build_net(args.cfg, 544, dev)
 img = torch.randn(args.batch, 3, 544, 544, device=dev)
 pipe = None
@@ -150,10 +149,10 @@ for _, sig, t0 in sorted(order):
                 d.tile_m, d.tile_n, d.ksplit, d.kwaves, d.stages, d.tail_tiles, d.tail_ksplit, d.grid_wgs = keep
                 if t is not None:
                     cands.append((t, v))
-    if pipe is not None:              # the round-3 choice (LDS-tiled kernels, K split over workgroups) and the latency entry are candidates too
-        for alt in (E.tuned_table().get(sig), R3.get(sig)):
-            if alt:
-                cands.append((0.0, list(alt[:7]) + [alt[7] if len(alt) > 7 else 0]))
+    if pipe is not None:              # the latency entry is a candidate too (the slot may currently run a `_tp` row)
+        alt = E.tuned_table().get(sig)
+        if alt:
+            cands.append((0.0, list(alt[:7]) + [alt[7] if len(alt) > 7 else 0]))
     cands.sort()
     tried = 0
     t_ref = min([t0] + [t for t, _ in cands if t > 0])
@@ -176,7 +175,13 @@ if pipe is not None:
     kept = {k + '_tp': v for k, v in kept.items()}
 if args.out:
     json.dump(kept, open(args.out, 'w'), indent=0, sort_keys=True)
-if args.write:
-    table = E.tuned_table()
-    table.update(kept)
-    json.dump(table, open(E.TUNED_PATH, 'w'), indent=0, sort_keys=True)
+if args.write and kept:
+    # rows change the summation order of their layers: they reach the committed table only through the reference-digest gate
+    from tools.table_gate import merge_rows, GateRefused
+    torch.cuda.synchronize()
+    try:
+        merge_rows(kept, E.TUNED_PATH)
+        print(f'wrote {len(kept)} rows to {E.TUNED_PATH} (544 px reference digests green under the candidate table)')
+    except GateRefused as exc:
+        print(f'REFUSED: {exc}')
+        sys.exit(3)

@@ -866,7 +866,7 @@ struct Plan {
     int grid() const { return (tiles_m * tiles_n - tail_tiles) * ksplit + tail_tiles * (tail_tiles > 0 ? tail_split : 0); }
 };
 
-int make_plan(const ym_conv_desc* d, Plan* pl) {
+int make_plan(const ym_conv_desc* d, Plan* pl, bool allow_cls = true) {
     YM_REQUIRE(d && d->in && d->weight, "conv: null descriptor / pointer");
     YM_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cout > 0, "conv: bad shape");
     YM_REQUIRE(d->Cin == 4 || d->Cin % 32 == 0, "conv: Cin must be 4 (stem) or a multiple of 32, got %d", d->Cin);
@@ -938,7 +938,7 @@ int make_plan(const ym_conv_desc* d, Plan* pl) {
         // class's filter taps in its K range (ConvP::cls).  YM_DGRAD_CLASSES=0: the gather over all taps of rounds 1-3 (A/B).
         static int on = -1;
         if (on < 0) { const char* e = getenv("YM_DGRAD_CLASSES"); on = e ? atoi(e) : 1; }
-        if (on && d->transposed && d->stride == 2 && d->nlevels == 0 && vec_epilogue(d)) {
+        if (on && allow_cls && d->transposed && d->stride == 2 && d->nlevels == 0 && vec_epilogue(d)) {
             int t0 = 0, nkt_max = 0, nt_max = 0;
             for (int c = 0; c < 4; ++c) {
                 const int ph = c >> 1, pw = c & 1;
@@ -986,6 +986,10 @@ int make_plan(const ym_conv_desc* d, Plan* pl) {
         pl->tail_split = ym_cdiv(pl->nkt, pl->tail_ktps);
         pl->tail_tiles = pl->tail_split > 1 ? d->tail_tiles : 0;
     }
+    // The class-ordered rows exist only inside the launch: K slices of such a plan must meet in the fused finish (arrival counters),
+    // which maps a tile row back to its dx pixel.  `conv_splitk_reduce` reads the slabs as plain [M][Cout] rows, so without counters
+    // (none given, or a workspace past the 32-bit exchange offsets) the plan falls back to the gather over all taps.
+    if (pl->cls && pl->slots() > 1 && (!d->tile_counters || pl->ws_bytes(d->Cout) >= 0xFFFFFFF0ull)) return make_plan(d, pl, false);
     return YM_OK;
 }
 
@@ -1109,6 +1113,7 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
     if (const char* e = getenv("YM_PERS_ABL")) { if (!d->bn_sum) p.bnb_relu = atoi(e); }      // conv_persist.hip ablations (trace build only)
 #endif
     p.counters = (p.vec && pl.slots() > 1 && (d->kwaves == 0 || pl.tail_tiles > 0) && need < 0xFFFFFFF0ull) ? d->tile_counters : nullptr;
+    YM_REQUIRE(!pl.cls || (p.vec && (pl.slots() == 1 || p.counters)), "conv(dgrad, stride 2): the class-ordered plan needs a 16-byte aligned workspace");
     YM_REQUIRE(pl.tail_tiles == 0 || p.counters, "conv: tail_tiles needs a plain NHWC output (vector epilogue) and a workspace < 4 GiB");
     p.main_tiles = pl.tiles_m * pl.tiles_n - pl.tail_tiles;
     p.main_blocks = p.main_tiles * pl.ksplit;

@@ -47,6 +47,11 @@ def _grid_wgs(hit):
     g = hit[7]
     if isinstance(g, bool) or not isinstance(g, int) or g < 0:
         raise ValueError(f'tuned entry {hit}: field 7 must be grid_wgs (a non-negative integer)')
+    if hit[3] > 0 and 22 <= hit[4] <= 24:
+        # wave kernel with DMA rings (conv_wdma_f32): the field is WAVES PER WORKGROUP, not a grid size -- a row edited over from
+        # the persistent kernel (hundreds of workgroups) would be rejected by the launch, or silently lose its tail split
+        if g not in (0, 1, 2, 4) or (g and g < hit[3]) or ((hit[5] or hit[6]) and g not in (0, 4)):
+            raise ValueError(f'tuned entry {hit}: field 7 of a wave-DMA row is waves per workgroup (0 / 1 / 2 / 4, >= kwaves; 0 / 4 with a tail)')
     return g
 
 
@@ -685,7 +690,7 @@ class InferEngine:
                                 wave_cands.append(((tm, tn), 1, kwv, 22, (0, 0), 0))
                                 wave_cands += [((tm, tn), 1, kwv, 22, (0, 0), wpb) for wpb in (1, 2) if wpb >= kwv and kwv < 4]
                     tiles32 = -(-M // 32) * -(-d.Cout // 32)
-                    if tiles32 > 256 and d.nseg == 1 and d.tile_counters:
+                    if 256 < tiles32 <= hip.TILE_COUNTERS and d.nseg == 1 and d.tile_counters:
                         wave_cands += [((32, 32), 1, 4, 22, (tiles32 % 256 or 256, ts), 0) for ts in (4, 6, 8) if ts * 2 <= nkt]
             if mma:                                          # split-bf16: register staging with one (0) or two (3) register sets
                 cands = sorted({(tile, ks, kwv, st, tail) for tile, ks, kwv, stg, tail in cands for st in ((0, 3) if kwv == 0 else (0,))})

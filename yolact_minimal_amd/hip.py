@@ -265,11 +265,15 @@ TILE_COUNTERS = 16384     # int32 entries the engines allocate for ym_conv_desc.
 
 
 def conv2d_fwd(desc, workspace=None):
-    if desc.tile_counters and lib().ym_conv2d_tile_counters(ctypes.byref(desc)) > TILE_COUNTERS:
-        desc.tile_counters = None              # more output tiles than counters: separate reduce launch
+    counters = desc.tile_counters
+    if counters and lib().ym_conv2d_tile_counters(ctypes.byref(desc)) > TILE_COUNTERS:
+        desc.tile_counters = None              # more output tiles than counters: separate reduce launch (this launch only)
     ws_ptr = ctypes.c_void_p(workspace.data_ptr()) if workspace is not None else None
     ws_bytes = workspace.numel() * workspace.element_size() if workspace is not None else 0
-    check(lib().ym_conv2d_fwd(ctypes.byref(desc), ws_ptr, ws_bytes, stream_ptr()), 'ym_conv2d_fwd')
+    try:
+        check(lib().ym_conv2d_fwd(ctypes.byref(desc), ws_ptr, ws_bytes, stream_ptr()), 'ym_conv2d_fwd')
+    finally:
+        desc.tile_counters = counters          # the caller's descriptor is not ours to edit (tuners re-plan it with other tiles)
 
 
 def maxpool3x3s2(x, out):

@@ -151,13 +151,26 @@ class Yolact(nn.Module):
         for eng in self._engines.values():
             eng.set_mma(self._conv_mma)
 
+    PLAN_MODES = ('latency', 'throughput')
+
+    def set_plan_mode(self, mode):
+        """Which rows of the tuned table the engines behind `forward` read (not part of the reference's surface): 'latency' (default:
+        one request at a time has the chip to itself) or 'throughput' (`<shape>_tp` rows first: the plan the slots of a
+        `pipeline.RequestPipeline` with several requests in flight run, i.e. the plan behind bench.py's `value`).  Same kernels, same
+        arithmetic per launch; tile / K-split choices differ, so results agree to fp32 summation order."""
+        if mode not in self.PLAN_MODES:
+            raise ValueError(f'plan mode must be one of {self.PLAN_MODES}, got {mode!r}')
+        if mode != getattr(self, '_plan_mode', 'latency'):
+            self._plan_mode = mode
+            self._engines.clear()
+
     def _engine(self, img):
         from ..engine import InferEngine
         key = (img.device.index, img.shape[0], img.shape[2], img.shape[3])
         eng = self._engines.get(key)
         if eng is None:
             eng = InferEngine(self, batch=img.shape[0], height=img.shape[2], width=img.shape[3],
-                              device=img.device)
+                              device=img.device, mode=getattr(self, '_plan_mode', 'latency'))
             if getattr(self, '_conv_mma', None) is not None:
                 eng.set_mma(self._conv_mma)
             self._engines[key] = eng
