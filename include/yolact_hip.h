@@ -260,6 +260,22 @@ typedef struct {
 } ym_wgrad_desc;
 size_t ym_conv2d_wgrad_workspace_bytes(const ym_wgrad_desc* d);
 int ym_conv2d_wgrad(const ym_wgrad_desc* d, void* workspace, size_t workspace_bytes, ym_stream_t s);
+/* The two halves of ym_conv2d_wgrad apart, so that the slab reductions of MANY layers run as one launch (a res101 step has 104
+ * backbone weight gradients; reference: one `at::conv_backward` weight kernel per layer under `loss.backward()`, train.py:125).
+ * ym_conv2d_wgrad_slabs: first pass only -- the msplit partial gradients stay in `workspace` (which must then live, unshared, until
+ * the batched reduction has run) and *item describes the pending reduction (d->row_end[0] must be 0: one destination tensor).
+ * ym_wgrad_reduce_batch: `items_dev` = n_items such records in DEVICE memory, `first_block` of each set by the caller to the sum of
+ * `blocks` of the records before it, total_blocks = the sum over all; sums every item's slabs in slab order (the same bits as
+ * ym_conv2d_wgrad) into its OIHW tensor.  Items of one batch must not share a destination. */
+typedef struct {
+    const float* slabs;      /* = workspace of the slab pass */
+    float* dw;               /* OIHW destination (d->dw) */
+    uint32_t first_block;    /* IN: set by the caller when it builds the table */
+    uint32_t blocks;         /* OUT: 256-thread blocks this item occupies in the batched launch */
+    uint32_t plan[14];       /* OUT: opaque (sizes, slab stride, division constants) */
+} ym_wgrad_reduce_item;
+int ym_conv2d_wgrad_slabs(const ym_wgrad_desc* d, void* workspace, size_t workspace_bytes, ym_wgrad_reduce_item* item, ym_stream_t s);
+int ym_wgrad_reduce_batch(const ym_wgrad_reduce_item* items_dev, int n_items, uint32_t total_blocks, ym_stream_t s);
 
 /* BatchNorm2d forward in TRAIN mode on a conv output y [M][C] (C % 4 == 0): batch mean / biased variance
  * (fp64 accumulation), running stats updated in place with `momentum` (unbiased variance, torch semantics),

@@ -39,6 +39,7 @@ def test_struct_layout_matches_c():
     assert hip.lib().ym_sizeof_conv_desc() == ctypes.sizeof(hip.ConvDesc)
     assert ctypes.sizeof(hip.WgradDesc) == 24 + 14 * 4 + 4 + 8 + 4 + 16 + 8   # + accumulate, row_end[2], padding, dw_seg[2], lds_buffers (+pad)
     assert ctypes.sizeof(hip.NmsCfg) == 32
+    assert ctypes.sizeof(hip.WgradReduceItem) == 80
 
 
 def test_product_fails_loudly_on_cpu():

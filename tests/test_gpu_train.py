@@ -178,6 +178,97 @@ def test_bn_backward_sums_ride_on_the_consumers_dgrad(force_stages, force_grid, 
     T.tuned_table_changed()
 
 
+def test_shared_tensors_join_their_gradients_in_the_dgrad_epilogues(monkeypatch):
+    """`train_engine.GradJoin`: a tensor with several consumers (a stage input: conv1 + downsample conv [+ FPN lateral conv]; P3:
+    protonet + head + semantic conv; a lateral output: pred conv + upsample; ...) gets its gradient from ONE data-gradient launch
+    that folds the other consumers' gradients in through its epilogue -- no autograd sum (ATen add kernels), and that launch may
+    carry the producer BatchNorm's backward sums.  (a) two stage-first Bottlenecks + a lateral 1x1 conv on the first one's output
+    (modules/resnet.py:20-40,58-70, modules/yolact.py:73-76) against torch CPU autograd; (b) a whole res50 step with the joins on
+    and off: every gradient equal to fp32 rounding, 12 gradients handed on per step."""
+    import torch.nn as nn
+    from yolact_minimal_amd import train_engine as T
+    from yolact_minimal_amd.trainer import Trainer
+
+    class First(nn.Module):                       # a stage's first Bottleneck: stride on conv2 and on the downsample conv
+        def __init__(self, c, p, stride):
+            super().__init__()
+            self.conv1, self.bn1 = nn.Conv2d(c, p, 1, bias=False), nn.BatchNorm2d(p)
+            self.conv2, self.bn2 = nn.Conv2d(p, p, 3, stride, 1, bias=False), nn.BatchNorm2d(p)
+            self.conv3, self.bn3 = nn.Conv2d(p, 4 * p, 1, bias=False), nn.BatchNorm2d(4 * p)
+            self.downsample = nn.Sequential(nn.Conv2d(c, 4 * p, 1, stride, bias=False), nn.BatchNorm2d(4 * p))
+
+        def forward(self, x):
+            y = F.relu(self.bn1(self.conv1(x)))
+            y = F.relu(self.bn2(self.conv2(y)))
+            return F.relu(self.bn3(self.conv3(y)) + self.downsample(x))
+
+    torch.manual_seed(7)
+    b1, b2, lat = First(64, 32, 1).train(), First(128, 32, 2).train(), nn.Conv2d(128, 64, 1)
+    mods = nn.ModuleList([b1, b2, lat])
+    for m in mods.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            nn.init.uniform_(m.weight, 0.5, 1.5)
+            nn.init.normal_(m.bias, 0, 0.2)
+    x = torch.randn(2, 64, 21, 21)
+    g2, gl = torch.randn(2, 128, 11, 11), torch.randn(2, 64, 21, 21)
+    xc = x.clone().requires_grad_()
+    c = b1(xc)
+    ((b2(c) * g2).sum() + (lat(c) * gl).sum()).backward()
+    ref = {n: p.grad.clone() for n, p in mods.named_parameters()}
+    ref_dx = xc.grad.clone()
+    mods.to(DEV)
+    res = {}
+    for join in (False, True):
+        mods.zero_grad(set_to_none=True)
+        T.grad_join_passes[0] = T.bn_bwd_fused_launches[0] = 0
+        xg = _nhwc(x).to(DEV).requires_grad_()
+        T._stats_pool.begin(xg.device)
+        t = xg
+        for blk in (b1, b2):
+            xj = T.GradJoin() if join else None
+            if xj is not None:
+                t._ym_join = xj
+            h = T._conv_bn(t, blk.conv1, blk.bn1, sole_grad=join, xjoin=xj, xrole='take')
+            h = T._conv_bn(h, blk.conv2, blk.bn2, sole_grad=True)
+            skip = T._conv_bn(t, blk.downsample[0], blk.downsample[1], relu=False, xjoin=xj, xrole='pass')
+            t = T._conv_bn(h, blk.conv3, blk.bn3, relu=True, residual=skip, sole_grad=True)
+            if blk is b1:
+                c_dev = t
+        # the lateral conv is created AFTER the next block's convs, like the FPN after the backbone: it runs first and passes
+        p = T._conv_bias(c_dev, lat, xjoin=getattr(c_dev, '_ym_join', None), xrole='pass')
+        ((t * _nhwc(g2).to(DEV)).sum() + (p * _nhwc(gl).to(DEV)).sum()).backward()
+        # x -> b1: downsample passes; c -> b2: lateral + downsample pass; b2.conv1's launch carries b1.bn3's backward sums
+        assert T.grad_join_passes[0] == (3 if join else 0)
+        assert T.bn_bwd_fused_launches[0] == (5 if join else 4)
+        res[join] = ({n: q.grad.cpu().clone() for n, q in mods.named_parameters()}, _nchw(xg.grad).cpu())
+    for n in ref:
+        torch.testing.assert_close(res[True][0][n], res[False][0][n], rtol=2e-5, atol=2e-6, msg=lambda m: f'{n}: {m}')
+        assert float((res[True][0][n] - ref[n]).norm() / ref[n].norm()) < 2e-4, n
+    torch.testing.assert_close(res[True][1], res[False][1], rtol=2e-5, atol=2e-6)
+    assert float((res[True][1] - ref_dx).norm() / ref_dx.norm()) < 2e-4
+
+    # (b) the whole network
+    cfg = build_cfg('res50_coco', 'train', 128, train_bs=2, bs_per_gpu=2)
+    img = torch.randn(2, 3, 128, 128, generator=torch.Generator().manual_seed(1)).to(DEV)
+    boxes, masks = R.synth_targets(2, 128, seed=5)
+    boxes, masks = [t_.to(DEV) for t_ in boxes], [m.to(DEV) for m in masks]
+    grads = {}
+    for join in (False, True):
+        monkeypatch.setattr(T, '_GRAD_JOIN', join)
+        torch.manual_seed(3)
+        torch.cuda.manual_seed(3)
+        tr = Trainer(Yolact(cfg), cfg, torch.device(DEV))
+        T.grad_join_passes[0] = 0
+        tr.step(img, boxes, masks)
+        assert T.grad_join_passes[0] == (12 if join else 0)
+        grads[join] = (tr.opt.grad.clone(), tr)
+    tr = grads[True][1]
+    for q, (lo, hi) in zip(tr.opt.params, tr.opt.offsets):
+        a, b_ = grads[False][0][lo:hi], grads[True][0][lo:hi]
+        scale = float(a.abs().max()) + 1e-12
+        assert float((a - b_).abs().max()) <= 1e-4 * scale + 1e-9, (tuple(q.shape), float((a - b_).abs().max()), scale)
+
+
 @pytest.mark.parametrize('cin,cout,k,stride,hw,b,msplit', [(128, 256, 1, 1, 34, 4, 7), (64, 128, 3, 1, 23, 3, 5), (128, 160, 3, 2, 30, 2, 3),
                                                            (4, 96, 7, 2, 64, 2, 9), (256, 352, 3, 1, 9, 8, 2), (256, 256, 3, 2, 10, 2, 4),
                                                            (128, 192, 1, 1, 3, 1, 1), (64, 64, 3, 1, 21, 2, 3), (256, 64, 1, 1, 17, 3, 2),
@@ -220,6 +311,63 @@ def test_conv_wgrad_staging_variants_agree(cin, cout, k, stride, hw, b, msplit):
         assert torch.equal(outs[nb], outs[2]), f'lds_buffers={nb} differs from the double-buffered variant'
     scale = float(want.abs().max())
     torch.testing.assert_close(outs[2], want, rtol=2e-4, atol=2e-5 * max(1.0, scale))
+
+
+def test_batched_slab_reduction_equals_the_per_layer_launch():
+    """`ym_conv2d_wgrad_slabs` + ONE `ym_wgrad_reduce_batch` over several layers (3x3, 1x1, the padded 4-channel stem, a tensor that
+    does not fill its last 256-thread block) against `ym_conv2d_wgrad` per layer: the same bits; `accumulate` adds to what the
+    destination holds; a gradient routed to several tensors is refused by the slab entry point."""
+    from yolact_minimal_amd import hip
+    from yolact_minimal_amd.hip import WgradDesc, WgradReduceItem
+    L = hip.lib()
+    shapes = [(128, 256, 1, 1, 34, 4, 7, 22), (64, 128, 3, 1, 23, 3, 5, 2), (4, 96, 7, 2, 64, 2, 9, 2), (256, 64, 1, 1, 17, 3, 2, 22),
+              (128, 160, 3, 2, 30, 2, 3, 23), (128, 192, 1, 1, 3, 1, 1, 1)]
+    g = torch.Generator().manual_seed(11)
+    ws = torch.empty(1 << 27, dtype=torch.uint8, device=DEV)
+    keep, items, wants, dsts = [], [], [], []
+    for i, (cin, cout, k, stride, hw, b, msplit, nb) in enumerate(shapes):
+        pad = k // 2
+        ho = (hw + 2 * pad - k) // stride + 1
+        cin_real = 3 if cin == 4 else cin
+        x = torch.zeros(b, hw, hw, cin)
+        x[..., :cin_real] = torch.randn(b, hw, hw, cin_real, generator=g)
+        x, dy = x.to(DEV), torch.randn(b, ho, ho, cout, generator=g).to(DEV)
+        acc = i == 1                                       # one item accumulates into a destination that already holds values
+        base = torch.randn(cout, cin_real, k, k, generator=g).to(DEV)
+        want, dst = base.clone(), base.clone()
+        d = WgradDesc()
+        d.x, d.dy, d.dw = x.data_ptr(), dy.data_ptr(), want.data_ptr()
+        d.B, d.H, d.W, d.Cin, d.Cin_real, d.Cout, d.Cout_real = b, hw, hw, cin, cin_real, cout, cout
+        d.KH, d.KW, d.stride, d.pad, d.Ho, d.Wo, d.msplit, d.lds_buffers, d.accumulate = k, k, stride, pad, ho, ho, msplit, nb, int(acc)
+        hip.check(L.ym_conv2d_wgrad(ctypes.byref(d), ctypes.c_void_p(ws.data_ptr()), ws.numel(), hip.stream_ptr()), 'wgrad')
+        own = torch.empty(L.ym_conv2d_wgrad_workspace_bytes(ctypes.byref(d)), dtype=torch.uint8, device=DEV)
+        d.dw = dst.data_ptr()
+        it = WgradReduceItem()
+        hip.check(L.ym_conv2d_wgrad_slabs(ctypes.byref(d), ctypes.c_void_p(own.data_ptr()), own.numel(), ctypes.byref(it),
+                                          hip.stream_ptr()), 'slabs')
+        assert it.slabs == own.data_ptr() and it.dw == dst.data_ptr() and it.blocks == -(-(cout * k * k * cin // 4) // 256)
+        assert torch.equal(dst, base)                      # nothing reduced yet
+        keep.append((x, dy, own, d))
+        items.append(it)
+        wants.append(want)
+        dsts.append(dst)
+    arr = (WgradReduceItem * len(items))()
+    at = 0
+    for dst_it, it in zip(arr, items):
+        ctypes.memmove(ctypes.byref(dst_it), ctypes.byref(it), ctypes.sizeof(it))
+        dst_it.first_block = at
+        at += it.blocks
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
+    hip.check(L.ym_wgrad_reduce_batch(ctypes.c_void_p(table.data_ptr()), len(items), at, hip.stream_ptr()), 'reduce batch')
+    torch.cuda.synchronize()
+    for (cin, cout, k, *_), w, dgot in zip(shapes, wants, dsts):
+        assert torch.equal(w, dgot), (cin, cout, k, float((w - dgot).abs().max()))
+    # several destination tensors: ym_conv2d_wgrad only
+    x, dy, own, d = keep[1]
+    d.row_end[0], d.row_end[1] = 32, 64
+    d.dw_seg[0], d.dw_seg[1] = dsts[1].data_ptr(), dsts[1].data_ptr()
+    assert L.ym_conv2d_wgrad_slabs(ctypes.byref(d), ctypes.c_void_p(own.data_ptr()), own.numel(), ctypes.byref(items[1]), hip.stream_ptr()) != 0
+    assert L.ym_wgrad_reduce_batch(None, 0, 0, hip.stream_ptr()) != 0
 
 
 def test_pool_and_upsample_backward():
@@ -1056,6 +1204,8 @@ def test_side_stream_gradients_equal_single_stream(cfg_name, fused_head, monkeyp
     ref, g_ref = run(False, False)
     tst, g_tst = run(True, True)
     assert any(getattr(p, '_ym_side_written', False) for p in tst.opt.params)       # the side stream was really used
+    # ... and its slab reductions ran batched (ym_wgrad_reduce_batch): several layers per launch, against per-layer launches in `ref`
+    assert T.wgrad_reduce_launches[1] > 3 * T.wgrad_reduce_launches[0] > 0, T.wgrad_reduce_launches
     for step, (a, b) in enumerate(zip(g_ref, g_tst)):
         for p, (lo, hi) in zip(ref.opt.params, ref.opt.offsets):
             x, y = a[lo:hi], b[lo:hi]

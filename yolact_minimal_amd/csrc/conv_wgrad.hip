@@ -434,6 +434,60 @@ __global__ __launch_bounds__(256) void wgrad_reduce_unpack(const float* __restri
     }
 }
 
+// The same reduction for MANY weight gradients in one launch (ym_wgrad_reduce_batch): a res101 step has 104 backbone weight
+// gradients, each followed by its own 5-20 us reduce launch; their slabs stay in per-layer scratch instead and one launch per
+// gradient bucket reduces them all.  Block b belongs to the item with first_block <= b < first_block + blocks (binary search over
+// the table, block-uniform); thread = four input channels of one (output channel, tap), exactly wgrad_reduce_unpack's unit, slabs
+// summed in the same order -> the same bits.
+struct WRItemDev {
+    const float* ws; float* dw;
+    unsigned first_block, blocks, quads, slab_hi;      // slab = floats per slab (lo | hi << 32)
+    unsigned slab_lo; int msplit, Ktot, Cin_real, KHW, accumulate;
+    FastDiv fd_ktot4, fd_cinp4;
+};
+static_assert(sizeof(WRItemDev) == sizeof(ym_wgrad_reduce_item), "ym_wgrad_reduce_item must mirror WRItemDev");
+
+__global__ __launch_bounds__(256) void wgrad_reduce_batch(const WRItemDev* __restrict__ items, int n_items) {
+    int lo = 0, hi = n_items - 1;
+    const unsigned b = blockIdx.x;
+    while (lo < hi) {                                   // last item with first_block <= b
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].first_block <= b) lo = mid; else hi = mid - 1;
+    }
+    const WRItemDev it = items[lo];
+    const unsigned q = (b - it.first_block) * 256u + threadIdx.x;
+    if (q >= it.quads) return;
+    unsigned un, ukk4, utap, uci4;
+    it.fd_ktot4.divmod(q, un, ukk4);
+    it.fd_cinp4.divmod(ukk4, utap, uci4);
+    const int n = (int)un, tap = (int)utap, ci = (int)uci4 * 4;
+    if (ci >= it.Cin_real) return;
+    const size_t slab = (size_t)it.slab_lo | ((size_t)it.slab_hi << 32);
+    const float* src = it.ws + (size_t)n * it.Ktot + (size_t)ukk4 * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(src);
+    int s = 1;
+    for (; s + 3 < it.msplit; s += 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src + (size_t)s * slab), b4 = *reinterpret_cast<const f32x4*>(src + (size_t)(s + 1) * slab);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(src + (size_t)(s + 2) * slab), d = *reinterpret_cast<const f32x4*>(src + (size_t)(s + 3) * slab);
+        v += a; v += b4; v += c; v += d;
+    }
+    for (; s < it.msplit; ++s) v += *reinterpret_cast<const f32x4*>(src + (size_t)s * slab);
+    float* dst = it.dw + ((size_t)n * it.Cin_real + ci) * it.KHW + tap;
+    if (it.KHW == 1 && (it.Cin_real & 3) == 0 && ((uintptr_t)dst & 15) == 0) {
+        f32x4 w = v;
+        if (it.accumulate) w += *reinterpret_cast<const f32x4*>(dst);
+        *reinterpret_cast<f32x4*>(dst) = w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (ci + e < it.Cin_real) {
+                float* d1 = dst + (size_t)e * it.KHW;
+                *d1 = it.accumulate ? *d1 + v[e] : v[e];
+            }
+        }
+    }
+}
+
 struct WPlan { int M, Ktot, tiles_n, tiles_k, msplit, m_per_split, tbn, nb; };
 
 void fastdiv_make(unsigned d, unsigned* mg, unsigned* sh) {
@@ -490,10 +544,10 @@ extern "C" size_t ym_conv2d_wgrad_workspace_bytes(const ym_wgrad_desc* d) {
     return (size_t)pl.msplit * d->Cout * pl.Ktot * sizeof(float);
 }
 
-extern "C" int ym_conv2d_wgrad(const ym_wgrad_desc* d, void* workspace, size_t workspace_bytes, ym_stream_t s) {
-    WPlan pl;
-    int rc = wplan(d, &pl);
-    if (rc != YM_OK) return rc;
+namespace {
+// first pass: msplit partial gradients [msplit][Cout][Ktot] into the workspace
+int wgrad_slabs(const ym_wgrad_desc* d, const WPlan& pl, void* workspace, size_t workspace_bytes, ym_stream_t s) {
+    int rc = YM_OK;
     const size_t need = (size_t)pl.msplit * d->Cout * pl.Ktot * sizeof(float);
     if (!workspace || workspace_bytes < need) { ym_set_error("wgrad: workspace %zu B < %zu B", workspace_bytes, need); return YM_ENOSPC; }
     WgradP p;
@@ -544,7 +598,17 @@ extern "C" int ym_conv2d_wgrad(const ym_wgrad_desc* d, void* workspace, size_t w
 #undef YM_WG_LAUNCH
 #undef YM_WG_LAUNCH_DL
     rc = ym_check_launch("conv_wgrad_f32");
+    return rc;
+}
+}  // namespace
+
+extern "C" int ym_conv2d_wgrad(const ym_wgrad_desc* d, void* workspace, size_t workspace_bytes, ym_stream_t s) {
+    WPlan pl;
+    int rc = wplan(d, &pl);
     if (rc != YM_OK) return rc;
+    rc = wgrad_slabs(d, pl, workspace, workspace_bytes, s);
+    if (rc != YM_OK) return rc;
+    hipStream_t st = (hipStream_t)s;
     const size_t total = (size_t)d->Cout_real * pl.Ktot;
     YM_REQUIRE(pl.Ktot % 4 == 0 && d->Cin % 4 == 0 && ((uintptr_t)workspace & 15) == 0, "wgrad: reduce needs K %% 4 == 0 and a 16-byte aligned workspace");
     int grid = (int)((total / 4 + 255) / 256);
@@ -564,4 +628,33 @@ extern "C" int ym_conv2d_wgrad(const ym_wgrad_desc* d, void* workspace, size_t w
     hipLaunchKernelGGL(wgrad_reduce_unpack, dim3(grid), dim3(256), 0, st, (const float*)workspace, o, pl.msplit, d->Cout_real,
                        d->Cout, pl.Ktot, d->Cin, d->Cin_real, d->KH * d->KW, FastDiv::make((unsigned)pl.Ktot / 4), FastDiv::make((unsigned)d->Cin / 4));
     return ym_check_launch("wgrad_reduce_unpack");
+}
+
+extern "C" int ym_conv2d_wgrad_slabs(const ym_wgrad_desc* d, void* workspace, size_t workspace_bytes, ym_wgrad_reduce_item* item,
+                                     ym_stream_t s) {
+    WPlan pl;
+    int rc = wplan(d, &pl);
+    if (rc != YM_OK) return rc;
+    YM_REQUIRE(item, "wgrad(slabs): null item");
+    YM_REQUIRE(d->row_end[0] == 0, "wgrad(slabs): a gradient routed to several tensors takes ym_conv2d_wgrad");
+    YM_REQUIRE(pl.Ktot % 4 == 0 && d->Cin % 4 == 0 && ((uintptr_t)workspace & 15) == 0, "wgrad: reduce needs K %% 4 == 0 and a 16-byte aligned workspace");
+    const size_t quads = (size_t)d->Cout_real * pl.Ktot / 4;
+    YM_REQUIRE(quads < (1ull << 31), "wgrad: gradient tensor too large for 32-bit indexing");
+    rc = wgrad_slabs(d, pl, workspace, workspace_bytes, s);
+    if (rc != YM_OK) return rc;
+    WRItemDev it = {};
+    it.ws = (const float*)workspace; it.dw = d->dw;
+    it.first_block = 0; it.blocks = (unsigned)((quads + 255) / 256); it.quads = (unsigned)quads;
+    const size_t slab = (size_t)d->Cout * pl.Ktot;
+    it.slab_lo = (unsigned)(slab & 0xFFFFFFFFull); it.slab_hi = (unsigned)(slab >> 32);
+    it.msplit = pl.msplit; it.Ktot = pl.Ktot; it.Cin_real = d->Cin_real; it.KHW = d->KH * d->KW; it.accumulate = d->accumulate ? 1 : 0;
+    it.fd_ktot4 = FastDiv::make((unsigned)pl.Ktot / 4); it.fd_cinp4 = FastDiv::make((unsigned)d->Cin / 4);
+    *reinterpret_cast<WRItemDev*>(item) = it;
+    return YM_OK;
+}
+
+extern "C" int ym_wgrad_reduce_batch(const ym_wgrad_reduce_item* items_dev, int n_items, unsigned total_blocks, ym_stream_t s) {
+    YM_REQUIRE(items_dev && n_items > 0 && total_blocks > 0, "wgrad(reduce batch): empty table");
+    hipLaunchKernelGGL(wgrad_reduce_batch, dim3(total_blocks), dim3(256), 0, (hipStream_t)s, (const WRItemDev*)items_dev, n_items);
+    return ym_check_launch("wgrad_reduce_batch");
 }

@@ -23,7 +23,7 @@ ABI_SYMBOLS = (
     'ym_greedy_nms_workspace_bytes', 'ym_greedy_nms', 'ym_mask_assemble', 'ym_mask_resize_binarize',
     'ym_boxes_to_pixels', 'ym_expf_cr', 'ym_nms_batch_workspace_bytes', 'ym_detect_fast_nms_batch', 'ym_after_nms_batch_workspace_bytes',
     'ym_after_nms_batch', 'ym_head_grad_gather', 'ym_scatter3',
-    'ym_pack_conv_weight_dgrad', 'ym_pack_conv_weights_batch', 'ym_conv2d_wgrad_workspace_bytes', 'ym_conv2d_wgrad', 'ym_bn_train_fwd',
+    'ym_pack_conv_weight_dgrad', 'ym_pack_conv_weights_batch', 'ym_conv2d_wgrad_workspace_bytes', 'ym_conv2d_wgrad', 'ym_conv2d_wgrad_slabs', 'ym_wgrad_reduce_batch', 'ym_bn_train_fwd',
     'ym_val_preprocess', 'ym_layernorm', 'ym_patch_merge_layernorm', 'ym_swin_window_attention',
     'ym_mask_loss_workspace_bytes', 'ym_mask_loss_fwd_bwd', 'ym_mask_loss_batch_workspace_bytes', 'ym_mask_loss_batch',
     'ym_mask_iou_workspace_bytes', 'ym_mask_iou', 'ym_box_iou', 'ym_match_detections', 'ym_rle_encode', 'ym_ann_to_mask_workspace_bytes', 'ym_poly_to_mask', 'ym_runs_to_mask', 'ym_train_aug_image', 'ym_train_aug_masks',
@@ -64,6 +64,11 @@ class WgradDesc(ctypes.Structure):
                 ('KH', ctypes.c_int32), ('KW', ctypes.c_int32), ('stride', ctypes.c_int32), ('pad', ctypes.c_int32),
                 ('Ho', ctypes.c_int32), ('Wo', ctypes.c_int32), ('msplit', ctypes.c_int32), ('accumulate', ctypes.c_int32),
                 ('row_end', ctypes.c_int32 * 2), ('dw_seg', ctypes.c_void_p * 2), ('lds_buffers', ctypes.c_int32)]
+
+
+class WgradReduceItem(ctypes.Structure):
+    _fields_ = [('slabs', ctypes.c_void_p), ('dw', ctypes.c_void_p), ('first_block', ctypes.c_uint32), ('blocks', ctypes.c_uint32),
+                ('plan', ctypes.c_uint32 * 14)]
 
 
 class AugPlanC(ctypes.Structure):
@@ -146,6 +151,8 @@ def lib():
         L.ym_conv2d_wgrad_workspace_bytes.argtypes = [ctypes.POINTER(WgradDesc)]
         L.ym_conv2d_wgrad_workspace_bytes.restype = sz
         L.ym_conv2d_wgrad.argtypes = [ctypes.POINTER(WgradDesc), vp, sz, vp]
+        L.ym_conv2d_wgrad_slabs.argtypes = [ctypes.POINTER(WgradDesc), vp, sz, ctypes.POINTER(WgradReduceItem), vp]
+        L.ym_wgrad_reduce_batch.argtypes = [vp, i32, ctypes.c_uint32, vp]
         L.ym_bn_train_fwd.argtypes = [vp, i64, i32, vp, vp, f32, f32, vp, vp, vp, i32, vp, vp, vp, vp, sz, vp]
         L.ym_val_preprocess.argtypes = [vp, i32, i32, i32, i32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), vp, vp]
         L.ym_layernorm.argtypes = [vp, vp, vp, f32, vp, i64, i32, vp]

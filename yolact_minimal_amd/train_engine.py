@@ -523,6 +523,7 @@ def wgrad_stream_if_used(device):
     otherwise.  Collectives over gradients are issued from it (trainer.FlatGradReducer)."""
     s = _side_streams.get(_dev_key(device))
     if s is not None:
+        flush_wgrad_reduces(device)                  # the bucket about to be all-reduced must hold finished gradients
         for e in _extra_streams.get(_dev_key(device), ()):
             s.wait_stream(e)
     return s
@@ -554,6 +555,7 @@ def wgrad_stream(device, ordered=True):
 
 def join_wgrad_stream(device):
     """Main stream waits for every weight gradient enqueued so far (call before the optimizer step / a gradient all-reduce)."""
+    flush_wgrad_reduces(device)
     s = _side_streams.get(_dev_key(device))
     if s is not None:
         torch.cuda.current_stream(_dev_key(device)).wait_stream(s)
@@ -582,6 +584,57 @@ def _keep_for_side(device, side, *tensors):
         q.popleft()
 
 
+# ---- batched slab reductions ----------------------------------------------------------------------------------------------------
+# A weight gradient is a slab pass (msplit partial gradients over pixel ranges) + a reduction that sums the slabs in order and
+# scatters into OIHW.  On the side stream the reduction of every layer was its own 5-20 us launch (128 per res101 step, 3 ms of
+# kernel time next to the data-gradient chain).  Inside `wgrad_on_side_stream` the slabs of single-destination gradients stay in
+# per-layer scratch instead (persistent: ~2 GB for res101 at batch 8) and ONE `ym_wgrad_reduce_batch` launch reduces every pending
+# layer: when YM_WGRAD_REDUCE_BATCH layers are pending, before a gradient bucket is all-reduced (`wgrad_stream_if_used`) and when
+# the streams join.  Same sums in the same order as the per-layer launch.  YM_WGRAD_REDUCE_BATCH=0: per-layer launches.
+_REDUCE_BATCH = int(os.environ.get('YM_WGRAD_REDUCE_BATCH', '24'))
+_slab_arena = {}          # (device, destination pointer) -> that layer's private slab scratch
+_pending_reduce = {}      # device -> [WgradReduceItem]
+_reduce_tables = {}       # (device, the items' bytes) -> (device copy of the item table, total blocks)
+wgrad_reduce_launches = [0, 0]       # [batched launches, layers reduced by them] (tests / tools look at it)
+
+
+def release_wgrad_scratch():
+    """Drop the per-layer slab scratch and the cached item tables (a new Trainer calls this: the arena is keyed by gradient-slot
+    addresses, which belong to the previous trainer's flat buffer)."""
+    for dev, items in _pending_reduce.items():
+        if items:
+            raise RuntimeError('release_wgrad_scratch() with slab reductions still pending')
+    _slab_arena.clear()
+    _reduce_tables.clear()
+
+
+def flush_wgrad_reduces(device):
+    """Launch the pending slab reductions (on the side stream: that is where their slab passes ran)."""
+    device = _dev_key(device)
+    items = _pending_reduce.get(device)
+    if not items:
+        return
+    _pending_reduce[device] = []
+    key = (device, b''.join(bytes(it) for it in items))          # (pointers and plans are the same every step: the table is built once)
+    ent = _reduce_tables.get(key)
+    if ent is None:
+        arr = (hip.WgradReduceItem * len(items))()
+        at = 0
+        for dst, it in zip(arr, items):
+            ctypes.memmove(ctypes.byref(dst), ctypes.byref(it), ctypes.sizeof(it))
+            dst.first_block = at
+            at += it.blocks
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        ent = _reduce_tables[key] = (host.to(device), at)          # (pageable H2D: synchronous, once per table)
+    table, total = ent
+    side = _side_streams[device]
+    with torch.cuda.stream(side):
+        hip.check(hip.lib().ym_wgrad_reduce_batch(ctypes.c_void_p(table.data_ptr()), len(items), total, hip.stream_ptr()),
+                  'ym_wgrad_reduce_batch')
+    wgrad_reduce_launches[0] += 1
+    wgrad_reduce_launches[1] += len(items)
+
+
 def _conv_wgrad(x, dz, weight_shape, stride, pad, weight_param=None, dw=None, accumulate=False, segments=None, owners=None):
     """`owners`: the parameters a caller-owned `dw` (+ `segments` destinations) belong to (default: `weight_param`)."""
     if not _side_active[0] or not x.is_cuda:
@@ -599,17 +652,22 @@ def _conv_wgrad(x, dz, weight_shape, stride, pad, weight_param=None, dw=None, ac
         return _conv_wgrad_now(x, dz, weight_shape, stride, pad, weight_param, dw, accumulate, segments)
     side = wgrad_stream(x.device, ordered=shared_dst)
     side.wait_stream(torch.cuda.current_stream(x.device))          # x, dz (and earlier accumulations into dw) are ready
+    # (a caller-owned destination is accumulated into by several launches of one step: those reduce at once, in order)
+    defer = _REDUCE_BATCH > 0 and _N_SIDE <= 1 and not shared_dst and segments is None and not accumulate
     with torch.cuda.stream(side):
-        _conv_wgrad_now(x, dz, weight_shape, stride, pad, weight_param, dw, accumulate, segments)
+        _conv_wgrad_now(x, dz, weight_shape, stride, pad, weight_param, dw, accumulate, segments, defer=defer)
+    if defer and len(_pending_reduce.get(_dev_key(x.device), ())) >= _REDUCE_BATCH:
+        flush_wgrad_reduces(x.device)
     _keep_for_side(x.device, side, x, dz)                          # neither recycled nor summed into in place until the side stream is past
     for o in owners:
         getattr(o, '_ym_owner', o)._ym_side_written = True
     return dw
 
 
-def _conv_wgrad_now(x, dz, weight_shape, stride, pad, weight_param=None, dw=None, accumulate=False, segments=None):
+def _conv_wgrad_now(x, dz, weight_shape, stride, pad, weight_param=None, dw=None, accumulate=False, segments=None, defer=False):
     """`dw`: destination OIHW tensor (default: the parameter's gradient slot / a fresh tensor).  `accumulate`: dw += gradient.
-    `segments` = (row_end0, row_end1, dw1, dw2): output channels [0,row_end0) -> dw, [row_end0,row_end1) -> dw1, the rest -> dw2."""
+    `segments` = (row_end0, row_end1, dw1, dw2): output channels [0,row_end0) -> dw, [row_end0,row_end1) -> dw1, the rest -> dw2.
+    `defer`: slab pass only, into this layer's private scratch; the reduction joins the next `flush_wgrad_reduces`."""
     cout, cin, kh, kw = weight_shape
     b, h, w, cin_p = x.shape
     if dw is None:
@@ -636,6 +694,17 @@ def _conv_wgrad_now(x, dz, weight_shape, stride, pad, weight_param=None, dw=None
     d.accumulate = int(accumulate)
     if segments is not None:
         d.dw_seg[0], d.dw_seg[1] = segments[2].data_ptr(), segments[3].data_ptr()
+    if defer:
+        dev = _dev_key(x.device)
+        akey = (dev, dw.data_ptr())                      # per DESTINATION (= per layer: layers of one shape share `key`)
+        ws = _slab_arena.get(akey)
+        if ws is None or ws.numel() < nbytes:
+            ws = _slab_arena[akey] = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        item = hip.WgradReduceItem()
+        hip.check(hip.lib().ym_conv2d_wgrad_slabs(ctypes.byref(d), ctypes.c_void_p(ws.data_ptr()), ws.numel(), ctypes.byref(item),
+                                                  hip.stream_ptr()), 'ym_conv2d_wgrad_slabs')
+        _pending_reduce.setdefault(dev, []).append(item)
+        return dw
     ws = scratch(x.device, nbytes)
     hip.check(hip.lib().ym_conv2d_wgrad(ctypes.byref(d), ctypes.c_void_p(ws.data_ptr()), ws.numel(), hip.stream_ptr()),
               'ym_conv2d_wgrad')
@@ -647,7 +716,9 @@ class ConvBias(torch.autograd.Function):
     gradient is needed).  Replaces conv+bias+ReLU/tanh of FPN / ProtoNet / head (modules/yolact.py:18-30,37-47,62-68)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, act, cout_pad, residual=None):
+    def forward(ctx, x, weight, bias, stride, pad, act, cout_pad, residual=None, xjoin=None, xrole=None, producer=None):
+        ctx.xjoin, ctx.xrole = xjoin, xrole
+        ctx.producer = producer          # BnGradLink of the ConvBn that produced x, when this conv's dgrad writes x's WHOLE gradient
         cout, cin, kh, kw = weight.shape
         wp, k_pad = _pack_fwd(weight, x.shape[-1], cout_pad)
         shift = None
@@ -693,10 +764,13 @@ class ConvBias(torch.autograd.Function):
             hip.check(hip.lib().ym_act_bias_bwd(hip.ptr(dy), y_ptr, m, c, act, hip.ptr(dz), None, None, 0, hip.stream_ptr()),
                       'ym_act_bias_bwd')
         dw = _conv_wgrad(x, dz, weight.shape, stride, pad, weight)          # (side stream: overlaps the data gradient below)
-        dx = _conv_dgrad(dz, weight, cout_pad, x.shape, stride, pad) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            add = _join_add(ctx.xjoin)
+            dx = _join_result(ctx.xjoin, ctx.xrole, _conv_dgrad(dz, weight, cout_pad, x.shape, stride, pad, add, bn_bwd=ctx.producer))
         if dbias is not None and cout_pad != weight.shape[0]:
             dbias = dbias[:weight.shape[0]].contiguous()
-        return dx, dw, dbias, None, None, None, None, (dz if has_res else None)
+        return dx, dw, dbias, None, None, None, None, (dz if has_res else None), None, None, None
 
 
 class _HeadWeights:
@@ -747,7 +821,8 @@ class PredictionHead(torch.autograd.Function):
     (the reference's autograd sums five per-level gradients with separate kernels)."""
 
     @staticmethod
-    def forward(ctx, w_up, b_up, w_conf, b_conf, w_box, b_box, w_coef, b_coef, hd, nc, cd, na, *levels):
+    def forward(ctx, w_up, b_up, w_conf, b_conf, w_box, b_box, w_coef, b_coef, hd, nc, cd, na, joins, *levels):
+        ctx.joins = joins if joins is not None else (None,) * len(levels)
         dev = levels[0].device
         bsz = levels[0].shape[0]
         shapes = [(lv.shape[1], lv.shape[2]) for lv in levels]
@@ -827,9 +902,16 @@ class PredictionHead(torch.autograd.Function):
         for l, lv in enumerate(levels):
             h, w = shapes[l]
             dzu = dzu_all[row_off[l]:row_off[l + 1]].view(bsz, h, w, 256)
-            dlevels.append(_conv_dgrad(dzu, w_up, 256, lv.shape, 1, 1) if ctx.needs_input_grad[12 + l] else None)
+            if ctx.needs_input_grad[13 + l]:
+                # (a level with other consumers -- P3: protonet + semantic conv, P5 / P6: the stride-2 convs -- hands its gradient on
+                # through the level's GradJoin instead of returning it: no autograd sum)
+                j = ctx.joins[l]
+                dlevels.append(_join_result(j, 'pass' if j is not None else None,
+                                            _conv_dgrad(dzu, w_up, 256, lv.shape, 1, 1, _join_add(j))))
+            else:
+                dlevels.append(None)
             _conv_wgrad(lv, dzu, tuple(w_up.shape), 1, 1, dw=dw_up, accumulate=l > 0, owners=(w_up,))
-        return (dw_up, db_up, dw[0], db[0], dw[1], db[1], dw[2], db[2], None, None, None, None, *dlevels)
+        return (dw_up, db_up, dw[0], db[0], dw[1], db[1], dw[2], db[2], None, None, None, None, None, *dlevels)
 
 
 class ResGradLink:
@@ -840,6 +922,43 @@ class ResGradLink:
 
     def __init__(self):
         self.grad = None
+
+
+class GradJoin:
+    """A tensor with several consumers (a stage input feeds conv1 and the downsample conv, C3 / C4 also the FPN lateral conv; P3 feeds
+    the protonet, the prediction head and the semantic conv; ...): autograd would sum the consumers' gradients with one elementwise
+    kernel per extra consumer (ATen's, 14 per res101 step).  Instead the consumers form a chain through this object: autograd runs
+    the nodes of one device in strictly decreasing creation order, so the consumer created LAST runs its backward FIRST; every
+    consumer but the first-created one has the role 'pass' (its data-gradient launch adds what is parked here in its epilogue,
+    parks the sum here and returns None), and the first-created one 'take's: its launch adds the parked sum and returns the WHOLE
+    gradient of the tensor -- which also lets it carry the BatchNorm-backward sums of the tensor's producer (`sole_grad`).
+    Same summation order as autograd's (arrival order).  ResGradLink is the two-consumer special case where the giver is a
+    residual add rather than a convolution."""
+    __slots__ = ('grad',)
+
+    def __init__(self):
+        self.grad = None
+
+
+_GRAD_JOIN = os.environ.get('YM_GRAD_JOIN', '1') != '0'
+grad_join_passes = [0]           # gradients handed on through a GradJoin instead of an autograd sum (tests look at it)
+
+
+def _join_add(join):
+    """What the earlier-run consumers of the tensor parked (None for the first one to run)."""
+    if join is None:
+        return None
+    add, join.grad = join.grad, None
+    return add
+
+
+def _join_result(join, role, dx):
+    """'pass': park the running sum and return nothing to autograd; 'take' / no join: the gradient itself."""
+    if join is not None and role == 'pass':
+        join.grad = dx
+        grad_join_passes[0] += 1
+        return None
+    return dx
 
 
 class BnGradLink:
@@ -863,8 +982,9 @@ class ConvBn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, running_mean, running_var, residual, stride, pad, relu, momentum, eps, link=None,
-                role=None, producer=None, own=None):
+                role=None, producer=None, own=None, xjoin=None, xrole=None):
         ctx.link, ctx.role = link, role
+        ctx.xjoin, ctx.xrole = xjoin, xrole
         ctx.producer, ctx.own = producer, own
         cout, cin, kh, kw = weight.shape
         wp, k_pad = _pack_fwd(weight, x.shape[-1], cout)
@@ -934,9 +1054,14 @@ class ConvBn(torch.autograd.Function):
                 ctx.link.grad, dres = dres, None                  # handed to the consumer that shares the tensor
             elif ctx.role == 'take' and need_dx:
                 add, ctx.link.grad = ctx.link.grad, None
+        if need_dx and ctx.xjoin is not None:
+            assert add is None
+            add = _join_add(ctx.xjoin)
         dw = _conv_wgrad(x, dy, weight.shape, stride, pad, weight)          # (side stream: overlaps the data gradient below)
         dx = _conv_dgrad(dy, weight, cout, x.shape, stride, pad, add, bn_bwd=ctx.producer) if need_dx else None
-        return dx, dw, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None, None
+        if need_dx:
+            dx = _join_result(ctx.xjoin, ctx.xrole, dx)
+        return dx, dw, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None, None, None, None
 
 
 class MaxPool(torch.autograd.Function):
@@ -967,7 +1092,8 @@ class MaxPool(torch.autograd.Function):
 
 class Bilinear2x(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, align):
+    def forward(ctx, x, align, xjoin=None):
+        ctx.xjoin = xjoin                 # x has an earlier-created consumer that 'take's (GradJoin): this node passes its gradient on
         b, h, w, c = x.shape
         out = torch.empty(b, 2 * h, 2 * w, c, device=x.device, dtype=torch.float32)
         hip.bilinear2x(x, out, align)
@@ -980,16 +1106,20 @@ class Bilinear2x(torch.autograd.Function):
         dx = torch.empty(b, h, w, c, device=dy.device, dtype=torch.float32)
         hip.check(hip.lib().ym_bilinear2x_bwd(hip.ptr(dy.contiguous()), hip.ptr(dx), b, h, w, c, int(align), hip.stream_ptr()),
                   'ym_bilinear2x_bwd')
-        return dx, None
+        if ctx.xjoin is not None:
+            assert ctx.xjoin.grad is None, 'Bilinear2x must be the last-created consumer of its input'
+            return _join_result(ctx.xjoin, 'pass', dx), None, None
+        return dx, None, None
 
 
-def _conv_bn(x, conv, bn, relu=True, residual=None, link=None, role=None, sole_grad=False):
+def _conv_bn(x, conv, bn, relu=True, residual=None, link=None, role=None, sole_grad=False, xjoin=None, xrole=None):
     """`sole_grad`: this conv's data-gradient launch writes the WHOLE gradient of x (x has no other consumer, or this is the
-    ResGradLink 'take' end that folds the other one in) -> it may carry the backward statistics of the BN that produced x."""
+    ResGradLink / GradJoin 'take' end that folds the others in) -> it may carry the backward statistics of the BN that produced x.
+    `xjoin`, `xrole`: x has several consumers, chained through a GradJoin (this one 'take's or 'pass'es)."""
     producer = getattr(x, '_ym_bn_link', None) if (sole_grad and _FUSE_BN_BWD) else None
     own = BnGradLink() if _FUSE_BN_BWD else None
     out = ConvBn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, conv.stride[0],
-                       conv.padding[0], relu, float(bn.momentum), float(bn.eps), link, role, producer, own)
+                       conv.padding[0], relu, float(bn.momentum), float(bn.eps), link, role, producer, own, xjoin, xrole)
     if own is not None:
         out._ym_bn_link = own
     if not getattr(bn, '_ym_nbt_flat', False):               # the trainer bumps all counters with one launch
@@ -997,9 +1127,12 @@ def _conv_bn(x, conv, bn, relu=True, residual=None, link=None, role=None, sole_g
     return out
 
 
-def _conv_bias(x, conv, act=ACT_NONE, cout_pad=None, residual=None):
+def _conv_bias(x, conv, act=ACT_NONE, cout_pad=None, residual=None, xjoin=None, xrole=None, sole_grad=False):
+    """`sole_grad`: as in `_conv_bn` (C5's only consumer is the FPN lateral conv: its dgrad carries layer4's last bn3 sums)."""
     cout = conv.out_channels
-    return ConvBias.apply(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], act, cout_pad or cout, residual)
+    producer = getattr(x, '_ym_bn_link', None) if (sole_grad and _FUSE_BN_BWD) else None
+    return ConvBias.apply(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], act, cout_pad or cout, residual, xjoin, xrole,
+                          producer)
 
 
 _FUSE_RES_GRAD = os.environ.get('YM_FUSE_RES_GRAD', '1') != '0'
@@ -1024,28 +1157,49 @@ def train_features(net, img):
             for blk in stage:
                 # identity blocks: x feeds conv1 and the residual add; their two gradients meet in conv1's dgrad epilogue
                 link = ResGradLink() if (blk.downsample is None and x.requires_grad and _FUSE_RES_GRAD) else None
-                # (with the link, conv1's dgrad writes the whole gradient of x: it also carries the previous bn3's backward sums)
-                y = _conv_bn(x, blk.conv1, blk.bn1, link=link, role='take', sole_grad=link is not None)
+                # a stage's first block: x feeds conv1 and the downsample conv (C3 / C4 later also the FPN lateral conv): GradJoin,
+                # conv1 'take's.  Either way conv1's dgrad writes the whole gradient of x and carries the previous bn3's backward sums
+                xj = GradJoin() if (blk.downsample is not None and x.requires_grad and _GRAD_JOIN) else None
+                if xj is not None:
+                    x._ym_join = xj
+                y = _conv_bn(x, blk.conv1, blk.bn1, link=link, role='take', sole_grad=link is not None or xj is not None,
+                             xjoin=xj, xrole='take')
                 y = _conv_bn(y, blk.conv2, blk.bn2, sole_grad=True)
-                skip = _conv_bn(x, blk.downsample[0], blk.downsample[1], relu=False) if blk.downsample is not None else x
+                skip = _conv_bn(x, blk.downsample[0], blk.downsample[1], relu=False, xjoin=xj, xrole='pass') \
+                    if blk.downsample is not None else x
                 x = _conv_bn(y, blk.conv3, blk.bn3, relu=True, residual=skip, link=link, role='give', sole_grad=True)
             outs.append(x)
         c3, c4, c5 = outs[1:4]
+
+    def join_of(t):                  # the GradJoin a backbone tensor already has (C3 / C4: the next stage's conv1 takes), for a 'pass'
+        return getattr(t, '_ym_join', None)
+
+    def new_join(t):
+        return GradJoin() if (_GRAD_JOIN and t.requires_grad) else None
+
+    # Consumers of a shared tensor are created taker first (see GradJoin): each pred conv before the upsample of its input, the
+    # protonet / stride-2 convs before the prediction head.
     fpn = net.fpn
-    p5_1 = _conv_bias(c5, fpn.lat_layers[2])
-    p4_1 = _conv_bias(c4, fpn.lat_layers[1], residual=Bilinear2x.apply(p5_1, False))     # top-down add fused
-    p3_1 = _conv_bias(c3, fpn.lat_layers[0], residual=Bilinear2x.apply(p4_1, False))
-    p5 = _conv_bias(p5_1, fpn.pred_layers[2][0], ACT_RELU)
-    p4 = _conv_bias(p4_1, fpn.pred_layers[1][0], ACT_RELU)
+    p5_1 = _conv_bias(c5, fpn.lat_layers[2], sole_grad=True)
+    j = new_join(p5_1)
+    p5 = _conv_bias(p5_1, fpn.pred_layers[2][0], ACT_RELU, xjoin=j, xrole='take')
+    p4_1 = _conv_bias(c4, fpn.lat_layers[1], residual=Bilinear2x.apply(p5_1, False, j),      # top-down add fused
+                      xjoin=join_of(c4), xrole='pass')
+    j = new_join(p4_1)
+    p4 = _conv_bias(p4_1, fpn.pred_layers[1][0], ACT_RELU, xjoin=j, xrole='take')
+    p3_1 = _conv_bias(c3, fpn.lat_layers[0], residual=Bilinear2x.apply(p4_1, False, j), xjoin=join_of(c3), xrole='pass')
     p3 = _conv_bias(p3_1, fpn.pred_layers[0][0], ACT_RELU)
-    p6 = _conv_bias(p5, fpn.downsample_layers[0][0], ACT_RELU)
-    p7 = _conv_bias(p6, fpn.downsample_layers[1][0], ACT_RELU)
+    j5, j6, j3 = new_join(p5), None, new_join(p3)
+    p6 = _conv_bias(p5, fpn.downsample_layers[0][0], ACT_RELU, xjoin=j5, xrole='take')
+    j6 = new_join(p6)
+    p7 = _conv_bias(p6, fpn.downsample_layers[1][0], ACT_RELU, xjoin=j6, xrole='take')
     levels = [p3, p4, p5, p6, p7]
+    level_joins = (j3, None, j5, j6, None)
 
     pn = net.proto_net
     y = p3
     for i in (0, 2, 4):
-        y = _conv_bias(y, pn.proto1[i], ACT_RELU)
+        y = _conv_bias(y, pn.proto1[i], ACT_RELU, xjoin=j3 if i == 0 else None, xrole='take')
     y = Bilinear2x.apply(y, True)
     y = _conv_bias(y, pn.proto2[0], ACT_RELU)
     proto = _conv_bias(y, pn.proto2[2], ACT_RELU)                 # NHWC [B,Hp,Wp,32] == proto_out layout
@@ -1055,8 +1209,8 @@ def train_features(net, img):
     if os.environ.get('YM_FUSED_HEAD', '1') != '0':
         conf_all, box_all, coef_all = PredictionHead.apply(
             hd.upfeature[0].weight, hd.upfeature[0].bias, hd.conf_layer.weight, hd.conf_layer.bias, hd.bbox_layer.weight,
-            hd.bbox_layer.bias, hd.coef_layer[0].weight, hd.coef_layer[0].bias, hd, nc, cd, na, *levels)
-        seg = _conv_bias(p3, net.semantic_seg_conv, ACT_NONE, _ru(nc - 1, 32))[..., :nc - 1].permute(0, 3, 1, 2)
+            hd.bbox_layer.bias, hd.coef_layer[0].weight, hd.coef_layer[0].bias, hd, nc, cd, na, level_joins, *levels)
+        seg = _conv_bias(p3, net.semantic_seg_conv, ACT_NONE, _ru(nc - 1, 32), xjoin=j3, xrole='pass')[..., :nc - 1].permute(0, 3, 1, 2)
         return conf_all, box_all, coef_all, proto, seg
     c_conf, c_box, c_coef = na * nc, na * 4, na * cd
     w_head = torch.cat([hd.conf_layer.weight, hd.bbox_layer.weight, hd.coef_layer[0].weight], 0)

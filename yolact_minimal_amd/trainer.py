@@ -17,7 +17,7 @@ import torch
 import torch.distributed as dist
 
 from . import hip
-from .train_engine import wgrad_stream_if_used, weights_changed
+from .train_engine import wgrad_stream_if_used, weights_changed, release_wgrad_scratch
 
 
 def init_distributed(backend=None):
@@ -290,6 +290,7 @@ def flatten_buffers(module):
 class Trainer:
     def __init__(self, net, cfg, device, world=1, local_rank=0):
         self.net, self.cfg, self.device, self.world = net.train().to(device), cfg, device, world
+        release_wgrad_scratch()                      # (per-layer scratch of a previous trainer in this process)
         if cfg.__class__.__name__ == 'swin_tiny_coco':           # optimizer choice of the reference (train.py:60-63)
             self.opt = FlatAdamW(self.net.parameters(), cfg.lr, weight_decay=0.05)
         else:
