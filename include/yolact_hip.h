@@ -123,6 +123,11 @@ typedef struct {
     int32_t grid_wgs;        /* persistent kernel (stages 4x): workgroups to launch; 0 = as many as the CUs hold (LDS-limited, at most  */
                              /* 4 per CU), never more than there are work items.  Wave kernel with DMA rings (kwaves > 0, stages 22-24):  */
                              /* waves per workgroup, 0 = 4 (1 / 2 with kwaves <= that: single tiles are balanced over the CUs)            */
+    int32_t bn_replicas;     /* 0 / 1: bn_sum / bn_sumsq are [Cout] each.  R > 1: the statistics are spread over R replicas -- output    */
+                             /* tile row t (workgroup w of the weight-stationary kernel) adds into replica t % R, which lives r * 2 *    */
+                             /* Cout doubles after bn_sum / bn_sumsq (caller: 2 * Cout * R doubles, zeroed, bn_sumsq = bn_sum + Cout).   */
+                             /* A layer with thousands of row tiles otherwise queues that many fp64 atomics on every channel's address   */
+                             /* (2312 at M = 147968: 2.5x the launch time).  ym_bn_train_fwd_stats / _bwd_apply take the same R.          */
 } ym_conv_desc;
 
 /* y = act(conv(x, w) * scale + shift + residual), one launch (plus a reduce launch if K is split).
@@ -286,9 +291,10 @@ int ym_bn_train_fwd(const float* y, int64_t M, int C, const float* gamma, const 
                     float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes, ym_stream_t s);
 /* Same, but the first 16*C bytes of `workspace` already hold the fp64 sum[C] | sumsq[C] of y (accumulated by
  * ym_conv2d_fwd through ym_conv_desc.bn_sum / bn_sumsq): skips the statistics pass over y. */
+/* (`replicas`: see ym_conv_desc.bn_replicas -- the sums are the total over `replicas` (>= 1) copies spaced 2 * C doubles apart) */
 int ym_bn_train_fwd_stats(const float* y, int64_t M, int C, const float* gamma, const float* beta, float eps,
                           float momentum, float* running_mean, float* running_var, const float* residual, int relu,
-                          float* out, float* save_mean, float* save_invstd, const void* stats, ym_stream_t s);
+                          float* out, float* save_mean, float* save_invstd, const void* stats, int replicas, ym_stream_t s);
 
 /* Backward of the above: dz = dout * (out > 0 if relu); dres (optional) = dz; dgamma/dbeta [C];
  * out may be NULL with relu = 1 when the forward had NO residual and `beta` is given: the mask is then re-derived from y with the
@@ -304,7 +310,7 @@ int ym_bn_train_bwd(const float* dout, const float* out, const float* y, int64_t
  * data-gradient conv that produced `dout` (ym_conv_desc.bnb_*).  Every other argument as in ym_bn_train_bwd. */
 int ym_bn_train_bwd_apply(const float* dout, const float* out, const float* y, int64_t M, int C, const float* gamma,
                           const float* beta, const float* save_mean, const float* save_invstd, int relu, float* dy, float* dres,
-                          float* dgamma, float* dbeta, const void* stats, ym_stream_t s);
+                          float* dgamma, float* dbeta, const void* stats, int replicas, ym_stream_t s);
 
 /* Gradient of the fused prediction-head output w.r.t. the 351(+pad)-channel conv output, for all FPN levels in one launch:
  * the loss hands back dclass [B][N][nc], dbox [B][N][4], dcoef [B][N][cd] (N = anchors of all levels, anchor = (pixel, a) level by
@@ -416,6 +422,13 @@ int ym_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n,
 
 /* MaxPool2d(3, stride 2, pad 1), reference modules/resnet.py:91. C % 4 == 0. */
 int ym_maxpool3x3s2_fwd(const float* in, float* out, int B, int H, int W, int C, ym_stream_t s);
+/* The ResNet stem in eval mode as ONE launch (modules/resnet.py:86-91: conv1 7x7/2 pad 3 -> bn1 -> relu -> maxpool 3x3/2 pad 1):
+ * img NCHW [B][3][H][W] (read directly: no NHWC4 copy), w_packed = ym_pack_conv_weight(conv1.weight, cin_pad 4, k_pad 224)
+ * [64][224], scale / shift [64] from ym_fold_bn, out NHWC [B][Hp][Wp][64] with Hp = ((H-1)/2+1 + 1)/2 ... (the two layers'
+ * usual output sizes).  The 64-channel conv output never reaches HBM.  Same MFMA order and epilogue arithmetic as
+ * ym_nchw_to_nhwc4 + ym_conv2d_fwd (stem mode) + ym_maxpool3x3s2_fwd: the same bits. */
+int ym_stem_conv_bn_relu_maxpool(const float* img_nchw, const float* w_packed, const float* scale, const float* shift, float* out,
+                                 int B, int H, int W, int k_pad, ym_stream_t s);
 
 /* Bilinear x2 upsample, align_corners 0 (FPN, modules/yolact.py:70-71) or 1 (ProtoNet, :43). C % 4 == 0. */
 int ym_bilinear2x_fwd(const float* in, float* out, int B, int H, int W, int C, int align_corners, ym_stream_t s);

@@ -263,6 +263,85 @@ def test_conv_persistent_kernel_parity(case):
     torch.testing.assert_close(base, ref_conv(x, wt, scale, shift, res, stride, pad, act), rtol=1e-4, atol=1e-5)
 
 
+WS_CASES = [
+    # b, cin, h, w, cout, act, residual, scale/shift
+    (2, 64, 37, 41, 256, 1, True, True),         # layer1 conv3 shape class: K = 64, ragged M (3034 rows: no tile divides it)
+    (1, 64, 30, 30, 64, 1, False, True),         # layer1.0 conv1
+    (2, 256, 23, 19, 64, 1, False, True),        # layer1 conv1: K = 256 -> only the 64-channel slice fits the LDS
+    (1, 128, 33, 33, 512, 0, True, False),       # layer2 conv3: four 128-channel slices, no activation
+    (3, 96, 20, 20, 288, 0, False, True),        # Swin stage-1 qkv: K = 96 (3 K tiles), N = 288 = 2 x 128 + 32
+    (1, 32, 9, 7, 36, 1, True, True),            # one K tile, fewer rows than a block, N % 32 != 0
+]
+
+
+@pytest.mark.parametrize('case', WS_CASES)
+def test_conv_weight_stationary_kernel_parity(case):
+    """stages 52 / 53 / 54 (csrc/conv_ws.hip): the 1x1 / stride-1 convolution as a GEMM whose filter slice stays in LDS while the
+    workgroup walks M blocks.  Every tile (64x256, 128x128, 256x64) whose slice fits, every ring depth, the library's grid and a
+    grid of 8 workgroups (many blocks per workgroup: the A stream crosses block boundaries), against an fp64 convolution (1e-4)
+    and against the 64x64 direct-to-LDS kernel (fp32 summation order); repeated launches give the same bits.  A request the
+    kernel does not cover (a 3x3 filter) runs as the 64x64 kernel: the same bits as asking for that directly."""
+    b, cin, h, w, cout, act, use_res, affine = case
+    g = torch.Generator().manual_seed(cin * 7 + cout + h)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) * (1.0 / cin ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5 if affine else None
+    shift = torch.randn(cout, generator=g) * 0.1 if affine else None
+    res = torch.randn(b, cout, h, w, generator=g) if use_res else None
+    want = ref_conv(x, wt, scale, shift, res, 1, 0, act)
+    base = run_conv(x, wt, scale, shift, res, 1, 0, act, (64, 64), 1, 0, 22)
+    ran = 0
+    for tile in ((64, 256), (128, 128), (256, 64)):
+        if tile[1] * cin * 4 > 64 * 1024:
+            continue                                  # the slice does not fit: covered by the fallback check below
+        for stages in (52, 53, 54):
+            for gw in (0, 8):
+                got = run_conv(x, wt, scale, shift, res, 1, 0, act, tile, 1, 0, stages, grid_wgs=gw, repeat=2)
+                assert not torch.isnan(got).any(), (tile, stages, gw)
+                torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4, msg=lambda m: f'{tile} {stages} {gw}: {m}')
+                torch.testing.assert_close(got, base, rtol=2e-5, atol=2e-5)
+                ran += 1
+    assert ran >= 6
+    # not covered: a slice that does not fit the LDS, a filter with taps -> the 64x64 direct-to-LDS kernel
+    if 256 * cin * 4 > 64 * 1024:
+        got = run_conv(x, wt, scale, shift, res, 1, 0, act, (64, 256), 1, 0, 53)
+        assert torch.equal(got, base)
+    w3 = torch.randn(cout, cin, 3, 3, generator=g) * (1.0 / (9 * cin) ** 0.5)
+    a = run_conv(x, w3, scale, shift, res, 1, 1, act, (64, 64), 1, 0, 22)
+    b3 = run_conv(x, w3, scale, shift, res, 1, 1, act, (128, 128), 1, 0, 53)
+    assert torch.equal(a, b3)
+
+
+def test_conv_weight_stationary_kernel_batchnorm_sums():
+    """ym_conv_desc.bn_sum with the weight-stationary kernel: per-channel sum / sum of squares of the conv output, kept in
+    registers for the workgroup's whole life and flushed once -- against fp64 sums of the kernel's own output (ragged last block:
+    rows past M must not count)."""
+    from yolact_minimal_amd import hip
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    b, cin, h, w, cout = 2, 64, 37, 41, 256
+    x = torch.randn(b, h, w, cin, generator=g).to(dev)
+    wt = (torch.randn(cout, cin, generator=g) / cin ** 0.5).to(dev)
+    for tile, stages, gw in (((64, 256), 53, 0), ((128, 128), 52, 8), ((256, 64), 54, 0)):
+        out = torch.full((b, h, w, cout), float('nan'), device=dev)
+        sums = torch.zeros(2, cout, dtype=torch.float64, device=dev)
+        d = hip.ConvDesc()
+        d.inp, d.weight = x.data_ptr(), wt.data_ptr()
+        d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW = b, h, w, cin, cout, 1, 1
+        d.stride, d.pad, d.Ho, d.Wo, d.k_pad, d.nseg = 1, 0, h, w, cin, 1
+        d.seg[0].n_begin, d.seg[0].n_end, d.seg[0].out = 0, cout, out.data_ptr()
+        d.seg[0].batch_stride, d.seg[0].pitch, d.seg[0].act = h * w * cout, cout, 0
+        d.tile_m, d.tile_n, d.ksplit, d.stages, d.grid_wgs = tile[0], tile[1], 1, stages, gw
+        assert hip.lib().ym_conv2d_fuses_bn_stats(ctypes.byref(d)) == 1
+        d.bn_sum, d.bn_sumsq = sums[0].data_ptr(), sums[1].data_ptr()
+        hip.conv2d_fwd(d, None)
+        torch.cuda.synchronize()
+        y = out.double().reshape(-1, cout)
+        torch.testing.assert_close(out.reshape(-1, cout), (x.reshape(-1, cin) @ wt.t()), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(sums[0], y.sum(0), rtol=1e-5, atol=1e-3)          # (fp32 over the 32 rows of a block, fp64 across)
+        torch.testing.assert_close(sums[1], (y * y).sum(0), rtol=1e-5, atol=1e-3)
+
+
 WAVE_CASES = [
     # b, cin, h, w, cout, k, stride, pad, act, residual, wave tile, kwaves
     (1, 64, 17, 17, 64, 1, 1, 0, 1, False, (32, 32), 1),
@@ -446,6 +525,44 @@ def test_maxpool():
     hip.maxpool3x3s2(xin, out)
     want = F.max_pool2d(x, 3, 2, 1)
     assert torch.equal(out.cpu().permute(0, 3, 1, 2), want)
+
+
+@pytest.mark.parametrize('b,h,w', [(2, 64, 64), (1, 33, 47), (1, 70, 54), (2, 97, 161), (1, 544, 544)])
+def test_fused_stem_equals_conv_then_maxpool(b, h, w):
+    """`ym_stem_conv_bn_relu_maxpool` (the eval-mode ResNet stem in one launch, modules/resnet.py:86-91, reading the NCHW image
+    itself) against the three launches it replaces -- `ym_nchw_to_nhwc4`, `ym_conv2d_fwd` in stem mode with folded BN + ReLU,
+    `ym_maxpool3x3s2_fwd`: same MFMA order and epilogue arithmetic -> the SAME BITS (pooled tiles that overhang the image, odd
+    conv / pool sizes, image borders where the window is clipped); and against PyTorch fp64 on the CPU."""
+    from yolact_minimal_amd import hip
+    g = torch.Generator().manual_seed(b * 1000 + h + w)
+    x = torch.randn(b, 3, h, w, generator=g)
+    wt = torch.randn(64, 3, 7, 7, generator=g) * 0.08
+    scale, shift = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3
+    conv = run_conv(x, wt, scale, shift, None, 2, 3, 1)                       # NCHW cpu, [b, 64, ho, wo]
+    ho, wo = conv.shape[2:]
+    hp, wp = (ho + 2 - 3) // 2 + 1, (wo + 2 - 3) // 2 + 1
+    pooled = torch.empty(b, hp, wp, 64, device=_dev())
+    hip.maxpool3x3s2(conv.permute(0, 2, 3, 1).contiguous().to(_dev()), pooled)
+    wpk = hip.pack_conv_weight(wt.to(_dev()), 4, 224)
+    out = torch.full((b, hp, wp, 64), float('nan'), device=_dev())
+    hip.stem_conv_bn_relu_maxpool(x.to(_dev()), wpk, scale.to(_dev()), shift.to(_dev()), out)
+    torch.cuda.synchronize()
+    assert torch.equal(out, pooled), float((out - pooled).abs().max())
+    want = F.max_pool2d(F.relu(F.conv2d(x.double(), wt.double(), None, 2, 3) * scale.double().view(1, -1, 1, 1)
+                               + shift.double().view(1, -1, 1, 1)), 3, 2, 1)
+    torch.testing.assert_close(out.cpu().permute(0, 3, 1, 2).double(), want, rtol=1e-4, atol=1e-4)
+    # NaN / inf in the image propagate like the two-kernel path (max-pool takes NaN; padded K taps contribute nothing)
+    x2 = x.clone()
+    x2[0, 1, h // 2, w // 3] = float('nan')
+    x2[0, 2, 0, 0] = float('inf')
+    conv2 = run_conv(x2, wt, scale, shift, None, 2, 3, 1)
+    hip.maxpool3x3s2(conv2.permute(0, 2, 3, 1).contiguous().to(_dev()), pooled)
+    hip.stem_conv_bn_relu_maxpool(x2.to(_dev()), wpk, scale.to(_dev()), shift.to(_dev()), out)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.isnan(out), torch.isnan(pooled)) and bool(torch.isnan(out).any())
+    assert torch.equal(torch.nan_to_num(out, 7.0), torch.nan_to_num(pooled, 7.0))
+    with pytest.raises(RuntimeError):
+        hip.stem_conv_bn_relu_maxpool(x.to(_dev()), torch.zeros(64, 256, device=_dev()), scale.to(_dev()), shift.to(_dev()), out)
 
 
 @pytest.mark.parametrize('align', [False, True])

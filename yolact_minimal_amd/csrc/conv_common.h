@@ -73,6 +73,7 @@ struct ConvP {
     const float* bnb_gamma;
     const float* bnb_beta;
     int bnb_relu;
+    int bn_rep;        // replicas of the statistics (>= 1): tile row t / workgroup w adds into replica t % bn_rep, 2 * Cout doubles apart
     int* counters;     // optional per-output-tile arrival counters: fused split-K finish (see ym_conv_desc.tile_counters)
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, Kpad;
     int M, HoWo, nkt, ksplit, kt_per_split, tiles_m, tiles_n;
@@ -171,3 +172,8 @@ int ym_launch_conv_wave(const ymk::ConvP& p, int tm, int tn, int kwaves, int sta
 // defer: the un-split item's stores are issued under the next item's MFMAs (costs a dedicated 16 KB accumulator tile in LDS).
 int ym_launch_conv_pers(const ymk::ConvP& p, int bm, int bn, int mode, int ns, bool defer, int grid, hipStream_t st);
 size_t ym_conv_pers_lds_bytes(int bm, int bn, int ns, bool defer);
+// conv_ws.hip: weight-stationary 1x1 / stride-1 convolution (stages 52 / 53 / 54 = ring of 2 / 3 / 4; tile 64x256, 128x128 or
+// 256x64: a workgroup keeps `bn` output channels x all of K in LDS and walks M blocks of `bm` rows).  grid_wgs: workgroups (0 = as
+// many as the CUs hold).  YM_EINVAL: no such variant / too much LDS.
+int ym_launch_conv_ws(const ymk::ConvP& p, int bm, int bn, int nstg, int grid_wgs, hipStream_t st);
+size_t ym_conv_ws_lds_bytes(int bm, int bn, int nkt, int nstg);

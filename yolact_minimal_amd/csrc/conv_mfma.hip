@@ -750,8 +750,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
                 double S = 0.0, Q = 0.0;
 #pragma unroll
                 for (int r = 0; r < RPP; ++r) { S += R[(r * BN + tid) * 2]; Q += R[(r * BN + tid) * 2 + 1]; }
-                atomicAdd(p.bn_sum + n0 + tid, S);
-                atomicAdd(p.bn_sumsq + n0 + tid, Q);
+                // (replica tile_m % bn_rep: a layer with thousands of M tiles would queue them all on one address per channel)
+                const size_t rep = (size_t)(tile_m % p.bn_rep) * 2 * p.Cout;
+                atomicAdd(p.bn_sum + rep + n0 + tid, S);
+                atomicAdd(p.bn_sumsq + rep + n0 + tid, Q);
             }
         }
         YM_STAMP(3);
@@ -854,6 +856,8 @@ bool vec_epilogue(const ym_conv_desc* d) {
 
 struct Plan {
     int bm, bn, ksplit, kt_per_split, tiles_m, tiles_n, nkt, M;
+    int ws = 0;                                  // 1: the weight-stationary 1x1 kernel (conv_ws.hip) with a ring of `ws_ring` stages
+    int ws_ring = 0;
     int tail_tiles, tail_split, tail_ktps;     // 0 = no tail
     // stride-2 data gradient by output-pixel parity class (ConvP::cls): M is then the class-padded row count
     int cls, M_pix, cls_tile0[5], cls_rows[4], cls_w[4], cls_hw[4], cls_kh0[4], cls_kw0[4], cls_nkw[4], cls_nkt[4];
@@ -912,6 +916,24 @@ int make_plan(const ym_conv_desc* d, Plan* pl, bool allow_cls = true) {
             if (wgs >= 512) { bm = cand[c][0]; bn = cand[c][1]; break; }
         }
         if (d->Cin == 4) { bm = 128; bn = 64; }
+    }
+    pl->ws = 0; pl->ws_ring = 0;
+    if (d->stages >= 52 && d->stages <= 54) {
+        // weight-stationary 1x1 kernel (conv_ws.hip): a plain GEMM with the filter slice resident in LDS.  What it does not cover
+        // (a filter with taps, a stride, BatchNorm-backward sums, too much filter for the LDS) runs as a 64x64 direct-to-LDS launch.
+        const bool shape_ok = (bm == 64 && bn == 256) || (bm == 128 && bn == 128) || (bm == 256 && bn == 64);
+        const int act = d->seg[0].act;
+        const bool ok = shape_ok && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->Cin % 32 == 0 && d->k_pad == d->Cin &&
+                        d->nlevels == 0 && d->kwaves == 0 && d->mma == 0 && d->bnb_y == nullptr && vec_epilogue(d) &&
+                        (act == YM_ACT_NONE || act == YM_ACT_RELU) && (size_t)bn * d->Cin * 4 <= (64u << 10) &&
+                        ym_conv_ws_lds_bytes(bm, bn, pl->nkt, d->stages - 50) <= (160u << 10) && (unsigned long long)M * d->Cout * 4ull < 0xFFFFFFF0ull;
+        if (ok) {
+            pl->bm = bm; pl->bn = bn; pl->tiles_m = ym_cdiv(pl->M, bm); pl->tiles_n = ym_cdiv(d->Cout, bn);
+            pl->ksplit = 1; pl->kt_per_split = pl->nkt;
+            pl->ws = 1; pl->ws_ring = d->stages - 50;
+            return YM_OK;
+        }
+        bm = 64; bn = 64;
     }
     if (d->kwaves > 0) {
         YM_REQUIRE(d->Cin != 4, "conv: the wave-private kernel does not support the stem (Cin == 4)");
@@ -1099,6 +1121,8 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
         p.vec = (vec_epilogue(d) && ((uintptr_t)workspace & 15) == 0) ? 1 : 0;
     }
     p.bn_sum = d->bn_sum; p.bn_sumsq = d->bn_sumsq;
+    p.bn_rep = d->bn_replicas > 1 ? d->bn_replicas : 1;
+    YM_REQUIRE(p.bn_rep == 1 || !d->bn_sum || d->bn_sumsq == d->bn_sum + d->Cout, "conv: bn_replicas > 1 needs bn_sumsq == bn_sum + Cout");
     p.bnb_y = d->bnb_y; p.bnb_out = d->bnb_out; p.bnb_mean = d->bnb_mean; p.bnb_invstd = d->bnb_invstd;
     p.bnb_gamma = d->bnb_gamma; p.bnb_beta = d->bnb_beta; p.bnb_relu = d->bnb_relu;
     p.trace = nullptr; p.trace_epoch = nullptr; p.trace_ring = 0; p.trace_stride = 0; p.trace_rt = 0; p.trace_hw = nullptr;
@@ -1144,9 +1168,11 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
                    "conv(wave, DMA ring): needs Cin %% 32 == 0, one input size, a forward convolution");
         return ym_launch_conv_wave(p, pl.bm, pl.bn, d->kwaves, d->stages, d->grid_wgs, st);
     }
+    if (pl.ws) return ym_launch_conv_ws(p, pl.bm, pl.bn, pl.ws_ring, d->grid_wgs, st);
     const int grid = pl.grid();
     p.total_items = grid;
     int stages = d->stages;
+    if (stages >= 52 && stages <= 54) stages = 22;       // (a weight-stationary request the kernel does not cover: see make_plan)
     if (stages >= 42 && stages <= 48) {
         // persistent direct-to-LDS kernel (conv_persist.hip); what it does not cover runs on the non-persistent ring of the same depth
         const int ns = stages - 40;

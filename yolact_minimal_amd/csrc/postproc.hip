@@ -220,10 +220,11 @@ struct NmsWs {
     float* scores_t;     // [C-1][N] class-major scores of the kept anchors (background dropped)
     int* top_idx;        // [C-1][TOPK_CAP] index into the compacted list
     float* top_score;    // [C-1][TOPK_CAP]
-    int* top_cnt;        // [C-1]
-    uint8_t* col_keep;   // [C-1][TOPK_CAP]
+    int* top_cnt;        // [C-1]     entries of top_idx / top_score that SURVIVED the IoU test (compacted, still sorted)
+    int* chunk_cnt;      // [ceil(N / CHUNK)] anchors over threshold per chunk of CHUNK consecutive anchors
     size_t bytes;
 };
+constexpr int CHUNK = 64;    // anchors per workgroup of stage A
 
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -239,7 +240,7 @@ __device__ __forceinline__ NmsWs image_ws(const NmsWs& w, size_t stride, int b) 
     o.top_idx = (int*)((char*)w.top_idx + sh);
     o.top_score = (float*)((char*)w.top_score + sh);
     o.top_cnt = (int*)((char*)w.top_cnt + sh);
-    o.col_keep = w.col_keep + sh;
+    o.chunk_cnt = (int*)((char*)w.chunk_cnt + sh);
     return o;
 }
 
@@ -255,7 +256,7 @@ NmsWs carve(void* base, int N, int C) {
     w.top_idx = (int*)take((size_t)(C - 1) * TOPK_CAP * sizeof(int));
     w.top_score = (float*)take((size_t)(C - 1) * TOPK_CAP * sizeof(float));
     w.top_cnt = (int*)take((size_t)(C - 1) * sizeof(int));
-    w.col_keep = (uint8_t*)take((size_t)(C - 1) * TOPK_CAP);
+    w.chunk_cnt = (int*)take((size_t)((N + CHUNK - 1) / CHUNK) * sizeof(int));
     w.bytes = off;
     return w;
 }
@@ -263,70 +264,45 @@ NmsWs carve(void* base, int N, int C) {
 // ---------------------------------------------------------------------------------------------------
 // stage A: score filter, ordered compaction, decode + transpose  (utils/output_utils.py:135-153)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_score_flag(const float* __restrict__ cls, int N, int C, float thre,
-                                                     uint8_t* __restrict__ flag, size_t ws_stride) {
+// One workgroup per chunk of CHUNK consecutive anchors (16 waves x 4 anchors): flag = max over the foreground classes > threshold,
+// and the chunk's count of flagged anchors -- what the ordered compaction of the next launch needs to know about every OTHER chunk.
+__global__ __launch_bounds__(NT) void k_score_flag_count(const float* __restrict__ cls, int N, int C, float thre,
+                                                          uint8_t* __restrict__ flag, int* __restrict__ chunk_cnt, size_t ws_stride) {
     cls += (size_t)blockIdx.y * N * C;
     flag += ws_stride * blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int wave0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
-    for (int a = wave0; a < N; a += nw) {
-        const float* row = cls + (size_t)a * C;
-        float m = -INFINITY;
-        for (int c = 1 + lane; c < C; c += 64) m = fmaxf(m, row[c]);
+    chunk_cnt = (int*)((char*)chunk_cnt + ws_stride * blockIdx.y);
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int PER = CHUNK / (NT / 64);
+    const int a0 = blockIdx.x * CHUNK + wv * PER;
+    float m[PER];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        if (lane == 0) flag[a] = m > thre ? 1 : 0;
+    for (int i = 0; i < PER; ++i) {                       // (all rows' loads in flight before the first reduction)
+        const int a = a0 + i;
+        m[i] = -INFINITY;
+        if (a < N) {
+            const float* row = cls + (size_t)a * C;
+            for (int c = 1 + lane; c < C; c += 64) m[i] = fmaxf(m[i], row[c]);
+        }
     }
-}
-
-// Ordered compaction in ONE pass: every thread owns a contiguous run of flags (<= 32), one block-wide exclusive scan.
-__global__ __launch_bounds__(NT) void k_compact(const uint8_t* __restrict__ flag, int N, int* __restrict__ keep_idx,
-                                                int* __restrict__ counters, size_t ws_stride) {
-    flag += ws_stride * blockIdx.y;
-    keep_idx = (int*)((char*)keep_idx + ws_stride * blockIdx.y);
-    counters = (int*)((char*)counters + ws_stride * blockIdx.y);
-    __shared__ int wave_tot[NT / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int total_before = 0;
-    for (int chunk0 = 0; chunk0 < N; chunk0 += NT * 32) {            // one trip for N <= 32768
-        const int beg = chunk0 + tid * 32;
-        uint32_t bits = 0u;
-        if (beg < N) {
-            if (beg + 32 <= N && ((uintptr_t)(flag + beg) & 15) == 0) {
-                const uint4 a = *reinterpret_cast<const uint4*>(flag + beg), b = *reinterpret_cast<const uint4*>(flag + beg + 16);
-                const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    int local = 0;
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
+    for (int i = 0; i < PER; ++i) {
+        float v = m[i];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) bits |= ((w[q] >> (8 * e)) & 0xFFu) ? (1u << (q * 4 + e)) : 0u;
-            } else {
-                for (int e = 0; e < 32 && beg + e < N; ++e) bits |= flag[beg + e] ? (1u << e) : 0u;
-            }
+        for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+        const int a = a0 + i;
+        if (a < N) {
+            const bool keep = v > thre;
+            if (lane == 0) flag[a] = keep ? 1 : 0;
+            local += keep ? 1 : 0;
         }
-        const int mine = __popc(bits);
-        int incl = mine;                                               // wave inclusive scan
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o);
-            if (lane >= o) incl += v;
-        }
-        if (lane == 63) wave_tot[wv] = incl;
-        __syncthreads();
-        int off = total_before + incl - mine;
-        int chunk_total = 0;
-        for (int w = 0; w < NT / 64; ++w) {
-            if (w < wv) off += wave_tot[w];
-            chunk_total += wave_tot[w];
-        }
-        while (bits) {
-            const int e = __ffs(bits) - 1;
-            bits &= bits - 1;
-            keep_idx[off++] = beg + e;
-        }
-        total_before += chunk_total;
-        __syncthreads();
     }
-    if (tid == 0) counters[0] = total_before;
+    if (lane == 0 && local) atomicAdd(&cnt, local);
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_cnt[blockIdx.x] = cnt;
 }
 
 // exp() of the box decode (utils/output_utils.py:150).  The reference's torch.exp is Intel MKL VML here (closed source, host-ISA
@@ -363,47 +339,71 @@ __global__ __launch_bounds__(256) void k_expf_cr(const float* __restrict__ x, fl
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = expf_cr(x[i]);
 }
 
-__global__ __launch_bounds__(256) void k_decode_transpose(const float* __restrict__ cls, const float* __restrict__ box,
-                                                           const float* __restrict__ anchors, int N, int C,
-                                                           const int* __restrict__ keep_idx, const int* __restrict__ counters,
-                                                           float* __restrict__ boxes_k, float* __restrict__ scores_t, size_t ws_stride) {
+// Ordered compaction + box decode + class-major score matrix in ONE pass over the flagged anchors (boolean-mask gather order =
+// ascending anchor index, utils/output_utils.py:135-153).  Workgroup b owns chunk b: its first output slot is the sum of the
+// counts of the chunks before it (<= a few hundred integers, summed by the workgroup itself), so no single-workgroup scan launch
+// stands between the score filter and the decode; chunks without a flagged anchor exit at once.
+__global__ __launch_bounds__(256) void k_compact_decode(const float* __restrict__ cls, const float* __restrict__ box,
+                                                         const float* __restrict__ anchors, int N, int C,
+                                                         const uint8_t* __restrict__ flag, const int* __restrict__ chunk_cnt,
+                                                         int* __restrict__ keep_idx, int* __restrict__ counters,
+                                                         float* __restrict__ boxes_k, float* __restrict__ scores_t, size_t ws_stride) {
     {
         const size_t sh = ws_stride * blockIdx.y;
         cls += (size_t)blockIdx.y * N * C;
         box += (size_t)blockIdx.y * N * 4;
-        keep_idx = (const int*)((const char*)keep_idx + sh);
-        counters = (const int*)((const char*)counters + sh);
+        flag += sh;
+        chunk_cnt = (const int*)((const char*)chunk_cnt + sh);
+        keep_idx = (int*)((char*)keep_idx + sh);
+        counters = (int*)((char*)counters + sh);
         boxes_k = (float*)((char*)boxes_k + sh);
         scores_t = (float*)((char*)scores_t + sh);
     }
-    extern __shared__ float tile[];  // [64][C]
-    const int K = counters[0];
-    const int k0 = blockIdx.x * 64;
-    if (k0 >= K) return;
-    const int tid = threadIdx.x, CC = C - 1;
-    if (tid < 64 && k0 + tid < K) {
-        const int a = keep_idx[k0 + tid];
-        const f32x4 an = *reinterpret_cast<const f32x4*>(anchors + (size_t)a * 4);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(box + (size_t)a * 4);
-        const float cx = an[0] + (b[0] * 0.1f) * an[2];
-        const float cy = an[1] + (b[1] * 0.1f) * an[3];
-        const float w = an[2] * expf_cr(b[2] * 0.2f);
-        const float h = an[3] * expf_cr(b[3] * 0.2f);
-        float x1 = cx - w / 2.f, y1 = cy - h / 2.f;
-        float x2 = w + x1, y2 = h + y1;
-        auto clip01 = [](float v) { return v != v ? v : fminf(fmaxf(v, 0.f), 1.f); };
-        f32x4 o = {clip01(x1), clip01(y1), clip01(x2), clip01(y2)};
-        *reinterpret_cast<f32x4*>(boxes_k + (size_t)(k0 + tid) * 4) = o;
-    }
-    for (int e = tid; e < 64 * CC; e += 256) {
-        const int r = e / CC, c = e - r * CC;
-        tile[r * C + c] = (k0 + r < K) ? cls[(size_t)keep_idx[k0 + r] * C + 1 + c] : 0.f;
+    extern __shared__ float tile[];  // [CHUNK][C]
+    __shared__ int wsum[4];
+    __shared__ int kept_a[CHUNK];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, CC = C - 1;
+    const int b = blockIdx.x, nchunks = gridDim.x;
+    int part = 0;
+    for (int i = tid; i < b; i += 256) part += chunk_cnt[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if (lane == 0) wsum[wv] = part;
+    __syncthreads();
+    const int k0 = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    const int cntb = chunk_cnt[b];
+    if (b == nchunks - 1 && tid == 0) counters[0] = k0 + cntb;         // K: anchors over threshold
+    if (cntb == 0) return;
+    if (tid < CHUNK) {
+        const int a = b * CHUNK + tid;
+        const bool f = a < N && flag[a];
+        const unsigned long long bal = __ballot(f);
+        const int pos = __popcll(bal & ((1ull << lane) - 1ull));
+        if (f) {
+            kept_a[pos] = a;
+            keep_idx[k0 + pos] = a;
+            const f32x4 an = *reinterpret_cast<const f32x4*>(anchors + (size_t)a * 4);
+            const f32x4 bx = *reinterpret_cast<const f32x4*>(box + (size_t)a * 4);
+            const float cx = an[0] + (bx[0] * 0.1f) * an[2];
+            const float cy = an[1] + (bx[1] * 0.1f) * an[3];
+            const float w = an[2] * expf_cr(bx[2] * 0.2f);
+            const float h = an[3] * expf_cr(bx[3] * 0.2f);
+            float x1 = cx - w / 2.f, y1 = cy - h / 2.f;
+            float x2 = w + x1, y2 = h + y1;
+            auto clip01 = [](float v) { return v != v ? v : fminf(fmaxf(v, 0.f), 1.f); };
+            f32x4 o = {clip01(x1), clip01(y1), clip01(x2), clip01(y2)};
+            *reinterpret_cast<f32x4*>(boxes_k + (size_t)(k0 + pos) * 4) = o;
+        }
     }
     __syncthreads();
-    for (int e = tid; e < 64 * CC; e += 256) {
-        const int c = e >> 6, r = e & 63;
-        if (k0 + r < K) scores_t[(size_t)c * N + k0 + r] = tile[r * C + c];
+    for (int e = tid; e < cntb * CC; e += 256) {
+        const int r = e / CC, c = e - r * CC;
+        tile[r * C + c] = cls[(size_t)kept_a[r] * C + 1 + c];
     }
+    __syncthreads();
+    const int r = tid & 63;
+    if (r < cntb)
+        for (int c = tid >> 6; c < CC; c += 4) scores_t[(size_t)c * N + k0 + r] = tile[r * C + c];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -418,13 +418,10 @@ __global__ __launch_bounds__(NT) void k_class_topk_iou(const NmsWs w0, int N, in
     const int c = blockIdx.x, tid = threadIdx.x;
     const float* srow = w.scores_t + (size_t)c * N;
     const int cnt = block_topk_sorted<TOPK_CAP>([&](int i) { return f2key(srow[i]); }, K, top_k, sh);
-    for (int j = tid; j < cnt; j += NT) {
-        const int k = sh.idx[j];
-        w.top_idx[c * TOPK_CAP + j] = k;
-        w.top_score[c * TOPK_CAP + j] = key2f(sh.keys[j]);
-        *reinterpret_cast<f32x4*>(sbox + j * 4) = *reinterpret_cast<const f32x4*>(w.boxes_k + (size_t)k * 4);
-    }
-    if (tid == 0) w.top_cnt[c] = cnt;
+    __shared__ uint8_t skeep[TOPK_CAP];
+    __shared__ int wtot[TOPK_CAP / 64];
+    for (int j = tid; j < cnt; j += NT)
+        *reinterpret_cast<f32x4*>(sbox + j * 4) = *reinterpret_cast<const f32x4*>(w.boxes_k + (size_t)sh.idx[j] * 4);
     __syncthreads();
     // wavefront reduction: one wave per column j, lanes stride over the higher-scored rows i < j.
     // keep[j] = max_i<j IoU(i,j) <= thre with torch.max's NaN propagation  <=>  every IoU(i,j) <= thre.
@@ -438,18 +435,62 @@ __global__ __launch_bounds__(NT) void k_class_topk_iou(const NmsWs w0, int N, in
             bad |= !(v <= iou_thre);
         }
         const bool any_bad = __any(bad);
-        if (lane == 0) w.col_keep[c * TOPK_CAP + j] = any_bad ? 0 : 1;
+        if (lane == 0) skeep[j] = any_bad ? 0 : 1;
+    }
+    __syncthreads();
+    // the survivors, compacted in rank order (still sorted by score, ties by index): what the global top-k merges
+    bool f = false;
+    int pre = 0;
+    if (tid < TOPK_CAP) {
+        f = tid < cnt && skeep[tid];
+        const unsigned long long bal = __ballot(f);
+        pre = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wtot[wv] = __popcll(bal);
+    }
+    __syncthreads();
+    if (tid < TOPK_CAP && f) {
+        int off = pre;
+        for (int x = 0; x < wv; ++x) off += wtot[x];
+        w.top_idx[c * TOPK_CAP + off] = sh.idx[tid];
+        w.top_score[c * TOPK_CAP + off] = key2f(sh.keys[tid]);
+    }
+    if (tid == 0) {
+        int t = 0;
+        for (int x = 0; x < TOPK_CAP / 64; ++x) t += wtot[x];
+        w.top_cnt[c] = t;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // stage C: global top max_det over the kept (class, rank) pairs + gather  (utils/output_utils.py:31-43)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_final_topk(const NmsWs w0, int ncls, int max_det, const float* __restrict__ coef,
-                                                   int coef_dim, int32_t* __restrict__ out_count,
-                                                   int64_t* __restrict__ out_ids, float* __restrict__ out_scores,
-                                                   float* __restrict__ out_boxes, float* __restrict__ out_coefs, size_t ws_stride,
-                                                   int N) {
+// Maximum of an unsigned value over the 64 lanes of a wave, returned to every lane: inclusive max-scan with DPP (row_shr 1 / 2 / 4 / 8
+// inside each row of 16 lanes, row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3; lanes without a source keep the
+// identity 0), lane 63 then holds the total.  ~14 VALU instructions; a ds_bpermute butterfly is 12 LDS-crossbar round trips.
+__device__ __forceinline__ uint32_t wave_umax(uint32_t x) {
+    int v = (int)x;
+#define YM_DPP_MAX(ctrl, rmask) v = (int)max((uint32_t)v, (uint32_t)__builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, false))
+    YM_DPP_MAX(0x111, 0xf);      // row_shr:1
+    YM_DPP_MAX(0x112, 0xf);      // row_shr:2
+    YM_DPP_MAX(0x114, 0xf);      // row_shr:4
+    YM_DPP_MAX(0x118, 0xf);      // row_shr:8
+    YM_DPP_MAX(0x142, 0xa);      // row_bcast:15 -> rows 1, 3
+    YM_DPP_MAX(0x143, 0xc);      // row_bcast:31 -> rows 2, 3
+#undef YM_DPP_MAX
+    return (uint32_t)__builtin_amdgcn_readlane(v, 63);
+}
+
+// Every class's survivors arrive sorted (k_class_topk_iou), and an entry with >= max_det survivors of its OWN class ahead of it
+// cannot be among the global top max_det: the answer is the max_det-way merge of the first min(count, max_det) entries of ncls
+// sorted lists.  One wave does it: lane l owns the heads of lists l, l + 64, ...; each round a shuffle butterfly finds the best
+// head (key descending, ties by the lower flat slot = class-major, rank-minor: the order of the radix select it replaces), the
+// owning lane advances.  ~100 rounds of ~60 instructions against a 4-pass radix select over 20 480 slots with 1024-thread
+// barriers: 53 -> ~12 us.
+__global__ __launch_bounds__(256) void k_final_merge(const NmsWs w0, int ncls, int max_det, const float* __restrict__ coef,
+                                                     int coef_dim, int32_t* __restrict__ out_count,
+                                                     int64_t* __restrict__ out_ids, float* __restrict__ out_scores,
+                                                     float* __restrict__ out_boxes, float* __restrict__ out_coefs, size_t ws_stride,
+                                                     int N) {
     const NmsWs w = image_ws(w0, ws_stride, blockIdx.y);
     {
         const size_t b = blockIdx.y;                       // image b's outputs: [B][max_det] rows
@@ -460,38 +501,92 @@ __global__ __launch_bounds__(NT) void k_final_topk(const NmsWs w0, int ncls, int
         out_boxes += b * (size_t)max_det * 4;
         out_coefs += b * (size_t)max_det * coef_dim;
     }
-    __shared__ TopkShared<DET_CAP> sh;
-    __shared__ int n_valid;
+    extern __shared__ uint32_t lkeys[];                    // [ncls][DET_CAP]: keys of each class's leading survivors, 0 = none
+    __shared__ int sel[DET_CAP];
+    __shared__ int n_sel;
+    __shared__ int lcnt[256];                              // (ncls <= 255)
     const int tid = threadIdx.x;
     const int K = w.counters[0];
     if (K == 0) {
         if (tid == 0) out_count[0] = 0;
         return;
     }
-    const int L = ncls * TOPK_CAP;
-    auto key_at = [&](int f) -> uint32_t {
-        const int c = f / TOPK_CAP, j = f - c * TOPK_CAP;
-        if (j < w.top_cnt[c] && w.col_keep[f]) return f2key(w.top_score[f]);
-        return 0u;
-    };
-    block_topk_sorted<DET_CAP>(key_at, L, max_det, sh);
-    if (tid == 0) n_valid = 0;
+    if (tid < ncls) lcnt[tid] = min(w.top_cnt[tid], max_det);
     __syncthreads();
-    if (tid < max_det && sh.keys[tid] != 0u) atomicAdd(&n_valid, 1);
+    // the leading DET_CAP scores of every class row, 16 bytes per load, all loads independent (entries past the class's survivor
+    // count are whatever an earlier launch left there: masked by the count, never interpreted)
+    for (int q4 = tid; q4 < ncls * (DET_CAP / 4); q4 += 256) {
+        const int c = q4 / (DET_CAP / 4), j = (q4 - c * (DET_CAP / 4)) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(w.top_score + c * TOPK_CAP + j);
+        const int cnt = lcnt[c];
+        uint32_t* dst = lkeys + c * DET_CAP + j;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[e] = j + e < cnt ? f2key(v[e]) : 0u;
+    }
     __syncthreads();
-    const int n = n_valid;
+    if (tid < 64) {
+        constexpr int LPL = 4;                             // lists per lane: ncls <= 255 (check_cfg)
+        // per list of this lane: position of its head, the head's key and the key behind it (read one round before it can become
+        // the head, so that no LDS latency sits on the round's critical path)
+        int head[LPL];
+        uint32_t hk[LPL], nk[LPL];
+#pragma unroll
+        for (int q = 0; q < LPL; ++q) {
+            const int c = tid + 64 * q;
+            head[q] = 0;
+            hk[q] = c < ncls ? lkeys[c * DET_CAP] : 0u;
+            nk[q] = c < ncls ? lkeys[c * DET_CAP + 1] : 0u;
+        }
+        uint32_t bk;
+        int bf;
+        auto lane_best = [&]() {                           // registers only
+            bk = 0u; bf = INT_MAX;
+#pragma unroll
+            for (int q = 0; q < LPL; ++q) {
+                const int f = (tid + 64 * q) * TOPK_CAP + head[q];
+                if (hk[q] > bk || (hk[q] == bk && hk[q] != 0u && f < bf)) { bk = hk[q]; bf = f; }
+            }
+        };
+        lane_best();
+        int n = 0;
+        for (; n < max_det; ++n) {
+            // best head of the wave: maximum key by a DPP scan, ties by the lower flat slot -- a second scan, taken only when two
+            // lanes really hold the same key
+            const uint32_t mk = wave_umax(bk);
+            if (mk == 0u) break;                           // (uniform) every list is exhausted
+            const unsigned long long tied = __ballot(bk == mk);
+            int mf;
+            if (__popcll(tied) == 1) mf = __builtin_amdgcn_readlane(bf, __ffsll((long long)tied) - 1);
+            else mf = (int)~wave_umax(bk == mk ? ~(uint32_t)bf : 0u);
+            if (tid == 0) sel[n] = mf;
+            const int c = mf / TOPK_CAP;
+            if ((c & 63) == tid) {                         // the owner advances that list
+#pragma unroll
+                for (int q = 0; q < LPL; ++q)
+                    if (q == (c >> 6)) {
+                        ++head[q];
+                        hk[q] = nk[q];
+                        nk[q] = head[q] + 1 < DET_CAP ? lkeys[c * DET_CAP + head[q] + 1] : 0u;
+                    }
+                lane_best();
+            }
+        }
+        if (tid == 0) n_sel = n;
+    }
+    __syncthreads();
+    const int n = n_sel;
     if (tid == 0) out_count[0] = n;
-    for (int j = tid; j < n; j += NT) {
-        const int f = sh.idx[j];
+    for (int j = tid; j < n; j += 256) {
+        const int f = sel[j];
         const int c = f / TOPK_CAP;
         const int k = w.top_idx[f];
         out_ids[j] = c;
-        out_scores[j] = key2f(sh.keys[j]);
+        out_scores[j] = key2f(lkeys[c * DET_CAP + (f - c * TOPK_CAP)]);
         *reinterpret_cast<f32x4*>(out_boxes + j * 4) = *reinterpret_cast<const f32x4*>(w.boxes_k + (size_t)k * 4);
     }
-    for (int e = tid; e < n * coef_dim; e += NT) {
+    for (int e = tid; e < n * coef_dim; e += 256) {
         const int j = e / coef_dim, d = e - j * coef_dim;
-        const int a = w.keep_idx[w.top_idx[sh.idx[j]]];
+        const int a = w.keep_idx[w.top_idx[sel[j]]];
         out_coefs[e] = coef[(size_t)a * coef_dim + d];
     }
 }
@@ -688,12 +783,10 @@ int check_cfg(const ym_nms_cfg* cfg) {
 int run_stage_a(const float* cls, const float* box, const float* anchors, const ym_nms_cfg* cfg, const NmsWs& w,
                 hipStream_t st, int B = 1, size_t ws_stride = 0) {
     const int N = cfg->num_anchors, C = cfg->num_classes;
-    int g1 = ym_cdiv(N, 4);
-    if (g1 > 2048) g1 = 2048;
-    hipLaunchKernelGGL(k_score_flag, dim3(g1, B), dim3(256), 0, st, cls, N, C, cfg->score_thre, w.flag, ws_stride);
-    hipLaunchKernelGGL(k_compact, dim3(1, B), dim3(NT), 0, st, w.flag, N, w.keep_idx, w.counters, ws_stride);
-    hipLaunchKernelGGL(k_decode_transpose, dim3(ym_cdiv(N, 64), B), dim3(256), (size_t)64 * C * sizeof(float), st, cls, box,
-                       anchors, N, C, w.keep_idx, w.counters, w.boxes_k, w.scores_t, ws_stride);
+    const int nchunks = ym_cdiv(N, CHUNK);
+    hipLaunchKernelGGL(k_score_flag_count, dim3(nchunks, B), dim3(NT), 0, st, cls, N, C, cfg->score_thre, w.flag, w.chunk_cnt, ws_stride);
+    hipLaunchKernelGGL(k_compact_decode, dim3(nchunks, B), dim3(256), (size_t)CHUNK * C * sizeof(float), st, cls, box, anchors, N, C,
+                       w.flag, w.chunk_cnt, w.keep_idx, w.counters, w.boxes_k, w.scores_t, ws_stride);
     return ym_check_launch("nms stage A");
 }
 
@@ -730,7 +823,13 @@ extern "C" int ym_detect_fast_nms_batch(const float* class_pred, const float* bo
     if (rc != YM_OK) return rc;
     const int ncls = cfg->num_classes - 1;
     hipLaunchKernelGGL(k_class_topk_iou, dim3(ncls, B), dim3(NT), 0, st, w, cfg->num_anchors, cfg->top_k, cfg->iou_thre, stride);
-    hipLaunchKernelGGL(k_final_topk, dim3(1, B), dim3(NT), 0, st, w, ncls, cfg->max_det, coef_pred, cfg->coef_dim, out_count,
+    const size_t merge_lds = (size_t)ncls * DET_CAP * sizeof(uint32_t);          // <= 255 * 128 * 4 = 130 KB
+    static size_t merge_lds_set = 0;
+    if (merge_lds > merge_lds_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_final_merge), hipFuncAttributeMaxDynamicSharedMemorySize, (int)merge_lds);
+        merge_lds_set = merge_lds;
+    }
+    hipLaunchKernelGGL(k_final_merge, dim3(1, B), dim3(256), merge_lds, st, w, ncls, cfg->max_det, coef_pred, cfg->coef_dim, out_count,
                        out_ids, out_scores, out_boxes, out_coefs, stride, cfg->num_anchors);
     return ym_check_launch("fast_nms");
 }

@@ -279,7 +279,9 @@ class InferEngine:
         self._side_streams = {}
         self._events = {}
         self.use_branches = os.environ.get('YM_BRANCHES', '0') == '1'   # measured neutral on ROCm 7.2 hipGraph: off by default
-        self.convs = []        # every _Conv, for weight refresh / flop accounting
+        self.convs = []        # every _Conv launched through ym_conv2d_fwd, for weight refresh / tuning / flop accounting
+        self.fused_stem = None  # the ResNet stem's _Conv when it runs inside the fused stem + max-pool launch (not in `convs`)
+        self._img = None
         self._weights_epoch = -1
         self._bufs = []
         hip.lib()              # fail loudly here if the .so is missing
@@ -380,13 +382,27 @@ class InferEngine:
         net, B, H, W = self.net, self.B, self.H, self.W
         bb = net.backbone
 
-        # stem + maxpool
+        # stem + maxpool: one launch straight from the NCHW image (csrc/stem.hip; YM_FUSED_STEM=0: NHWC4 copy + conv + pool, the
+        # same bits from three launches and an 18.9 MB round trip per image)
         stem = _Conv('backbone.conv1', bb.conv1, bb.bn1, ACT_RELU, stem=True)
-        x = self._conv(stem, self.x_in)
-        hp, wp = (x.shape[1] + 2 - 3) // 2 + 1, (x.shape[2] + 2 - 3) // 2 + 1
-        pooled = self._buf(B, hp, wp, 64)
-        self._add_op('maxpool', (x, pooled), [x], [pooled])
-        x = pooled
+        conv1 = bb.conv1
+        fusable = (conv1.out_channels == 64 and conv1.in_channels == 3 and tuple(conv1.kernel_size) == (7, 7) and
+                   tuple(conv1.stride) == (2, 2) and tuple(conv1.padding) == (3, 3))
+        if fusable and os.environ.get('YM_FUSED_STEM', '1') != '0':
+            stem.refresh()
+            ho, wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+            hp, wp = (ho + 2 - 3) // 2 + 1, (wo + 2 - 3) // 2 + 1
+            stem.flops = 2.0 * B * ho * wo * stem.cout * stem.kh * stem.kw * stem.cin
+            self.fused_stem = stem
+            pooled = self._buf(B, hp, wp, 64)
+            self._add_op('stem_pool', (stem, pooled), [], [pooled])
+            x = pooled
+        else:
+            x = self._conv(stem, self.x_in)
+            hp, wp = (x.shape[1] + 2 - 3) // 2 + 1, (x.shape[2] + 2 - 3) // 2 + 1
+            pooled = self._buf(B, hp, wp, 64)
+            self._add_op('maxpool', (x, pooled), [x], [pooled])
+            x = pooled
 
         # residual stages
         stage_outs = []
@@ -500,7 +516,7 @@ class InferEngine:
         self._add_op('softmax', (self.class_logits, self.class_pred), [self.class_logits], [self.class_pred])
 
         self._alloc_workspaces()
-        self.total_flops = sum(c.flops for c in self.convs)
+        self.total_flops = sum(c.flops for c in self.convs) + (self.fused_stem.flops if self.fused_stem is not None else 0.0)
         self._weights_epoch = self.net._weights_epoch
 
     def _alloc_workspaces(self):
@@ -530,6 +546,8 @@ class InferEngine:
     def refresh_weights(self):
         for c in self.convs:
             c.refresh()
+        if self.fused_stem is not None:
+            self.fused_stem.refresh()
         self._weights_epoch = self.net._weights_epoch
         self.graph = None
 
@@ -716,6 +734,8 @@ class InferEngine:
             hip.conv2d_fwd(arg.desc, ws)
         elif kind == 'maxpool':
             hip.maxpool3x3s2(arg[0], arg[1])
+        elif kind == 'stem_pool':
+            hip.stem_conv_bn_relu_maxpool(self._img, arg[0].weight, arg[0].scale, arg[0].shift, arg[1])
         elif kind == 'bilinear':
             hip.bilinear2x(arg[0], arg[1], arg[2])
         elif kind == 'softmax':
@@ -732,7 +752,9 @@ class InferEngine:
     def _launch_all(self, img):
         """Replay the plan.  Ops tagged with a branch stream run on side streams; cross-stream producer->consumer edges
         become event waits (inside hipGraph capture they become graph edges, so independent branches overlap)."""
-        hip.nchw_to_nhwc4(img, self.x_in)
+        if self.fused_stem is None:
+            hip.nchw_to_nhwc4(img, self.x_in)
+        self._img = img                                    # (the fused stem reads the NCHW image itself)
         main = torch.cuda.current_stream()
         needs_event = {j for deps in self.op_deps.values() for j in deps}
         used = set()

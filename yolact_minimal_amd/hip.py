@@ -18,7 +18,7 @@ ACT_NONE, ACT_RELU, ACT_TANH, ACT_GELU = 0, 1, 2, 3
 # every symbol include/yolact_hip.h declares (checked by tests/test_abi.py without a GPU)
 ABI_SYMBOLS = (
     'ym_abi_version', 'ym_last_error', 'ym_nchw_to_nhwc4', 'ym_pack_conv_weight', 'ym_fold_bn',
-    'ym_sizeof_conv_desc', 'ym_conv2d_workspace_bytes', 'ym_conv2d_tile_counters', 'ym_conv2d_fwd', 'ym_maxpool3x3s2_fwd', 'ym_bilinear2x_fwd',
+    'ym_sizeof_conv_desc', 'ym_conv2d_workspace_bytes', 'ym_conv2d_tile_counters', 'ym_conv2d_fwd', 'ym_maxpool3x3s2_fwd', 'ym_stem_conv_bn_relu_maxpool', 'ym_bilinear2x_fwd',
     'ym_softmax_rows', 'ym_nms_workspace_bytes', 'ym_detect_fast_nms', 'ym_detect_greedy_nms',
     'ym_greedy_nms_workspace_bytes', 'ym_greedy_nms', 'ym_mask_assemble', 'ym_mask_resize_binarize',
     'ym_boxes_to_pixels', 'ym_expf_cr', 'ym_nms_batch_workspace_bytes', 'ym_detect_fast_nms_batch', 'ym_after_nms_batch_workspace_bytes',
@@ -54,7 +54,7 @@ class ConvDesc(ctypes.Structure):
                 ('level_w', ctypes.c_int32 * 5), ('tail_tiles', ctypes.c_int32), ('tail_ksplit', ctypes.c_int32), ('mma', ctypes.c_int32),
                 ('bnb_relu', ctypes.c_int32), ('bnb_y', ctypes.c_void_p), ('bnb_out', ctypes.c_void_p),
                 ('bnb_mean', ctypes.c_void_p), ('bnb_invstd', ctypes.c_void_p), ('bnb_gamma', ctypes.c_void_p),
-                ('bnb_beta', ctypes.c_void_p), ('grid_wgs', ctypes.c_int32)]
+                ('bnb_beta', ctypes.c_void_p), ('grid_wgs', ctypes.c_int32), ('bn_replicas', ctypes.c_int32)]
 
 
 class WgradDesc(ctypes.Structure):
@@ -124,6 +124,7 @@ def lib():
         L.ym_conv2d_fwd.argtypes = [ctypes.POINTER(ConvDesc), vp, sz, vp]
         L.ym_conv2d_tile_counters.argtypes = [ctypes.POINTER(ConvDesc)]
         L.ym_maxpool3x3s2_fwd.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+        L.ym_stem_conv_bn_relu_maxpool.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
         L.ym_bilinear2x_fwd.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
         L.ym_softmax_rows.argtypes = [vp, vp, i64, i32, vp]
         L.ym_nms_workspace_bytes.argtypes = [ctypes.POINTER(NmsCfg)]
@@ -195,11 +196,11 @@ def lib():
         L.ym_class_box_loss.argtypes = [vp, vp, vp, vp, i32, i32, i32, f32, f32, i32, vp, vp, vp, vp, vp, vp, sz, vp]
         L.ym_semantic_loss.argtypes = [vp, i32, i32, i32, vp, vp, i32, i32, f32, vp, vp, vp]
         L.ym_conv2d_fuses_bn_stats.argtypes = [ctypes.POINTER(ConvDesc)]
-        L.ym_bn_train_fwd_stats.argtypes = [vp, i64, i32, vp, vp, f32, f32, vp, vp, vp, i32, vp, vp, vp, vp, vp]
+        L.ym_bn_train_fwd_stats.argtypes = [vp, i64, i32, vp, vp, f32, f32, vp, vp, vp, i32, vp, vp, vp, vp, i32, vp]
         L.ym_bn_train_bwd_workspace_bytes.argtypes = [i64, i32]
         L.ym_bn_train_bwd_workspace_bytes.restype = sz
         L.ym_bn_train_bwd.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, sz, vp]
-        L.ym_bn_train_bwd_apply.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]
+        L.ym_bn_train_bwd_apply.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp]
         L.ym_act_bias_bwd.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp, sz, vp]
         L.ym_maxpool3x3s2_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
         L.ym_maxpool3x3s2_fwd_idx.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
@@ -281,6 +282,15 @@ def conv2d_fwd(desc, workspace=None):
         check(lib().ym_conv2d_fwd(ctypes.byref(desc), ws_ptr, ws_bytes, stream_ptr()), 'ym_conv2d_fwd')
     finally:
         desc.tile_counters = counters          # the caller's descriptor is not ours to edit (tuners re-plan it with other tiles)
+
+
+def stem_conv_bn_relu_maxpool(img, w_packed, scale, shift, out):
+    """img NCHW [B,3,H,W] -> out NHWC [B,Hp,Wp,64]: the eval-mode ResNet stem in one launch (ym_stem_conv_bn_relu_maxpool)."""
+    b, c, h, w = img.shape
+    if c != 3 or tuple(w_packed.shape) != (64, 224):
+        raise RuntimeError(f'stem: expects a 3-channel image and a [64, 224] packed filter, got {tuple(img.shape)} / {tuple(w_packed.shape)}')
+    check(lib().ym_stem_conv_bn_relu_maxpool(ptr(img), ptr(w_packed), ptr(scale), ptr(shift), ptr(out), b, h, w, w_packed.shape[1],
+                                             stream_ptr()), 'ym_stem_conv_bn_relu_maxpool')
 
 
 def maxpool3x3s2(x, out):

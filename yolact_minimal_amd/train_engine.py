@@ -22,6 +22,12 @@ from .hip import ConvDesc, WgradDesc, ACT_NONE, ACT_RELU, ACT_TANH
 
 _scratch = {}
 _desc_cache = {}      # shape key -> (descriptor with every shape-dependent field set, ...): see _conv_forward
+launch_counts = None  # tools/train_layer_table.py sets this to a dict: desc-cache key -> launches (per-shape accounting of a step)
+
+
+def _count(key):
+    if launch_counts is not None:
+        launch_counts[key] = launch_counts.get(key, 0) + 1
 
 # ---- per-shape kernel configuration (measured on MI355X; same JSON as the inference engine) ---------------------
 _TUNING = os.environ.get('YM_TUNE_TRAIN', '0') == '1'     # sweep unseen shapes inline and remember the winner
@@ -214,6 +220,11 @@ class _StatsPool:
 
 
 _stats_pool = _StatsPool()
+# The fused statistics are accumulated with one fp64 atomic per channel per output-tile row: a layer1 conv at batch 8 has 2312 tile
+# rows, i.e. 2312 atomics queued on every channel's address (the launch took 2.5x as long as the same conv without statistics).
+# R replicas of the [2][C] sums (tile row t adds into replica t % R, ym_conv_desc.bn_replicas) cut the queue by R; the BatchNorm
+# kernels that consume the sums add the replicas up.  YM_BN_REPLICAS=1: the single copy of rounds 1-4.
+_BN_REPLICAS = max(1, int(os.environ.get('YM_BN_REPLICAS', '16')))
 
 
 # ---- packed weight images ---------------------------------------------------------------------------------------------------
@@ -403,7 +414,9 @@ def _conv_forward(x, wp, k_pad, cout_pad, kh, kw, stride, pad, shift, act, resid
             d.seg[i].out = sg[2]
     if fused:
         d.bn_sum, d.bn_sumsq = bn_stats.data_ptr(), bn_stats.data_ptr() + cout_pad * 8
+        d.bn_replicas = bn_stats.numel() // (2 * cout_pad)
     ws = scratch(x.device, ws_bytes)
+    _count(key)
     hip.conv2d_fwd(d, ws)
     if bn_stats is not None:
         return y, fused
@@ -443,11 +456,13 @@ def _conv_dgrad(dz, weight, cout_pad, x_shape, stride, pad, add=None, out=None, 
         d.residual = add.data_ptr()
     if fuses:
         assert bn_bwd.c == cin and bn_bwd.m == b * h * w
-        stats = _stats_pool.take(2 * cin, dz.device)                 # zeroed
+        stats = _stats_pool.take(2 * cin * _BN_REPLICAS, dz.device)                 # zeroed
         d.bn_sum, d.bn_sumsq = stats.data_ptr(), stats.data_ptr() + cin * 8
+        d.bn_replicas = _BN_REPLICAS
         d.bnb_y, d.bnb_out, d.bnb_mean, d.bnb_invstd = bn_bwd.y, bn_bwd.out, bn_bwd.mean, bn_bwd.invstd
         d.bnb_gamma, d.bnb_beta, d.bnb_relu = bn_bwd.gamma, bn_bwd.beta, bn_bwd.relu
     ws = scratch(dz.device, ws_bytes)
+    _count(key)
     hip.conv2d_fwd(d, ws)
     if fuses:
         bn_bwd.stats, bn_bwd.dout_ptr = stats, dx.data_ptr()
@@ -692,6 +707,7 @@ def _conv_wgrad_now(x, dz, weight_shape, stride, pad, weight_param=None, dw=None
     d, nbytes = ent
     d.x, d.dy, d.dw = x.data_ptr(), dz.data_ptr(), dw.data_ptr()
     d.accumulate = int(accumulate)
+    _count(key)
     if segments is not None:
         d.dw_seg[0], d.dw_seg[1] = segments[2].data_ptr(), segments[3].data_ptr()
     if defer:
@@ -988,7 +1004,7 @@ class ConvBn(torch.autograd.Function):
         ctx.producer, ctx.own = producer, own
         cout, cin, kh, kw = weight.shape
         wp, k_pad = _pack_fwd(weight, x.shape[-1], cout)
-        stats = _stats_pool.take(2 * cout, x.device)           # zeroed (the fused epilogue accumulates into it)
+        stats = _stats_pool.take(2 * cout * _BN_REPLICAS, x.device)           # zeroed (the fused epilogue accumulates into it)
         y, fused = _conv_forward(x, wp, k_pad, cout, kh, kw, stride, pad, None, ACT_NONE, bn_stats=stats)
         m = y.numel() // cout
         out = torch.empty_like(y)
@@ -999,7 +1015,7 @@ class ConvBn(torch.autograd.Function):
             hip.check(hip.lib().ym_bn_train_fwd_stats(hip.ptr(y), m, cout, hip.ptr(gamma.detach()), hip.ptr(beta.detach()), eps,
                                                       momentum, hip.ptr(running_mean), hip.ptr(running_var), res_ptr, int(relu),
                                                       hip.ptr(out), hip.ptr(mean), hip.ptr(invstd),
-                                                      ctypes.c_void_p(stats.data_ptr()), hip.stream_ptr()), 'ym_bn_train_fwd_stats')
+                                                      ctypes.c_void_p(stats.data_ptr()), _BN_REPLICAS, hip.stream_ptr()), 'ym_bn_train_fwd_stats')
         else:
             hip.check(hip.lib().ym_bn_train_fwd(hip.ptr(y), m, cout, hip.ptr(gamma.detach()), hip.ptr(beta.detach()), eps, momentum,
                                                 hip.ptr(running_mean), hip.ptr(running_var), res_ptr, int(relu),
@@ -1035,7 +1051,8 @@ class ConvBn(torch.autograd.Function):
             hip.check(hip.lib().ym_bn_train_bwd_apply(hip.ptr(dout), out_ptr, hip.ptr(y), m, cout, hip.ptr(gamma.detach()), beta_ptr,
                                                       hip.ptr(mean), hip.ptr(invstd), int(relu), hip.ptr(dy),
                                                       hip.ptr(dres) if has_res else None, hip.ptr(dgamma), hip.ptr(dbeta),
-                                                      ctypes.c_void_p(own.stats.data_ptr()), hip.stream_ptr()), 'ym_bn_train_bwd_apply')
+                                                      ctypes.c_void_p(own.stats.data_ptr()), own.stats.numel() // (2 * cout),
+                                                      hip.stream_ptr()), 'ym_bn_train_bwd_apply')
             bn_bwd_fused_launches[0] += 1
         else:
             ws = scratch(y.device, hip.lib().ym_bn_train_bwd_workspace_bytes(m, cout))
