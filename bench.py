@@ -145,26 +145,26 @@ def conv_roofline(engine, img, iters=5):
     stream), eager (no graph) so each launch can be bracketed.  Returns (flops per forward, seconds per forward,
     launches per forward)."""
     from yolact_minimal_amd import hip
-    convs = [arg for kind, arg in engine.ops if kind == 'conv']
+    # (the fused stem + max-pool launch counts as a conv launch: it carries the stem's FLOPs)
+    timed = [(kind, arg) for kind, arg in engine.ops if kind in ('conv', 'stem_pool')]
+    convs = [arg if kind == 'conv' else arg[0] for kind, arg in timed]
     ws = engine.workspace
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in convs]
     total = 0.0
     per_layer = [0.0] * len(convs)
     for it in range(iters + 1):
-        hip.nchw_to_nhwc4(img, engine.x_in)
+        if engine.fused_stem is None:
+            hip.nchw_to_nhwc4(img, engine.x_in)
+        engine._img = img
         ci = 0
         for kind, arg in engine.ops:
-            if kind == 'conv':
+            if kind in ('conv', 'stem_pool'):
                 evs[ci][0].record()
-                hip.conv2d_fwd(arg.desc, ws)
+                engine._launch_one(kind, arg, ws)
                 evs[ci][1].record()
                 ci += 1
-            elif kind == 'maxpool':
-                hip.maxpool3x3s2(arg[0], arg[1])
-            elif kind == 'bilinear':
-                hip.bilinear2x(arg[0], arg[1], arg[2])
-            elif kind == 'softmax':
-                hip.softmax_rows(arg[0], arg[1])
+            else:
+                engine._launch_one(kind, arg, ws)
         torch.cuda.synchronize()
         if it == 0:
             continue   # warm-up
@@ -414,7 +414,7 @@ def ddp_block(tr, timing, img_s, world, cfg_name, batch):
     collectives cost where backward could not hide them, and what the process group actually saw."""
     import torch.distributed as dist
     ref, ref_src = None, None
-    for r in (4, 3):
+    for r in (5, 4, 3):
         q = os.path.join(REPO, 'profiles', f'r0{r}_bench_line.json')
         if os.path.exists(q):
             try:
@@ -599,7 +599,7 @@ def main():
         flops, conv_secs, launches, layers = conv_roofline(fw.engine, fw.img)
         achieved = flops / conv_secs / 1e12
         traffic, traffic_src = None, None
-        pmc_path = next((q for q in (os.path.join(REPO, 'profiles', f'r0{r}_pmc_hbm_infer_bs1_res101.json') for r in (4, 3))
+        pmc_path = next((q for q in (os.path.join(REPO, 'profiles', f'r0{r}_pmc_hbm_infer_bs1_res101.json') for r in (5, 4, 3))
                          if os.path.exists(q)), '')
         if args.cfg == 'res101_coco' and args.batch == 1 and pmc_path:
             # HBM-side bytes per conv launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2

@@ -123,11 +123,6 @@ typedef struct {
     int32_t grid_wgs;        /* persistent kernel (stages 4x): workgroups to launch; 0 = as many as the CUs hold (LDS-limited, at most  */
                              /* 4 per CU), never more than there are work items.  Wave kernel with DMA rings (kwaves > 0, stages 22-24):  */
                              /* waves per workgroup, 0 = 4 (1 / 2 with kwaves <= that: single tiles are balanced over the CUs)            */
-    int32_t bn_replicas;     /* 0 / 1: bn_sum / bn_sumsq are [Cout] each.  R > 1: the statistics are spread over R replicas -- output    */
-                             /* tile row t (workgroup w of the weight-stationary kernel) adds into replica t % R, which lives r * 2 *    */
-                             /* Cout doubles after bn_sum / bn_sumsq (caller: 2 * Cout * R doubles, zeroed, bn_sumsq = bn_sum + Cout).   */
-                             /* A layer with thousands of row tiles otherwise queues that many fp64 atomics on every channel's address   */
-                             /* (2312 at M = 147968: 2.5x the launch time).  ym_bn_train_fwd_stats / _bwd_apply take the same R.          */
 } ym_conv_desc;
 
 /* y = act(conv(x, w) * scale + shift + residual), one launch (plus a reduce launch if K is split).
@@ -291,10 +286,9 @@ int ym_bn_train_fwd(const float* y, int64_t M, int C, const float* gamma, const 
                     float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes, ym_stream_t s);
 /* Same, but the first 16*C bytes of `workspace` already hold the fp64 sum[C] | sumsq[C] of y (accumulated by
  * ym_conv2d_fwd through ym_conv_desc.bn_sum / bn_sumsq): skips the statistics pass over y. */
-/* (`replicas`: see ym_conv_desc.bn_replicas -- the sums are the total over `replicas` (>= 1) copies spaced 2 * C doubles apart) */
 int ym_bn_train_fwd_stats(const float* y, int64_t M, int C, const float* gamma, const float* beta, float eps,
                           float momentum, float* running_mean, float* running_var, const float* residual, int relu,
-                          float* out, float* save_mean, float* save_invstd, const void* stats, int replicas, ym_stream_t s);
+                          float* out, float* save_mean, float* save_invstd, const void* stats, ym_stream_t s);
 
 /* Backward of the above: dz = dout * (out > 0 if relu); dres (optional) = dz; dgamma/dbeta [C];
  * out may be NULL with relu = 1 when the forward had NO residual and `beta` is given: the mask is then re-derived from y with the
@@ -310,7 +304,7 @@ int ym_bn_train_bwd(const float* dout, const float* out, const float* y, int64_t
  * data-gradient conv that produced `dout` (ym_conv_desc.bnb_*).  Every other argument as in ym_bn_train_bwd. */
 int ym_bn_train_bwd_apply(const float* dout, const float* out, const float* y, int64_t M, int C, const float* gamma,
                           const float* beta, const float* save_mean, const float* save_invstd, int relu, float* dy, float* dres,
-                          float* dgamma, float* dbeta, const void* stats, int replicas, ym_stream_t s);
+                          float* dgamma, float* dbeta, const void* stats, ym_stream_t s);
 
 /* Gradient of the fused prediction-head output w.r.t. the 351(+pad)-channel conv output, for all FPN levels in one launch:
  * the loss hands back dclass [B][N][nc], dbox [B][N][4], dcoef [B][N][cd] (N = anchors of all levels, anchor = (pixel, a) level by

@@ -28,7 +28,7 @@ def per_kernel(db, counter):
 
 def main(fetch_db, write_db, out_path, desc):
     f, w = per_kernel(fetch_db, 'FETCH_SIZE'), per_kernel(write_db, 'WRITE_SIZE')
-    conv = [k for k in f if k.startswith('conv_igemm_f32') or k.startswith('conv_igemm_pers') or k.startswith('conv_wdma_f32') or k.startswith('conv_wave_f32') or k.startswith('conv_splitk_reduce')]
+    conv = [k for k in f if k.startswith('conv_igemm_f32') or k.startswith('conv_igemm_pers') or k.startswith('conv_wdma_f32') or k.startswith('conv_wave_f32') or k.startswith('conv1x1_ws') or k.startswith('k_stem_pool') or k.startswith('conv_splitk_reduce')]
     main_k = [k for k in conv if not k.startswith('conv_splitk_reduce')]
     launches = sum(f[k][0] for k in main_k)
     fetch_b = sum(f[k][1] for k in conv) * 1024 * 2

@@ -19,9 +19,9 @@ run() {   # name, command...
 BENCH="python $R/bench.py --no-extra --no-cpu-baseline --no-train --lean --inflight 1"
 BENCH4="python $R/bench.py --no-extra --no-cpu-baseline --no-train --lean"
 db=$(run infer_bs1 $BENCH --steps 30 --warmup 5)
-[ -n "$db" ] && python $R/tools/prof_summary.py "$db" "$OUT/${TAG}_infer_bs1_res101_kernel_stats.md" > /dev/null && python $R/tools/gap_summary.py "$db" 30 k_nchw_to_nhwc4 > "$OUT/${TAG}_infer_bs1_res101_gaps.txt"
+[ -n "$db" ] && python $R/tools/prof_summary.py "$db" "$OUT/${TAG}_infer_bs1_res101_kernel_stats.md" > /dev/null && python $R/tools/gap_summary.py "$db" 30 k_stem_pool > "$OUT/${TAG}_infer_bs1_res101_gaps.txt"
 db=$(run infer_bs1_inflight4 $BENCH4 --steps 60 --warmup 8)
-[ -n "$db" ] && python $R/tools/prof_summary.py "$db" "$OUT/${TAG}_infer_bs1_inflight4_res101_kernel_stats.md" > /dev/null && python $R/tools/gap_summary.py "$db" 30 k_nchw_to_nhwc4 > "$OUT/${TAG}_infer_bs1_inflight4_res101_gaps.txt"
+[ -n "$db" ] && python $R/tools/prof_summary.py "$db" "$OUT/${TAG}_infer_bs1_inflight4_res101_kernel_stats.md" > /dev/null && python $R/tools/gap_summary.py "$db" 30 k_stem_pool > "$OUT/${TAG}_infer_bs1_inflight4_res101_gaps.txt"
 db=$(YM_CONV_MMA=3 run infer_bs8_bf16x3 $BENCH --batch 8 --steps 20 --warmup 5)
 [ -n "$db" ] && python $R/tools/prof_summary.py "$db" "$OUT/${TAG}_infer_bs8_res101_bf16x3_kernel_stats.md" > /dev/null
 db=$(run infer_bs8 $BENCH --batch 8 --steps 20 --warmup 5)
@@ -30,8 +30,8 @@ db=$(run train python $R/tools/train_profile.py --steps 10)
 [ -n "$db" ] && python $R/tools/prof_summary.py "$db" "$OUT/${TAG}_train_res101_bs8_kernel_stats.md" > /dev/null && python $R/tools/gap_summary.py "$db" 30 k_sgd > "$OUT/${TAG}_train_res101_bs8_gaps.txt"
 # HBM-side bytes per conv launch (separate PMC passes, kernel-trace only)
 rm -rf "$OUT/raw_pmc_f" "$OUT/raw_pmc_w"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/raw_pmc_f" -o f -- $BENCH --steps 20 --warmup 5 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/raw_pmc_w" -o w -- $BENCH --steps 20 --warmup 5 > /dev/null 2>&1
+YM_GRAPH=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/raw_pmc_f" -o f -- $BENCH --steps 20 --warmup 5 > /dev/null 2>&1      # (eager launches: rocprofv3 --pmc crashes on hipGraph replays on this pool)
+YM_GRAPH=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/raw_pmc_w" -o w -- $BENCH --steps 20 --warmup 5 > /dev/null 2>&1
 f=$(find "$OUT/raw_pmc_f" -name '*.db' | head -1); w=$(find "$OUT/raw_pmc_w" -name '*.db' | head -1)
 [ -n "$f" ] && [ -n "$w" ] && python $R/tools/pmc_summary.py "$f" "$w" "$OUT/${TAG}_pmc_hbm_infer_bs1_res101.json" "bench.py --steps 20 --warmup 5 --no-extra --no-cpu-baseline --no-train --lean --inflight 1 (res101_coco 544 bs=1, one request at a time)" > /dev/null
 rm -rf "$OUT"/raw_*          # the raw databases are large; only the summaries travel back

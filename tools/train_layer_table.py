@@ -83,7 +83,7 @@ for key, n in counts.items():
         if d.shift:
             d.shift = opb.data_ptr()
         if d.bn_sum:
-            d.bn_sum, d.bn_sumsq = stats.data_ptr(), stats.data_ptr() + 8 * d.Cout      # (replicas: 2 * Cout doubles apart)
+            d.bn_sum, d.bn_sumsq = stats.data_ptr(), stats.data_ptr() + 8 * d.Cout
         if d.bnb_y:
             d.bnb_y = opa.data_ptr()
             d.bnb_out = opa.data_ptr() if d.bnb_out else None

@@ -73,7 +73,6 @@ struct ConvP {
     const float* bnb_gamma;
     const float* bnb_beta;
     int bnb_relu;
-    int bn_rep;        // replicas of the statistics (>= 1): tile row t / workgroup w adds into replica t % bn_rep, 2 * Cout doubles apart
     int* counters;     // optional per-output-tile arrival counters: fused split-K finish (see ym_conv_desc.tile_counters)
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, Kpad;
     int M, HoWo, nkt, ksplit, kt_per_split, tiles_m, tiles_n;

@@ -750,10 +750,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
                 double S = 0.0, Q = 0.0;
 #pragma unroll
                 for (int r = 0; r < RPP; ++r) { S += R[(r * BN + tid) * 2]; Q += R[(r * BN + tid) * 2 + 1]; }
-                // (replica tile_m % bn_rep: a layer with thousands of M tiles would queue them all on one address per channel)
-                const size_t rep = (size_t)(tile_m % p.bn_rep) * 2 * p.Cout;
-                atomicAdd(p.bn_sum + rep + n0 + tid, S);
-                atomicAdd(p.bn_sumsq + rep + n0 + tid, Q);
+                atomicAdd(p.bn_sum + n0 + tid, S);
+                atomicAdd(p.bn_sumsq + n0 + tid, Q);
             }
         }
         YM_STAMP(3);
@@ -1121,8 +1119,6 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
         p.vec = (vec_epilogue(d) && ((uintptr_t)workspace & 15) == 0) ? 1 : 0;
     }
     p.bn_sum = d->bn_sum; p.bn_sumsq = d->bn_sumsq;
-    p.bn_rep = d->bn_replicas > 1 ? d->bn_replicas : 1;
-    YM_REQUIRE(p.bn_rep == 1 || !d->bn_sum || d->bn_sumsq == d->bn_sum + d->Cout, "conv: bn_replicas > 1 needs bn_sumsq == bn_sum + Cout");
     p.bnb_y = d->bnb_y; p.bnb_out = d->bnb_out; p.bnb_mean = d->bnb_mean; p.bnb_invstd = d->bnb_invstd;
     p.bnb_gamma = d->bnb_gamma; p.bnb_beta = d->bnb_beta; p.bnb_relu = d->bnb_relu;
     p.trace = nullptr; p.trace_epoch = nullptr; p.trace_ring = 0; p.trace_stride = 0; p.trace_rt = 0; p.trace_hw = nullptr;

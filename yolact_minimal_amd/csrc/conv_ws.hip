@@ -233,9 +233,8 @@ __global__ __launch_bounds__(256) void conv1x1_ws(const ConvP p, int nslices, in
             const double a = ds1[jj] + __shfl_xor(ds1[jj], 32), b = ds2[jj] + __shfl_xor(ds2[jj], 32);
             const int col = n0 + wn * 64 + jj * 32 + frag_row;
             if (khalf == 0 && col < N) {
-                const size_t rep = (size_t)((int)blockIdx.x % p.bn_rep) * 2 * N;
-                atomicAdd(p.bn_sum + rep + col, a);
-                atomicAdd(p.bn_sumsq + rep + col, b);
+                atomicAdd(p.bn_sum + col, a);
+                atomicAdd(p.bn_sumsq + col, b);
             }
         }
     }

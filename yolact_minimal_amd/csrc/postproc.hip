@@ -9,11 +9,19 @@
 // implementation-defined) are resolved here as "lower index first" (= a stable descending sort).
 #pragma clang fp contract(off)
 #include <limits.h>
+#include <type_traits>
 #include "ym_common.h"
 
 namespace {
 
 constexpr int NT = 1024;      // threads of the selection kernels
+// phase stamps of the single-workgroup kernels (debug build `make trace` only; tools/nms_stamps.py): s_memrealtime (100 MHz) of
+// thread 0 into the workspace's counter block, 64-bit slot `i` behind the 8 integer counters
+#ifdef YM_TRACE
+#define YM_NMS_STAMP(cnt, i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) reinterpret_cast<long long*>((cnt) + 8)[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define YM_NMS_STAMP(cnt, i) do { } while (0)
+#endif
 constexpr int TOPK_CAP = 256; // >= cfg.top_k
 constexpr int DET_CAP = 128;  // >= cfg.max_detections
 
@@ -413,11 +421,13 @@ __global__ __launch_bounds__(NT) void k_class_topk_iou(const NmsWs w0, int N, in
     const NmsWs w = image_ws(w0, ws_stride, blockIdx.y);
     __shared__ TopkShared<TOPK_CAP> sh;
     __shared__ __attribute__((aligned(16))) float sbox[TOPK_CAP * 4];
+    YM_NMS_STAMP(w.counters, 8);
     const int K = w.counters[0];
     if (K == 0) return;
     const int c = blockIdx.x, tid = threadIdx.x;
     const float* srow = w.scores_t + (size_t)c * N;
     const int cnt = block_topk_sorted<TOPK_CAP>([&](int i) { return f2key(srow[i]); }, K, top_k, sh);
+    YM_NMS_STAMP(w.counters, 9);
     __shared__ uint8_t skeep[TOPK_CAP];
     __shared__ int wtot[TOPK_CAP / 64];
     for (int j = tid; j < cnt; j += NT)
@@ -438,6 +448,7 @@ __global__ __launch_bounds__(NT) void k_class_topk_iou(const NmsWs w0, int N, in
         if (lane == 0) skeep[j] = any_bad ? 0 : 1;
     }
     __syncthreads();
+    YM_NMS_STAMP(w.counters, 10);
     // the survivors, compacted in rank order (still sorted by score, ties by index): what the global top-k merges
     bool f = false;
     int pre = 0;
@@ -459,6 +470,7 @@ __global__ __launch_bounds__(NT) void k_class_topk_iou(const NmsWs w0, int N, in
         for (int x = 0; x < TOPK_CAP / 64; ++x) t += wtot[x];
         w.top_cnt[c] = t;
     }
+    YM_NMS_STAMP(w.counters, 11);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -486,7 +498,8 @@ __device__ __forceinline__ uint32_t wave_umax(uint32_t x) {
 // head (key descending, ties by the lower flat slot = class-major, rank-minor: the order of the radix select it replaces), the
 // owning lane advances.  ~100 rounds of ~60 instructions against a 4-pass radix select over 20 480 slots with 1024-thread
 // barriers: 53 -> ~12 us.
-__global__ __launch_bounds__(256) void k_final_merge(const NmsWs w0, int ncls, int max_det, const float* __restrict__ coef,
+template <int LPL>
+__global__ __launch_bounds__(NT) void k_final_merge(const NmsWs w0, int ncls, int max_det, const float* __restrict__ coef,
                                                      int coef_dim, int32_t* __restrict__ out_count,
                                                      int64_t* __restrict__ out_ids, float* __restrict__ out_scores,
                                                      float* __restrict__ out_boxes, float* __restrict__ out_coefs, size_t ws_stride,
@@ -506,6 +519,7 @@ __global__ __launch_bounds__(256) void k_final_merge(const NmsWs w0, int ncls, i
     __shared__ int n_sel;
     __shared__ int lcnt[256];                              // (ncls <= 255)
     const int tid = threadIdx.x;
+    YM_NMS_STAMP(w.counters, 0);
     const int K = w.counters[0];
     if (K == 0) {
         if (tid == 0) out_count[0] = 0;
@@ -513,9 +527,10 @@ __global__ __launch_bounds__(256) void k_final_merge(const NmsWs w0, int ncls, i
     }
     if (tid < ncls) lcnt[tid] = min(w.top_cnt[tid], max_det);
     __syncthreads();
+    YM_NMS_STAMP(w.counters, 1);
     // the leading DET_CAP scores of every class row, 16 bytes per load, all loads independent (entries past the class's survivor
     // count are whatever an earlier launch left there: masked by the count, never interpreted)
-    for (int q4 = tid; q4 < ncls * (DET_CAP / 4); q4 += 256) {
+    for (int q4 = tid; q4 < ncls * (DET_CAP / 4); q4 += NT) {       // (<= 8 rounds of 1024 threads)
         const int c = q4 / (DET_CAP / 4), j = (q4 - c * (DET_CAP / 4)) * 4;
         const f32x4 v = *reinterpret_cast<const f32x4*>(w.top_score + c * TOPK_CAP + j);
         const int cnt = lcnt[c];
@@ -524,10 +539,12 @@ __global__ __launch_bounds__(256) void k_final_merge(const NmsWs w0, int ncls, i
         for (int e = 0; e < 4; ++e) dst[e] = j + e < cnt ? f2key(v[e]) : 0u;
     }
     __syncthreads();
+    YM_NMS_STAMP(w.counters, 2);
     if (tid < 64) {
-        constexpr int LPL = 4;                             // lists per lane: ncls <= 255 (check_cfg)
-        // per list of this lane: position of its head, the head's key and the key behind it (read one round before it can become
-        // the head, so that no LDS latency sits on the round's critical path)
+        // LPL lists per lane (template: 2 for COCO's 80 classes; a lone wave issues one instruction every ~4 cycles, so the round's
+        // instruction count IS its latency -- 100 rounds of ~190 instructions with LPL = 4 took 44 us).
+        // Per list of this lane: position of its head, the head's key and the key behind it (read one round before it can become
+        // the head, so that no LDS latency sits on the round's critical path).
         int head[LPL];
         uint32_t hk[LPL], nk[LPL];
 #pragma unroll
@@ -537,15 +554,13 @@ __global__ __launch_bounds__(256) void k_final_merge(const NmsWs w0, int ncls, i
             hk[q] = c < ncls ? lkeys[c * DET_CAP] : 0u;
             nk[q] = c < ncls ? lkeys[c * DET_CAP + 1] : 0u;
         }
-        uint32_t bk;
-        int bf;
-        auto lane_best = [&]() {                           // registers only
-            bk = 0u; bf = INT_MAX;
+        uint32_t bk = 0u;
+        int bf = INT_MAX;
+        auto lane_best = [&]() __attribute__((always_inline)) {                           // registers only
+            bk = hk[0]; bf = tid * TOPK_CAP + head[0];
 #pragma unroll
-            for (int q = 0; q < LPL; ++q) {
-                const int f = (tid + 64 * q) * TOPK_CAP + head[q];
-                if (hk[q] > bk || (hk[q] == bk && hk[q] != 0u && f < bf)) { bk = hk[q]; bf = f; }
-            }
+            for (int q = 1; q < LPL; ++q)
+                if (hk[q] > bk) { bk = hk[q]; bf = (tid + 64 * q) * TOPK_CAP + head[q]; }   // (equal keys: the lower class = lower slot stays)
         };
         lane_best();
         int n = 0;
@@ -559,36 +574,48 @@ __global__ __launch_bounds__(256) void k_final_merge(const NmsWs w0, int ncls, i
             if (__popcll(tied) == 1) mf = __builtin_amdgcn_readlane(bf, __ffsll((long long)tied) - 1);
             else mf = (int)~wave_umax(bk == mk ? ~(uint32_t)bf : 0u);
             if (tid == 0) sel[n] = mf;
-            const int c = mf / TOPK_CAP;
-            if ((c & 63) == tid) {                         // the owner advances that list
-#pragma unroll
-                for (int q = 0; q < LPL; ++q)
-                    if (q == (c >> 6)) {
-                        ++head[q];
-                        hk[q] = nk[q];
-                        nk[q] = head[q] + 1 < DET_CAP ? lkeys[c * DET_CAP + head[q] + 1] : 0u;
-                    }
+            const int c = mf / TOPK_CAP;                   // scalar
+            const int q = c >> 6;
+            if ((c & 63) == tid) {                         // the owner advances that list (q is wave-uniform: one block runs)
+                auto advance = [&](auto QC) __attribute__((always_inline)) {
+                    constexpr int Q = decltype(QC)::value;
+                    ++head[Q];
+                    hk[Q] = nk[Q];
+                    nk[Q] = head[Q] + 1 < DET_CAP ? lkeys[c * DET_CAP + head[Q] + 1] : 0u;
+                };
+                if (q == 0) advance(std::integral_constant<int, 0>{});
+                if constexpr (LPL > 1) { if (q == 1) advance(std::integral_constant<int, 1>{}); }
+                if constexpr (LPL > 2) { if (q == 2) advance(std::integral_constant<int, 2>{}); }
+                if constexpr (LPL > 3) { if (q == 3) advance(std::integral_constant<int, 3>{}); }
                 lane_best();
             }
         }
         if (tid == 0) n_sel = n;
     }
     __syncthreads();
+    YM_NMS_STAMP(w.counters, 3);
     const int n = n_sel;
     if (tid == 0) out_count[0] = n;
-    for (int j = tid; j < n; j += 256) {
-        const int f = sel[j];
+    // the two dependent look-ups (slot -> compacted candidate -> anchor) once per detection; the gathers below are then single loads
+    __shared__ int s_k[DET_CAP], s_a[DET_CAP];
+    if (tid < n) {
+        const int k = w.top_idx[sel[tid]];
+        s_k[tid] = k;
+        s_a[tid] = w.keep_idx[k];
+    }
+    __syncthreads();
+    if (tid < n) {
+        const int f = sel[tid];
         const int c = f / TOPK_CAP;
-        const int k = w.top_idx[f];
-        out_ids[j] = c;
-        out_scores[j] = key2f(lkeys[c * DET_CAP + (f - c * TOPK_CAP)]);
-        *reinterpret_cast<f32x4*>(out_boxes + j * 4) = *reinterpret_cast<const f32x4*>(w.boxes_k + (size_t)k * 4);
+        out_ids[tid] = c;
+        out_scores[tid] = key2f(lkeys[c * DET_CAP + (f - c * TOPK_CAP)]);
+        *reinterpret_cast<f32x4*>(out_boxes + tid * 4) = *reinterpret_cast<const f32x4*>(w.boxes_k + (size_t)s_k[tid] * 4);
     }
-    for (int e = tid; e < n * coef_dim; e += 256) {
+    for (int e = tid; e < n * coef_dim; e += NT) {
         const int j = e / coef_dim, d = e - j * coef_dim;
-        const int a = w.keep_idx[w.top_idx[sel[j]]];
-        out_coefs[e] = coef[(size_t)a * coef_dim + d];
+        out_coefs[e] = coef[(size_t)s_a[j] * coef_dim + d];
     }
+    YM_NMS_STAMP(w.counters, 4);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -824,13 +851,19 @@ extern "C" int ym_detect_fast_nms_batch(const float* class_pred, const float* bo
     const int ncls = cfg->num_classes - 1;
     hipLaunchKernelGGL(k_class_topk_iou, dim3(ncls, B), dim3(NT), 0, st, w, cfg->num_anchors, cfg->top_k, cfg->iou_thre, stride);
     const size_t merge_lds = (size_t)ncls * DET_CAP * sizeof(uint32_t);          // <= 255 * 128 * 4 = 130 KB
-    static size_t merge_lds_set = 0;
-    if (merge_lds > merge_lds_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_final_merge), hipFuncAttributeMaxDynamicSharedMemorySize, (int)merge_lds);
-        merge_lds_set = merge_lds;
-    }
-    hipLaunchKernelGGL(k_final_merge, dim3(1, B), dim3(256), merge_lds, st, w, ncls, cfg->max_det, coef_pred, cfg->coef_dim, out_count,
-                       out_ids, out_scores, out_boxes, out_coefs, stride, cfg->num_anchors);
+    const int lpl = (ncls + 63) / 64;                    // lists per lane of the merging wave (1..4: num_classes <= 256)
+#define YM_MERGE(L_)                                                                                                              \
+    do {                                                                                                                          \
+        static size_t set_ = 0;                                                                                                   \
+        if (merge_lds > set_) {                                                                                                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_final_merge<L_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)merge_lds); \
+            set_ = merge_lds;                                                                                                     \
+        }                                                                                                                         \
+        hipLaunchKernelGGL(k_final_merge<L_>, dim3(1, B), dim3(NT), merge_lds, st, w, ncls, cfg->max_det, coef_pred, cfg->coef_dim, \
+                           out_count, out_ids, out_scores, out_boxes, out_coefs, stride, cfg->num_anchors);                       \
+    } while (0)
+    if (lpl <= 1) YM_MERGE(1); else if (lpl == 2) YM_MERGE(2); else if (lpl == 3) YM_MERGE(3); else YM_MERGE(4);
+#undef YM_MERGE
     return ym_check_launch("fast_nms");
 }
 

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void k_bn_finalize_apply(const float* __restri
                                                             float* __restrict__ run_mean, float* __restrict__ run_var,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ residual, int relu, float* __restrict__ out,
-                                                            long long M, int C, int rep) {
+                                                            long long M, int C) {
     const int C4 = C >> 2;
     const size_t gt = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int cq = (int)(gt % C4);
@@ -234,10 +234,8 @@ __global__ __launch_bounds__(256) void k_bn_finalize_apply(const float* __restri
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int c = cq * 4 + e;
-        double S = sum[c], Q = sumsq[c];
-        for (int r = 1; r < rep; ++r) { S += sum[(size_t)r * 2 * C + c]; Q += sumsq[(size_t)r * 2 * C + c]; }   // replicas, in order
-        const double m = S / (double)M;
-        double var = Q / (double)M - m * m;
+        const double m = sum[c] / (double)M;
+        double var = sumsq[c] / (double)M - m * m;
         if (var < 0) var = 0;
         mu[e] = (float)m;
         is[e] = (float)(1.0 / sqrt(var + (double)eps));
@@ -272,18 +270,12 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                                                        const float* __restrict__ beta, const double* __restrict__ dbeta,
                                                        const double* __restrict__ dgamma, int relu, float* __restrict__ dy,
                                                        float* __restrict__ dres, long long M, int C, float* __restrict__ dgamma_f,
-                                                       float* __restrict__ dbeta_f, int rep) {
+                                                       float* __restrict__ dbeta_f) {
     const int C4 = C >> 2;
     const size_t total = (size_t)M * C4;
     const float invM = 1.f / (float)M;
-    // the two fp64 sums of channel c: the total over `rep` replicas spaced 2 C doubles apart, summed in replica order
-    auto tot = [&](const double* v, int c) __attribute__((always_inline)) {
-        double t = v[c];
-        for (int r = 1; r < rep; ++r) t += v[(size_t)r * 2 * C + c];
-        return t;
-    };
     if (blockIdx.x == 0)
-        for (int c = threadIdx.x; c < C; c += 256) { dgamma_f[c] = (float)tot(dgamma, c); dbeta_f[c] = (float)tot(dbeta, c); }
+        for (int c = threadIdx.x; c < C; c += 256) { dgamma_f[c] = (float)dgamma[c]; dbeta_f[c] = (float)dbeta[c]; }
     // When the grid stride is a multiple of C/4 a thread keeps its channel quad for the whole tensor: the seven per-channel vectors
     // (mean, invstd, gamma, beta, the two fp64 sums) are then loaded and converted ONCE instead of per 16 bytes of dout (they were
     // 8 of the 11 load instructions of an iteration of this HBM-bound pass).  Same arithmetic, same order.
@@ -296,7 +288,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
         g = *reinterpret_cast<const f32x4*>(gamma + cq * 4);
         if (relu && !out) bt = *reinterpret_cast<const f32x4*>(beta + cq * 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { dbf[e] = (float)tot(dbeta, cq * 4 + e); dgf[e] = (float)tot(dgamma, cq * 4 + e); }
+        for (int e = 0; e < 4; ++e) { dbf[e] = (float)dbeta[cq * 4 + e]; dgf[e] = (float)dgamma[cq * 4 + e]; }
     };
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (fixed_c && i < total) load_channel((int)(i % C4));
@@ -565,9 +557,9 @@ extern "C" int ym_bn_train_fwd(const float* y, int64_t M, int C, const float* ga
 
 extern "C" int ym_bn_train_fwd_stats(const float* y, int64_t M, int C, const float* gamma, const float* beta, float eps,
                                      float momentum, float* running_mean, float* running_var, const float* residual,
-                                     int relu, float* out, float* save_mean, float* save_invstd, const void* stats, int replicas,
+                                     int relu, float* out, float* save_mean, float* save_invstd, const void* stats,
                                      ym_stream_t s) {
-    YM_REQUIRE(y && gamma && beta && out && save_mean && save_invstd && stats && replicas >= 1, "bn_train_fwd_stats: null pointer / replicas < 1");
+    YM_REQUIRE(y && gamma && beta && out && save_mean && save_invstd && stats, "bn_train_fwd_stats: null pointer");
     YM_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_train_fwd_stats: C %% 4 != 0");
     hipStream_t st = (hipStream_t)s;
     const double* sum = (const double*)stats;
@@ -582,11 +574,10 @@ extern "C" int ym_bn_train_fwd_stats(const float* y, int64_t M, int C, const flo
             grid = (grid + step - 1) / step * step;
             while (grid * 256 < C4) grid += step;
             hipLaunchKernelGGL(k_bn_finalize_apply, dim3((unsigned)grid), dim3(256), 0, st, y, sum, sum + C, eps, momentum, save_mean,
-                               save_invstd, running_mean, running_var, gamma, beta, residual, relu, out, (long long)M, C, replicas);
+                               save_invstd, running_mean, running_var, gamma, beta, residual, relu, out, (long long)M, C);
             return ym_check_launch("bn_train_fwd_stats");
         }
     }
-    YM_REQUIRE(replicas == 1, "bn_train_fwd_stats: C = %d has no one-launch grid; replicated statistics need one (C / 4 must divide 256 g, g <= 64)", C);
     hipLaunchKernelGGL(k_bn_finalize, dim3(ym_cdiv(C, 256)), dim3(256), 0, st, sum, sum + C, (long long)M, eps, momentum,
                        save_mean, save_invstd, running_mean, running_var, C);
     hipLaunchKernelGGL(k_bn_apply, dim3(ew_grid((size_t)M * (C / 4))), dim3(256), 0, st, y, save_mean, save_invstd, gamma, beta,
@@ -628,20 +619,19 @@ extern "C" int ym_bn_train_bwd(const float* dout, const float* out, const float*
                            relu, 0, db, dg, (double*)nullptr, gamma, beta);
     }
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid((size_t)M * (C / 4))), dim3(256), 0, st, dout, out, y, save_mean,
-                       save_invstd, gamma, beta, db, dg, relu, dy, dres, (long long)M, C, dgamma, dbeta, 1);
+                       save_invstd, gamma, beta, db, dg, relu, dy, dres, (long long)M, C, dgamma, dbeta);
     return ym_check_launch("bn_train_bwd");
 }
 
 extern "C" int ym_bn_train_bwd_apply(const float* dout, const float* out, const float* y, int64_t M, int C, const float* gamma,
                                      const float* beta, const float* save_mean, const float* save_invstd, int relu, float* dy,
-                                     float* dres, float* dgamma, float* dbeta, const void* stats, int replicas, ym_stream_t s) {
-    YM_REQUIRE(replicas >= 1, "bn_train_bwd_apply: replicas < 1");
+                                     float* dres, float* dgamma, float* dbeta, const void* stats, ym_stream_t s) {
     YM_REQUIRE(dout && y && gamma && save_mean && save_invstd && dy && dgamma && dbeta && stats && (out || !relu || beta),
                "bn_train_bwd_apply: null pointer (relu needs `out`, or `beta` to re-derive the mask from y)");
     YM_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_train_bwd_apply: C %% 4 != 0");
     const double* db = (const double*)stats;
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid((size_t)M * (C / 4))), dim3(256), 0, (hipStream_t)s, dout, out, y, save_mean,
-                       save_invstd, gamma, beta, db, db + C, relu, dy, dres, (long long)M, C, dgamma, dbeta, replicas);
+                       save_invstd, gamma, beta, db, db + C, relu, dy, dres, (long long)M, C, dgamma, dbeta);
     return ym_check_launch("bn_train_bwd_apply");
 }
 

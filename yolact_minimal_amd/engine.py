@@ -203,6 +203,8 @@ class _Conv:
         hit = tuned_table().get(self.tuned_key()) if self.mma else None
         if hit is None:
             hit = _entry(self.sig)          # (no entry for this pipe: the f32 choice, incl. its wave kernel for tiny layers)
+            if self.mma and hit and len(hit) > 4 and 52 <= hit[4] <= 54:
+                hit = [0, 0, 0, 0, 0, 0, 0]  # (the f32 choice is the weight-stationary kernel, whose tiles the split-bf16 kernel does not have)
         d.mma = self.mma
         if hit and os.environ.get('YM_NO_TUNED', '0') != '1':     # each matrix pipe has its own measured tile / split-K / tail choice
             self.tile, self.ksplit, self.kwaves = (hit[0], hit[1]), hit[2], (hit[3] if len(hit) > 3 else 0)

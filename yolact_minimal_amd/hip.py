@@ -54,7 +54,7 @@ class ConvDesc(ctypes.Structure):
                 ('level_w', ctypes.c_int32 * 5), ('tail_tiles', ctypes.c_int32), ('tail_ksplit', ctypes.c_int32), ('mma', ctypes.c_int32),
                 ('bnb_relu', ctypes.c_int32), ('bnb_y', ctypes.c_void_p), ('bnb_out', ctypes.c_void_p),
                 ('bnb_mean', ctypes.c_void_p), ('bnb_invstd', ctypes.c_void_p), ('bnb_gamma', ctypes.c_void_p),
-                ('bnb_beta', ctypes.c_void_p), ('grid_wgs', ctypes.c_int32), ('bn_replicas', ctypes.c_int32)]
+                ('bnb_beta', ctypes.c_void_p), ('grid_wgs', ctypes.c_int32)]
 
 
 class WgradDesc(ctypes.Structure):
@@ -196,11 +196,11 @@ def lib():
         L.ym_class_box_loss.argtypes = [vp, vp, vp, vp, i32, i32, i32, f32, f32, i32, vp, vp, vp, vp, vp, vp, sz, vp]
         L.ym_semantic_loss.argtypes = [vp, i32, i32, i32, vp, vp, i32, i32, f32, vp, vp, vp]
         L.ym_conv2d_fuses_bn_stats.argtypes = [ctypes.POINTER(ConvDesc)]
-        L.ym_bn_train_fwd_stats.argtypes = [vp, i64, i32, vp, vp, f32, f32, vp, vp, vp, i32, vp, vp, vp, vp, i32, vp]
+        L.ym_bn_train_fwd_stats.argtypes = [vp, i64, i32, vp, vp, f32, f32, vp, vp, vp, i32, vp, vp, vp, vp, vp]
         L.ym_bn_train_bwd_workspace_bytes.argtypes = [i64, i32]
         L.ym_bn_train_bwd_workspace_bytes.restype = sz
         L.ym_bn_train_bwd.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, sz, vp]
-        L.ym_bn_train_bwd_apply.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp]
+        L.ym_bn_train_bwd_apply.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]
         L.ym_act_bias_bwd.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp, sz, vp]
         L.ym_maxpool3x3s2_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
         L.ym_maxpool3x3s2_fwd_idx.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]

@@ -220,13 +220,6 @@ class _StatsPool:
 
 
 _stats_pool = _StatsPool()
-# The fused statistics are accumulated with one fp64 atomic per channel per output-tile row: a layer1 conv at batch 8 has 2312 tile
-# rows, i.e. 2312 atomics queued on every channel's address (the launch took 2.5x as long as the same conv without statistics).
-# R replicas of the [2][C] sums (tile row t adds into replica t % R, ym_conv_desc.bn_replicas) cut the queue by R; the BatchNorm
-# kernels that consume the sums add the replicas up.  YM_BN_REPLICAS=1: the single copy of rounds 1-4.
-_BN_REPLICAS = max(1, int(os.environ.get('YM_BN_REPLICAS', '16')))
-
-
 # ---- packed weight images ---------------------------------------------------------------------------------------------------
 # Every conv needs its OIHW weight as a forward image ([Cout][k_pad]) and, in backward, as a dgrad image ([Cin][KH][KW][Cout]).
 # After an optimizer step all of them are stale at once: when the trainer's flat optimizer owns the parameters (FlatSGD sets
@@ -414,7 +407,6 @@ def _conv_forward(x, wp, k_pad, cout_pad, kh, kw, stride, pad, shift, act, resid
             d.seg[i].out = sg[2]
     if fused:
         d.bn_sum, d.bn_sumsq = bn_stats.data_ptr(), bn_stats.data_ptr() + cout_pad * 8
-        d.bn_replicas = bn_stats.numel() // (2 * cout_pad)
     ws = scratch(x.device, ws_bytes)
     _count(key)
     hip.conv2d_fwd(d, ws)
@@ -456,9 +448,8 @@ def _conv_dgrad(dz, weight, cout_pad, x_shape, stride, pad, add=None, out=None, 
         d.residual = add.data_ptr()
     if fuses:
         assert bn_bwd.c == cin and bn_bwd.m == b * h * w
-        stats = _stats_pool.take(2 * cin * _BN_REPLICAS, dz.device)                 # zeroed
+        stats = _stats_pool.take(2 * cin, dz.device)                 # zeroed
         d.bn_sum, d.bn_sumsq = stats.data_ptr(), stats.data_ptr() + cin * 8
-        d.bn_replicas = _BN_REPLICAS
         d.bnb_y, d.bnb_out, d.bnb_mean, d.bnb_invstd = bn_bwd.y, bn_bwd.out, bn_bwd.mean, bn_bwd.invstd
         d.bnb_gamma, d.bnb_beta, d.bnb_relu = bn_bwd.gamma, bn_bwd.beta, bn_bwd.relu
     ws = scratch(dz.device, ws_bytes)
@@ -1004,7 +995,7 @@ class ConvBn(torch.autograd.Function):
         ctx.producer, ctx.own = producer, own
         cout, cin, kh, kw = weight.shape
         wp, k_pad = _pack_fwd(weight, x.shape[-1], cout)
-        stats = _stats_pool.take(2 * cout * _BN_REPLICAS, x.device)           # zeroed (the fused epilogue accumulates into it)
+        stats = _stats_pool.take(2 * cout, x.device)           # zeroed (the fused epilogue accumulates into it)
         y, fused = _conv_forward(x, wp, k_pad, cout, kh, kw, stride, pad, None, ACT_NONE, bn_stats=stats)
         m = y.numel() // cout
         out = torch.empty_like(y)
@@ -1015,7 +1006,7 @@ class ConvBn(torch.autograd.Function):
             hip.check(hip.lib().ym_bn_train_fwd_stats(hip.ptr(y), m, cout, hip.ptr(gamma.detach()), hip.ptr(beta.detach()), eps,
                                                       momentum, hip.ptr(running_mean), hip.ptr(running_var), res_ptr, int(relu),
                                                       hip.ptr(out), hip.ptr(mean), hip.ptr(invstd),
-                                                      ctypes.c_void_p(stats.data_ptr()), _BN_REPLICAS, hip.stream_ptr()), 'ym_bn_train_fwd_stats')
+                                                      ctypes.c_void_p(stats.data_ptr()), hip.stream_ptr()), 'ym_bn_train_fwd_stats')
         else:
             hip.check(hip.lib().ym_bn_train_fwd(hip.ptr(y), m, cout, hip.ptr(gamma.detach()), hip.ptr(beta.detach()), eps, momentum,
                                                 hip.ptr(running_mean), hip.ptr(running_var), res_ptr, int(relu),
@@ -1051,8 +1042,7 @@ class ConvBn(torch.autograd.Function):
             hip.check(hip.lib().ym_bn_train_bwd_apply(hip.ptr(dout), out_ptr, hip.ptr(y), m, cout, hip.ptr(gamma.detach()), beta_ptr,
                                                       hip.ptr(mean), hip.ptr(invstd), int(relu), hip.ptr(dy),
                                                       hip.ptr(dres) if has_res else None, hip.ptr(dgamma), hip.ptr(dbeta),
-                                                      ctypes.c_void_p(own.stats.data_ptr()), own.stats.numel() // (2 * cout),
-                                                      hip.stream_ptr()), 'ym_bn_train_bwd_apply')
+                                                      ctypes.c_void_p(own.stats.data_ptr()), hip.stream_ptr()), 'ym_bn_train_bwd_apply')
             bn_bwd_fused_launches[0] += 1
         else:
             ws = scratch(y.device, hip.lib().ym_bn_train_bwd_workspace_bytes(m, cout))
