@@ -541,7 +541,7 @@ def wgrad_stream_if_used(device):
 # the first stream, which keeps them ordered.
 _N_SIDE = int(os.environ.get('YM_WGRAD_STREAMS', '1'))
 # YM_WGRAD_STREAM_PRIORITY=-1 creates the side stream(s) on a high-priority hardware queue (0 = like any other stream):
-# tools/train_prio.py measures both orders (the data-gradient chain ahead of the weight gradients and the reverse).
+# both orders were measured in round 4 (the data-gradient chain ahead of the weight gradients and the reverse): no change.
 _SIDE_PRIO = int(os.environ.get('YM_WGRAD_STREAM_PRIORITY', '0'))
 _extra_streams = {}
 _rr = [0]
