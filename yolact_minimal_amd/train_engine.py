@@ -921,6 +921,23 @@ class PredictionHead(torch.autograd.Function):
         return (dw_up, db_up, dw[0], db[0], dw[1], db[1], dw[2], db[2], None, None, None, None, None, *dlevels)
 
 
+# Every link of the current forward (ResGradLink / GradJoin): `check_links_drained()` after backward proves that no parked gradient
+# was left behind -- i.e. that every taker really ran AFTER its givers (the order autograd's engine is relied on for).
+_live_links = []
+
+
+def check_links_drained():
+    """Call after `backward()` (Trainer.step does): a gradient still parked in a link was never added by its taker -- the taker ran
+    before a giver, or never ran -- and would be silently MISSING from the step.  Raises instead."""
+    left = [type(l).__name__ for l in _live_links if l.grad is not None]
+    for l in _live_links:
+        l.grad = None
+    _live_links.clear()
+    if left:
+        raise RuntimeError(f'{len(left)} gradient(s) parked in {sorted(set(left))} were never consumed: autograd did not run the '
+                           f'consumers of a shared tensor in decreasing creation order (set YM_GRAD_JOIN=0 YM_FUSE_RES_GRAD=0)')
+
+
 class ResGradLink:
     """A Bottleneck's input feeds conv1 AND the residual add of conv3 (modules/resnet.py:21,35-37); autograd would sum the two
     gradients with an extra elementwise pass.  conv3's backward parks its residual gradient here (`give`) and conv1's backward,
@@ -929,6 +946,7 @@ class ResGradLink:
 
     def __init__(self):
         self.grad = None
+        _live_links.append(self)
 
 
 class GradJoin:
@@ -945,6 +963,7 @@ class GradJoin:
 
     def __init__(self):
         self.grad = None
+        _live_links.append(self)
 
 
 _GRAD_JOIN = os.environ.get('YM_GRAD_JOIN', '1') != '0'
@@ -1152,6 +1171,7 @@ def train_features(net, img):
     x = torch.empty(b, h, w, 4, device=img.device, dtype=torch.float32)
     hip.nchw_to_nhwc4(img.contiguous().float(), x)
     _stats_pool.begin(img.device)
+    _live_links.clear()                                          # (links of a forward whose backward never ran)
     bb = net.backbone
     if hasattr(bb, 'patch_embed'):                                # Swin-T (modules/swin_transformer.py)
         from .swin_train import swin_backbone_train

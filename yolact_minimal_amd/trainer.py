@@ -411,12 +411,13 @@ class Trainer:
             dist.all_reduce(all_loss)                 # 16-byte logging collective, train.py:121-122
         total = losses[0] + losses[1] + losses[2] + losses[3]
         from .loss import unit_loss_grads
-        from .train_engine import wgrad_on_side_stream
+        from .train_engine import wgrad_on_side_stream, check_links_drained
         # weight gradients run on a side stream next to the data-gradient chain; the main stream waits for them at the block's end
         if ev is not None:
             ev[2].record()
         with unit_loss_grads(), wgrad_on_side_stream(self.device):   # d(total)/d(loss_i) = 1: stored loss gradients pass through unscaled
             total.backward()
+        check_links_drained()                         # every gradient parked for a later consumer was consumed (host-side check)
         if ev is not None:
             ev[3].record()                            # backward done on the device: the weight-gradient stream was joined at the block's end
         if self.reducer is not None:
