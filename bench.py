@@ -100,7 +100,7 @@ class Workload:
         if self.inflight > 1:
             self.pipe = RequestPipeline(net, cfg, img_size, img_size, device, depth=self.inflight, out_hw=(480, 640), with_post=with_post,
                                         batch=batch, return_outputs=False, timed=timed)
-            self.pipe.warm_up(self.img)
+            self.pipe.warm_up(self.img, self.head if batch == 1 else self.head_b)   # (graph capture + 4 requests per slot: a warm allocator)
             self.engine = self.pipe.engines[0]
         else:
             self.engine = net._engine(self.img)

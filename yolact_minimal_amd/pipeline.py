@@ -75,13 +75,24 @@ class RequestPipeline:
         self.submitted = 0
         self.detections = 0
 
-    def warm_up(self, img):
-        """Capture every slot's hipGraph (first run of an engine) outside any timed region."""
+    def warm_up(self, img, head_outputs=None, rounds=4):
+        """Capture every slot's hipGraph (first run of an engine) and push `rounds` requests through every slot, outside any timed
+        region: the first requests of a pipeline allocate their result tensors (123 MB of masks per request at 480x640) with
+        hipMalloc until the caching allocator holds enough blocks for `depth` requests in flight plus the results the caller
+        still owns, and the part ramps its clocks; a server is warm, so the pipeline warms itself.  Counters start at zero after."""
         torch.cuda.synchronize(self.device)
         for e, st in zip(self.engines, self.streams):
             with torch.cuda.stream(st):
                 e.run(img)
         torch.cuda.synchronize(self.device)
+        timed, self.timed = self.timed, False
+        for _ in range(rounds * self.depth):
+            self.submit(img, head_outputs)
+        self.drain()
+        torch.cuda.synchronize(self.device)
+        self.timed = timed
+        self.submitted = self.detections = 0
+        self.latencies_ms = []
 
     def finish(self, slot):
         """Result of the request that last used `slot`: (ids, scores, boxes_px, masks) like `after_nms` (None x 4 without
