@@ -21,9 +21,10 @@ for it in range(5):
     torch.cuda.synchronize()
     ws = next(iter(OU._ws_cache.values()))
     st = ws[:256].view(torch.int32)[8:8 + 32].view(torch.int64).cpu().tolist()
-    m, c = st[0:5], st[8:12]
+    m, c, t = st[0:5], st[8:12], st[12:15]
     if it >= 2:
-        print('k_class_topk_iou (class 0): select+sort %.2f us, IoU columns %.2f us, compaction %.2f us' %
-              ((c[1] - c[0]) / 100, (c[2] - c[1]) / 100, (c[3] - c[2]) / 100))
+        print('k_class_topk_iou (class 0): select+sort %.2f us (keys in registers %.2f, radix passes %.2f, collect %.2f, sort %.2f), IoU '
+              'columns %.2f us, compaction %.2f us' % ((c[1] - c[0]) / 100, (t[0] - c[0]) / 100, (t[1] - t[0]) / 100, (t[2] - t[1]) / 100,
+                                                       (c[1] - t[2]) / 100, (c[2] - c[1]) / 100, (c[3] - c[2]) / 100))
         print('k_final_merge: counts %.2f us, key load %.2f us, merge %.2f us, gather %.2f us;  class start -> merge start %.2f us' %
               ((m[1] - m[0]) / 100, (m[2] - m[1]) / 100, (m[3] - m[2]) / 100, (m[4] - m[3]) / 100, (m[0] - c[0]) / 100))

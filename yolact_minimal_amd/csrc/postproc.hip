@@ -33,6 +33,36 @@ __device__ __forceinline__ float key2f(uint32_t k) {
     return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu));
 }
 
+// Maximum of an unsigned value over the 64 lanes of a wave, returned to every lane: inclusive max-scan with DPP (row_shr 1 / 2 / 4 / 8
+// inside each row of 16 lanes, row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3; lanes without a source keep the
+// identity 0), lane 63 then holds the total.  ~14 VALU instructions; a ds_bpermute butterfly is 12 LDS-crossbar round trips.
+__device__ __forceinline__ uint32_t wave_umax(uint32_t x) {
+    int v = (int)x;
+#define YM_DPP_MAX(ctrl, rmask) v = (int)max((uint32_t)v, (uint32_t)__builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, false))
+    YM_DPP_MAX(0x111, 0xf);      // row_shr:1
+    YM_DPP_MAX(0x112, 0xf);      // row_shr:2
+    YM_DPP_MAX(0x114, 0xf);      // row_shr:4
+    YM_DPP_MAX(0x118, 0xf);      // row_shr:8
+    YM_DPP_MAX(0x142, 0xa);      // row_bcast:15 -> rows 1, 3
+    YM_DPP_MAX(0x143, 0xc);      // row_bcast:31 -> rows 2, 3
+#undef YM_DPP_MAX
+    return (uint32_t)__builtin_amdgcn_readlane(v, 63);
+}
+
+// Inclusive prefix sum over the 64 lanes of a wave by the same DPP steps (Hillis-Steele inside the rows of 16, then the row totals).
+__device__ __forceinline__ int wave_incl_scan_add(int x) {
+    int v = x;
+#define YM_DPP_ADD(ctrl, rmask) v += __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, false)
+    YM_DPP_ADD(0x111, 0xf);      // row_shr:1
+    YM_DPP_ADD(0x112, 0xf);      // row_shr:2
+    YM_DPP_ADD(0x114, 0xf);      // row_shr:4
+    YM_DPP_ADD(0x118, 0xf);      // row_shr:8
+    YM_DPP_ADD(0x142, 0xa);      // row_bcast:15 -> rows 1, 3
+    YM_DPP_ADD(0x143, 0xc);      // row_bcast:31 -> rows 2, 3
+#undef YM_DPP_ADD
+    return v;
+}
+
 // utils/box_utils.py:8-37, one pair: inter / (area_a + area_b - inter); 0/0 -> NaN like torch.
 __device__ __forceinline__ float iou_pair(const f32x4 a, const f32x4 b) {
     const float hx = fminf(a[2], b[2]), hy = fminf(a[3], b[3]);
@@ -51,11 +81,12 @@ __device__ __forceinline__ float iou_pair(const f32x4 a, const f32x4 b) {
 // ---------------------------------------------------------------------------------------------------
 template <int CAP>
 struct TopkShared {
-    uint32_t hist[256];
+    uint32_t hist[4][256];      // one histogram per radix pass, all zeroed up front: a pass costs two barriers instead of four
     uint32_t keys[CAP];
     int idx[CAP];
     int wave_tot[NT / 64];
-    int sel_digit, remaining, eq_total, cnt_gt, cnt_eq, running;
+    int sel_digit[4], sel_remaining[4], sel_eq_total[4];   // per pass: nothing of pass p is overwritten while a wave may still read it
+    int cnt_gt, cnt_eq, running;
 };
 
 // (Measured: LDS atomics on a hot bin are NOT the bottleneck here — a ballot-aggregated histogram was 1.5x slower.
@@ -63,9 +94,10 @@ struct TopkShared {
 constexpr int KCACHE = 24;   // keys cached per thread: lists up to KCACHE*NT = 24576 entries are read from HBM once
 
 template <int CAP, typename KeyAt>
-__device__ int block_topk_sorted(KeyAt key_at, int L, int R, TopkShared<CAP>& sh) {
+__device__ int block_topk_sorted(KeyAt key_at, int L, int R, TopkShared<CAP>& sh, int* dbg = nullptr) {
     const int tid = threadIdx.x, nt = blockDim.x;
-    for (int i = tid; i < CAP; i += nt) { sh.keys[i] = 0u; sh.idx[i] = INT_MAX; }
+    for (int i = tid; i < CAP; i += nt) { sh.keys[i] = 0u; sh.idx[i] = INT_MAX - i; }      // (empty slots: distinct indices, so that the sort below has no ties)
+    for (int i = tid; i < 4 * 256; i += nt) (&sh.hist[0][0])[i] = 0u;
     if (tid == 0) { sh.cnt_gt = 0; sh.cnt_eq = 0; sh.running = 0; }
     __syncthreads();
     int cnt;
@@ -86,20 +118,25 @@ __device__ int block_topk_sorted(KeyAt key_at, int L, int R, TopkShared<CAP>& sh
         }
         uint32_t prefix = 0u, mask = 0u;
         int remaining = R;
-        for (int shift = 24; shift >= 0; shift -= 8) {
-            for (int i = tid; i < 256; i += nt) sh.hist[i] = 0u;
-            __syncthreads();
+        int eq_total_last = 0;
+        // (walking only the key bits that differ inside the list -- scores of one class share their top 6 -- so that no pass piles every
+        //  key onto 1-3 bins was built and measured: 35.5 -> 35.3 us per launch.  The select's time is not in the atomics: of its
+        //  27 us, 6 are the key loads, 9 the four passes, 4 the collection, 8 the rank-by-counting sort: tools/nms_stamps.py.)
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            const uint32_t dmask = 255u;
+            uint32_t* hist = sh.hist[pass];
             if (cached) {
 #pragma unroll
                 for (int j = 0; j < KCACHE; ++j) {
                     const int i = tid + j * nt;
-                    if (i < L && ck[j] != 0u && (ck[j] & mask) == prefix) atomicAdd(&sh.hist[(ck[j] >> shift) & 255u], 1u);
+                    if (i < L && ck[j] != 0u && (ck[j] & mask) == prefix) atomicAdd(&hist[(ck[j] >> shift) & dmask], 1u);
                 }
             } else {
                 for (int base = 0; base < L; base += nt) {
                     const int i = base + tid;
                     const uint32_t k = i < L ? key_at(i) : 0u;
-                    if (i < L && k != 0u && (k & mask) == prefix) atomicAdd(&sh.hist[(k >> shift) & 255u], 1u);
+                    if (i < L && k != 0u && (k & mask) == prefix) atomicAdd(&hist[(k >> shift) & dmask], 1u);
                 }
             }
             __syncthreads();
@@ -109,13 +146,8 @@ __device__ int block_topk_sorted(KeyAt key_at, int L, int R, TopkShared<CAP>& sh
                 // Walk the 256 bins from the top with ONE WAVE: lane l owns digits 255-4l .. 252-4l.
                 int c[4], lane_total = 0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { c[j] = (int)sh.hist[255 - (4 * tid + j)]; lane_total += c[j]; }
-                int incl = lane_total;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int v = __shfl_up(incl, o);
-                    if (tid >= o) incl += v;
-                }
+                for (int j = 0; j < 4; ++j) { c[j] = (int)hist[255 - (4 * tid + j)]; lane_total += c[j]; }
+                const int incl = wave_incl_scan_add(lane_total);      // (tid < 64: all lanes of wave 0 are active)
                 int run = incl - lane_total, found_r = -1, acc_before = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -123,30 +155,31 @@ __device__ int block_topk_sorted(KeyAt key_at, int L, int R, TopkShared<CAP>& sh
                     run += c[j];
                 }
                 const unsigned long long hit = __ballot(found_r >= 0);
-                const int total = __shfl(incl, 63);
+                const int total = __builtin_amdgcn_readlane(incl, 63);
                 if (hit) {
                     const int leader = __ffsll((long long)hit) - 1;
                     if (tid == leader) {
                         int d = 255 - found_r, acc = acc_before;
                         if (d == 0) { d = 0; }      // reached the last bin normally
-                        sh.sel_digit = d;
-                        sh.remaining = remaining - acc;
-                        sh.eq_total = (int)sh.hist[d];
+                        sh.sel_digit[pass] = d;
+                        sh.sel_remaining[pass] = remaining - acc;
+                        sh.sel_eq_total[pass] = (int)hist[d];
                     }
                 } else if (tid == 0) {
-                    sh.sel_digit = 0;                                  // fewer real keys than requested
-                    sh.remaining = remaining - (total - (int)sh.hist[0]);
-                    sh.eq_total = (int)sh.hist[0];
+                    sh.sel_digit[pass] = 0;                            // fewer real keys than requested
+                    sh.sel_remaining[pass] = remaining - (total - (int)hist[0]);
+                    sh.sel_eq_total[pass] = (int)hist[0];
                 }
             }
             __syncthreads();
-            prefix |= (uint32_t)sh.sel_digit << shift;
-            mask |= 0xFFu << shift;
-            remaining = sh.remaining;
-            __syncthreads();
+            prefix |= (uint32_t)sh.sel_digit[pass] << shift;
+            mask |= dmask << shift;
+            remaining = sh.sel_remaining[pass];
+            eq_total_last = sh.sel_eq_total[pass];
         }
+        if (dbg) YM_NMS_STAMP(dbg, 13);
         const uint32_t T = prefix;
-        const int r_eq = remaining, n_gt = R - r_eq, eq_total = sh.eq_total;
+        const int r_eq = remaining, n_gt = R - r_eq, eq_total = eq_total_last;
         auto collect = [&](uint32_t k, int i) {
             if (k > T) {
                 const int p = atomicAdd(&sh.cnt_gt, 1);
@@ -188,6 +221,7 @@ __device__ int block_topk_sorted(KeyAt key_at, int L, int R, TopkShared<CAP>& sh
         cnt = R;
     }
     __syncthreads();
+    if (dbg) YM_NMS_STAMP(dbg, 14);
     // Sort the CAP slots (key descending, index ascending; empty slots = key 0 last) by counting: NT / CAP threads share one
     // element, each ranks it against a slice of the list (broadcast LDS reads), the slice counts meet in LDS, one scatter.
     // Two barriers instead of the 28-36 of a bitonic network (a barrier of a 1024-thread workgroup costs ~1 us).
@@ -196,20 +230,25 @@ __device__ int block_topk_sorted(KeyAt key_at, int L, int R, TopkShared<CAP>& sh
     const int e = tid % CAP, sl = tid / CAP;
     const uint32_t ka = sh.keys[e];
     const int ia = sh.idx[e];
+    // (key, ~index) packed into 64 bits: "b sorts before a" is ONE unsigned compare (indices are distinct, real and empty slots
+    // alike), i.e. ds_read_b64 + v_cmp + add-with-carry per pair instead of two reads and a four-term predicate: the 65 k pair
+    // tests of this sort are VALU-bound (16 waves on 4 SIMDs), 8.2 us of the class kernel's 35.  hist[2..3] are free by now.
+    static_assert(CAP <= 256, "the packed sort keys live in two of the histograms");
+    unsigned long long* pk = reinterpret_cast<unsigned long long*>(&sh.hist[2][0]);
+    const unsigned long long pa = ((unsigned long long)ka << 32) | (unsigned)~ia;
+    if (sl == 0) pk[e] = pa;
+    __syncthreads();
     int before = 0;
     if (tid < NT) {
-        for (int x = sl * SPAN; x < (sl + 1) * SPAN; ++x) {
-            const uint32_t kb = sh.keys[x];
-            const int ib = sh.idx[x];
-            before += (kb > ka || (kb == ka && (ib < ia || (ib == ia && x < e)))) ? 1 : 0;
-        }
+#pragma unroll 8
+        for (int x = sl * SPAN; x < (sl + 1) * SPAN; ++x) before += pk[x] > pa ? 1 : 0;
     }
-    if (tid < CAP) sh.hist[tid] = 0u;                           // hist (256 >= CAP entries) is free now: rank accumulators
+    if (tid < CAP) sh.hist[0][tid] = 0u;                        // hist[0] (256 >= CAP entries) is free now: rank accumulators
     __syncthreads();
-    atomicAdd(&sh.hist[e], (uint32_t)before);
+    atomicAdd(&sh.hist[0][e], (uint32_t)before);
     __syncthreads();
     if (sl == 0) {
-        const int r = (int)sh.hist[e];
+        const int r = (int)sh.hist[0][e];
         sh.keys[r] = ka;
         sh.idx[r] = ia;
     }
@@ -426,7 +465,7 @@ __global__ __launch_bounds__(NT) void k_class_topk_iou(const NmsWs w0, int N, in
     if (K == 0) return;
     const int c = blockIdx.x, tid = threadIdx.x;
     const float* srow = w.scores_t + (size_t)c * N;
-    const int cnt = block_topk_sorted<TOPK_CAP>([&](int i) { return f2key(srow[i]); }, K, top_k, sh);
+    const int cnt = block_topk_sorted<TOPK_CAP>([&](int i) { return f2key(srow[i]); }, K, top_k, sh, w.counters);
     YM_NMS_STAMP(w.counters, 9);
     __shared__ uint8_t skeep[TOPK_CAP];
     __shared__ int wtot[TOPK_CAP / 64];
@@ -476,22 +515,6 @@ __global__ __launch_bounds__(NT) void k_class_topk_iou(const NmsWs w0, int N, in
 // ---------------------------------------------------------------------------------------------------
 // stage C: global top max_det over the kept (class, rank) pairs + gather  (utils/output_utils.py:31-43)
 // ---------------------------------------------------------------------------------------------------
-// Maximum of an unsigned value over the 64 lanes of a wave, returned to every lane: inclusive max-scan with DPP (row_shr 1 / 2 / 4 / 8
-// inside each row of 16 lanes, row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3; lanes without a source keep the
-// identity 0), lane 63 then holds the total.  ~14 VALU instructions; a ds_bpermute butterfly is 12 LDS-crossbar round trips.
-__device__ __forceinline__ uint32_t wave_umax(uint32_t x) {
-    int v = (int)x;
-#define YM_DPP_MAX(ctrl, rmask) v = (int)max((uint32_t)v, (uint32_t)__builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, false))
-    YM_DPP_MAX(0x111, 0xf);      // row_shr:1
-    YM_DPP_MAX(0x112, 0xf);      // row_shr:2
-    YM_DPP_MAX(0x114, 0xf);      // row_shr:4
-    YM_DPP_MAX(0x118, 0xf);      // row_shr:8
-    YM_DPP_MAX(0x142, 0xa);      // row_bcast:15 -> rows 1, 3
-    YM_DPP_MAX(0x143, 0xc);      // row_bcast:31 -> rows 2, 3
-#undef YM_DPP_MAX
-    return (uint32_t)__builtin_amdgcn_readlane(v, 63);
-}
-
 // Every class's survivors arrive sorted (k_class_topk_iou), and an entry with >= max_det survivors of its OWN class ahead of it
 // cannot be among the global top max_det: the answer is the max_det-way merge of the first min(count, max_det) entries of ncls
 // sorted lists.  One wave does it: lane l owns the heads of lists l, l + 64, ...; each round a shuffle butterfly finds the best
