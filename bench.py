@@ -756,6 +756,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
+        torch.cuda.synchronize()          # nothing in flight when the process group (and its watchdog thread) is torn down
         dist.destroy_process_group()
 
 
