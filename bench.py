@@ -190,21 +190,30 @@ def post_bench(net, cfg, device, img_size, iters=30):
     out = {}
     for b in (1, 8):
         hb = [t.expand(b, *t.shape[1:]).contiguous() for t in head]
-        t_nms = t_after = 0.0
-        for it in range(iters + 3):
-            e[0].record()
-            dets = nms_batch(*hb, anchors, cfg)
-            e[1].record()
-            r = after_nms_batch(dets, 480, 640, cfg, sync=False)
-            e[2].record()
-            torch.cuda.synchronize()
-            if it >= 3:
-                t_nms += e[0].elapsed_time(e[1])
-                t_after += e[1].elapsed_time(e[2])
+        res = {}
+        # 'eager': the stream is idle when the first event is recorded, so nms_us also holds the host's way from the event to the
+        # first launch (Python + ctypes); 'queued': a ~1 ms spin kernel in front, the launches wait in the stream behind it -- what the
+        # DEVICE spends on nms (the request graphs replay it like that; tools/nms_span.py reads the same span from a kernel trace)
+        for mode in ('eager', 'queued'):
+            t_nms = t_after = 0.0
+            for it in range(iters + 3):
+                if mode == 'queued':
+                    torch.cuda._sleep(2_000_000)
+                e[0].record()
+                dets = nms_batch(*hb, anchors, cfg)
+                e[1].record()
+                r = after_nms_batch(dets, 480, 640, cfg, sync=False)
+                e[2].record()
+                torch.cuda.synchronize()
+                if it >= 3:
+                    t_nms += e[0].elapsed_time(e[1])
+                    t_after += e[1].elapsed_time(e[2])
+            res[mode] = (t_nms / iters * 1e-3, t_after / iters * 1e-3)
         n_det = int(r[4].sum())
         nbytes = n_det * 480 * 640 * 4
-        t_nms, t_after = t_nms / iters * 1e-3, t_after / iters * 1e-3
+        (t_nms, t_after), (q_nms, q_after) = res['eager'], res['queued']
         out[f'bs{b}'] = dict(detections=n_det, nms_us=round(t_nms * 1e6, 1), after_nms_us=round(t_after * 1e6, 1),
+                             nms_device_us=round(q_nms * 1e6, 1), after_nms_device_us=round(q_after * 1e6, 1),
                              after_nms_gbs=round(nbytes / t_after / 1e9, 1), after_nms_frac_hbm_peak=round(nbytes / t_after / 1e9 / HBM_PEAK_GBS, 4))
     return out
 

@@ -488,7 +488,7 @@ __global__ __launch_bounds__(NT) void k_class_topk_iou(const NmsWs w0, int N, in
     }
     __syncthreads();
     YM_NMS_STAMP(w.counters, 10);
-    // the survivors, compacted in rank order (still sorted by score, ties by index): what the global top-k merges
+    // the survivors, compacted in rank order (still sorted by score, ties by index): what stage C merges
     bool f = false;
     int pre = 0;
     if (tid < TOPK_CAP) {
@@ -515,130 +515,206 @@ __global__ __launch_bounds__(NT) void k_class_topk_iou(const NmsWs w0, int N, in
 // ---------------------------------------------------------------------------------------------------
 // stage C: global top max_det over the kept (class, rank) pairs + gather  (utils/output_utils.py:31-43)
 // ---------------------------------------------------------------------------------------------------
-// Every class's survivors arrive sorted (k_class_topk_iou), and an entry with >= max_det survivors of its OWN class ahead of it
-// cannot be among the global top max_det: the answer is the max_det-way merge of the first min(count, max_det) entries of ncls
-// sorted lists.  One wave does it: lane l owns the heads of lists l, l + 64, ...; each round a shuffle butterfly finds the best
-// head (key descending, ties by the lower flat slot = class-major, rank-minor: the order of the radix select it replaces), the
-// owning lane advances.  ~100 rounds of ~60 instructions against a 4-pass radix select over 20 480 slots with 1024-thread
-// barriers: 53 -> ~12 us.
+// Every class's survivors arrive sorted (stage B), and an entry with >= max_det survivors of its OWN class ahead of it cannot be
+// among the global top max_det: the answer is the first max_det entries of the merge of the leading min(count, max_det) entries
+// of ncls sorted lists (key descending, ties by the lower flat slot = class-major, rank-minor).
+//
+// Rounds 4-5 merged them with ONE wave, a head per lane, max_det dependent rounds (24 us for 100 detections: a lone wave's
+// instruction count is its latency).  This form has no loop over the detections: a RADIX SELECT ON SORTED LISTS.  The max_det-th
+// largest key T is found 4 bits per round; inside a class the keys that share the prefix chosen so far are a contiguous range
+// [lo, hi) of its list, so "how many keys of class c fall into bin b" needs no histogram over the keys: lane (c, b) binary-searches
+// the range for the first key below prefix | b << shift (<= 8 LDS reads in the first round, 1-2 once the range is a few entries),
+// the 16 cumulative counts meet in LDS (one ds_add per lane), every wave reads them back with ONE lane-per-bin load + a ballot
+// and narrows its classes' ranges with two ds_bpermutes.  After 8 rounds class c contributes lo_c keys above T plus its share of
+// the ties (classes in ascending order); the <= max_det selected (key, ~slot) pairs are packed and ranked by counting.
+struct FinalOut {
+    const float* coef;
+    int coef_dim;
+    int32_t* out_count;
+    int64_t* out_ids;
+    float* out_scores;
+    float* out_boxes;
+    float* out_coefs;
+};
+__device__ __forceinline__ FinalOut image_out(FinalOut o, size_t b, int max_det, int N) {   // image b's outputs: [B][max_det] rows
+    o.coef += b * (size_t)N * o.coef_dim;
+    o.out_count += b;
+    o.out_ids += b * max_det;
+    o.out_scores += b * max_det;
+    o.out_boxes += b * (size_t)max_det * 4;
+    o.out_coefs += b * (size_t)max_det * o.coef_dim;
+    return o;
+}
+
+struct FinalShared {
+    unsigned long long cand[DET_CAP];   // (key << 32 | ~flat slot) of the selected entries, class-major
+    uint32_t hist[8][16];               // per round: cumulative count of range keys with digit >= b, summed over the classes
+    int sel[DET_CAP];                   // flat slot of output row j
+    int s_k[DET_CAP], s_a[DET_CAP];
+    int lcnt[256];                      // (ncls <= 255) leading survivors of a class that can matter: min(count, max_det)
+    int s_gt[256], s_eq[256];           // keys above the threshold / equal to it; then s_gt = entries the class contributes
+    int s_base[256];                    // first packed slot of a class
+    int wtot[2][4];
+};
+
+// exclusive prefix sum of v over threads 0..255 (values of the other threads are ignored); every thread of the workgroup calls it
+__device__ __forceinline__ int block256_excl_scan(int v, int* wtot) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int incl = wave_incl_scan_add(v);
+    if (wv < 4 && lane == 63) wtot[wv] = incl;
+    __syncthreads();
+    int off = 0;
+    for (int x = 0; x < 4; ++x) off += x < wv ? wtot[x] : 0;
+    return off + incl - v;
+}
+
+// LPL = classes per lane group (ncls <= 64 * LPL)
 template <int LPL>
-__global__ __launch_bounds__(NT) void k_final_merge(const NmsWs w0, int ncls, int max_det, const float* __restrict__ coef,
-                                                     int coef_dim, int32_t* __restrict__ out_count,
-                                                     int64_t* __restrict__ out_ids, float* __restrict__ out_scores,
-                                                     float* __restrict__ out_boxes, float* __restrict__ out_coefs, size_t ws_stride,
-                                                     int N) {
-    const NmsWs w = image_ws(w0, ws_stride, blockIdx.y);
-    {
-        const size_t b = blockIdx.y;                       // image b's outputs: [B][max_det] rows
-        coef += b * (size_t)N * coef_dim;
-        out_count += b;
-        out_ids += b * max_det;
-        out_scores += b * max_det;
-        out_boxes += b * (size_t)max_det * 4;
-        out_coefs += b * (size_t)max_det * coef_dim;
-    }
+__device__ __forceinline__ void final_stage(const NmsWs& w, int ncls, int max_det, const FinalOut& o, FinalShared& fs) {
     extern __shared__ uint32_t lkeys[];                    // [ncls][DET_CAP]: keys of each class's leading survivors, 0 = none
-    __shared__ int sel[DET_CAP];
-    __shared__ int n_sel;
-    __shared__ int lcnt[256];                              // (ncls <= 255)
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     YM_NMS_STAMP(w.counters, 0);
-    const int K = w.counters[0];
-    if (K == 0) {
-        if (tid == 0) out_count[0] = 0;
-        return;
-    }
-    if (tid < ncls) lcnt[tid] = min(w.top_cnt[tid], max_det);
+    if (tid < 256) fs.lcnt[tid] = tid < ncls ? min(w.top_cnt[tid], max_det) : 0;
+    if (tid < 8 * 16) (&fs.hist[0][0])[tid] = 0u;
     __syncthreads();
     YM_NMS_STAMP(w.counters, 1);
-    // the leading DET_CAP scores of every class row, 16 bytes per load, all loads independent (entries past the class's survivor
-    // count are whatever an earlier launch left there: masked by the count, never interpreted)
+    // the leading DET_CAP scores of every class row, all loads independent (entries past the class's survivor count are whatever an
+    // earlier launch left there: masked by the count, never interpreted)
     for (int q4 = tid; q4 < ncls * (DET_CAP / 4); q4 += NT) {       // (<= 8 rounds of 1024 threads)
         const int c = q4 / (DET_CAP / 4), j = (q4 - c * (DET_CAP / 4)) * 4;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(w.top_score + c * TOPK_CAP + j);
-        const int cnt = lcnt[c];
+        const int cnt = fs.lcnt[c];
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (j < cnt) v = *reinterpret_cast<const f32x4*>(w.top_score + c * TOPK_CAP + j);
         uint32_t* dst = lkeys + c * DET_CAP + j;
 #pragma unroll
         for (int e = 0; e < 4; ++e) dst[e] = j + e < cnt ? f2key(v[e]) : 0u;
     }
     __syncthreads();
     YM_NMS_STAMP(w.counters, 2);
-    if (tid < 64) {
-        // LPL lists per lane (template: 2 for COCO's 80 classes; a lone wave issues one instruction every ~4 cycles, so the round's
-        // instruction count IS its latency -- 100 rounds of ~190 instructions with LPL = 4 took 44 us).
-        // Per list of this lane: position of its head, the head's key and the key behind it (read one round before it can become
-        // the head, so that no LDS latency sits on the round's critical path).
-        int head[LPL];
-        uint32_t hk[LPL], nk[LPL];
+    // ---- radix select on the sorted lists: lane group g = tid / 16 owns classes g, g + 64, ...; lane b of the group owns bin b
+    const int g = tid >> 4, b = tid & 15;
+    int lo[LPL], hi[LPL];
+#pragma unroll
+    for (int q = 0; q < LPL; ++q) {
+        const int c = g + 64 * q;
+        lo[q] = 0;
+        hi[q] = c < ncls ? fs.lcnt[c] : 0;
+    }
+    uint32_t prefix = 0u;
+    int above = 0, need = 0;
+#pragma unroll 1
+    for (int r = 0; r < 8; ++r) {
+        const int shift = 28 - 4 * r;
+        const uint32_t thr = prefix | ((uint32_t)b << shift);
+        // F = entries of [lo, hi) with key >= thr (the range is sorted descending and shares the prefix: keys >= prefix throughout)
+        int l[LPL], h[LPL];
+#pragma unroll
+        for (int q = 0; q < LPL; ++q) { l[q] = lo[q]; h[q] = hi[q]; }
+        bool more;
+        do {
+            more = false;
+#pragma unroll
+            for (int q = 0; q < LPL; ++q) {
+                if (l[q] < h[q]) {
+                    const int m = (l[q] + h[q]) >> 1;
+                    const uint32_t k = lkeys[(g + 64 * q) * DET_CAP + m];
+                    if (k >= thr) l[q] = m + 1; else h[q] = m;
+                    more |= l[q] < h[q];
+                }
+            }
+        } while (__any(more));
+        int F[LPL], part = 0;
+#pragma unroll
+        for (int q = 0; q < LPL; ++q) { F[q] = l[q] - lo[q]; part += F[q]; }
+        if (part) atomicAdd(&fs.hist[r][b], (uint32_t)part);
+        __syncthreads();
+        // bin of T: the largest b with above + S(b) >= need (S is non-increasing in b, S(0) = every key of the ranges)
+        const int S = (int)fs.hist[r][lane & 15];
+        if (r == 0) need = min(max_det, __builtin_amdgcn_readfirstlane(S));      // S(0) of round 0 = every real key
+        const unsigned long long okm = __ballot(above + S >= need) & 0xFFFFull;    // lanes 0..15: bins 0..15
+        const int bs = need > 0 ? 63 - __builtin_clzll(okm | 1ull) : 0;
+        const int s_next = bs < 15 ? __builtin_amdgcn_readlane(S, bs + 1) : 0;
+        above += s_next;
+        prefix |= (uint32_t)bs << shift;
 #pragma unroll
         for (int q = 0; q < LPL; ++q) {
-            const int c = tid + 64 * q;
-            head[q] = 0;
-            hk[q] = c < ncls ? lkeys[c * DET_CAP] : 0u;
-            nk[q] = c < ncls ? lkeys[c * DET_CAP + 1] : 0u;
+            const int fb = __shfl(F[q], (lane & 48) | bs);
+            const int fb1 = __shfl(F[q], (lane & 48) | ((bs + 1) & 15));
+            hi[q] = lo[q] + fb;
+            lo[q] = lo[q] + (bs < 15 ? fb1 : 0);
         }
-        uint32_t bk = 0u;
-        int bf = INT_MAX;
-        auto lane_best = [&]() __attribute__((always_inline)) {                           // registers only
-            bk = hk[0]; bf = tid * TOPK_CAP + head[0];
+    }
+    // prefix = T, [lo, hi) = the class's keys equal to T, lo = its keys above T, above = all keys above T (< need)
+    if (b == 0) {
 #pragma unroll
-            for (int q = 1; q < LPL; ++q)
-                if (hk[q] > bk) { bk = hk[q]; bf = (tid + 64 * q) * TOPK_CAP + head[q]; }   // (equal keys: the lower class = lower slot stays)
-        };
-        lane_best();
-        int n = 0;
-        for (; n < max_det; ++n) {
-            // best head of the wave: maximum key by a DPP scan, ties by the lower flat slot -- a second scan, taken only when two
-            // lanes really hold the same key
-            const uint32_t mk = wave_umax(bk);
-            if (mk == 0u) break;                           // (uniform) every list is exhausted
-            const unsigned long long tied = __ballot(bk == mk);
-            int mf;
-            if (__popcll(tied) == 1) mf = __builtin_amdgcn_readlane(bf, __ffsll((long long)tied) - 1);
-            else mf = (int)~wave_umax(bk == mk ? ~(uint32_t)bf : 0u);
-            if (tid == 0) sel[n] = mf;
-            const int c = mf / TOPK_CAP;                   // scalar
-            const int q = c >> 6;
-            if ((c & 63) == tid) {                         // the owner advances that list (q is wave-uniform: one block runs)
-                auto advance = [&](auto QC) __attribute__((always_inline)) {
-                    constexpr int Q = decltype(QC)::value;
-                    ++head[Q];
-                    hk[Q] = nk[Q];
-                    nk[Q] = head[Q] + 1 < DET_CAP ? lkeys[c * DET_CAP + head[Q] + 1] : 0u;
-                };
-                if (q == 0) advance(std::integral_constant<int, 0>{});
-                if constexpr (LPL > 1) { if (q == 1) advance(std::integral_constant<int, 1>{}); }
-                if constexpr (LPL > 2) { if (q == 2) advance(std::integral_constant<int, 2>{}); }
-                if constexpr (LPL > 3) { if (q == 3) advance(std::integral_constant<int, 3>{}); }
-                lane_best();
-            }
+        for (int q = 0; q < LPL; ++q) {
+            const int c = g + 64 * q;
+            if (c < ncls) { fs.s_gt[c] = lo[q]; fs.s_eq[c] = hi[q] - lo[q]; }
         }
-        if (tid == 0) n_sel = n;
+    }
+    __syncthreads();
+    const int n = need;
+    {
+        // ties at T go to the classes in ascending order (lower flat slot first)
+        const int eq = tid < ncls ? fs.s_eq[tid] : 0;
+        const int eq_before = block256_excl_scan(eq, fs.wtot[0]);
+        const int take = min(max(n - above - eq_before, 0), eq);
+        const int mine = tid < ncls ? fs.s_gt[tid] + take : 0;
+        const int base = block256_excl_scan(mine, fs.wtot[1]);
+        if (tid < ncls) { fs.s_gt[tid] = mine; fs.s_base[tid] = base; }
+    }
+    __syncthreads();
+    for (int e = tid; e < ncls * DET_CAP; e += NT) {
+        const int c = e / DET_CAP, j = e - c * DET_CAP;
+        if (j < fs.s_gt[c]) fs.cand[fs.s_base[c] + j] = ((unsigned long long)lkeys[e] << 32) | (uint32_t)~(uint32_t)(c * TOPK_CAP + j);
+    }
+    __syncthreads();
+    {
+        // rank by counting: 8 lanes share an entry (n <= DET_CAP = NT / 8), packed values are distinct
+        static_assert(NT / 8 == DET_CAP, "eight lanes per selected entry");
+        const int i = tid >> 3, part8 = tid & 7;
+        const unsigned long long mine = i < n ? fs.cand[i] : 0ull;
+        int before = 0;
+        for (int k = part8; k < n; k += 8) before += fs.cand[k] > mine ? 1 : 0;
+        before += __shfl_xor(before, 1);
+        before += __shfl_xor(before, 2);
+        before += __shfl_xor(before, 4);
+        if (part8 == 0 && i < n) fs.sel[before] = (int)~(uint32_t)mine;
     }
     __syncthreads();
     YM_NMS_STAMP(w.counters, 3);
-    const int n = n_sel;
-    if (tid == 0) out_count[0] = n;
+    if (tid == 0) o.out_count[0] = n;
     // the two dependent look-ups (slot -> compacted candidate -> anchor) once per detection; the gathers below are then single loads
-    __shared__ int s_k[DET_CAP], s_a[DET_CAP];
     if (tid < n) {
-        const int k = w.top_idx[sel[tid]];
-        s_k[tid] = k;
-        s_a[tid] = w.keep_idx[k];
+        const int k = w.top_idx[fs.sel[tid]];
+        fs.s_k[tid] = k;
+        fs.s_a[tid] = w.keep_idx[k];
     }
     __syncthreads();
     if (tid < n) {
-        const int f = sel[tid];
+        const int f = fs.sel[tid];
         const int c = f / TOPK_CAP;
-        out_ids[tid] = c;
-        out_scores[tid] = key2f(lkeys[c * DET_CAP + (f - c * TOPK_CAP)]);
-        *reinterpret_cast<f32x4*>(out_boxes + tid * 4) = *reinterpret_cast<const f32x4*>(w.boxes_k + (size_t)s_k[tid] * 4);
+        o.out_ids[tid] = c;
+        o.out_scores[tid] = key2f(lkeys[c * DET_CAP + (f - c * TOPK_CAP)]);
+        *reinterpret_cast<f32x4*>(o.out_boxes + tid * 4) = *reinterpret_cast<const f32x4*>(w.boxes_k + (size_t)fs.s_k[tid] * 4);
     }
-    for (int e = tid; e < n * coef_dim; e += NT) {
-        const int j = e / coef_dim, d = e - j * coef_dim;
-        out_coefs[e] = coef[(size_t)s_a[j] * coef_dim + d];
+    for (int e = tid; e < n * o.coef_dim; e += NT) {
+        const int j = e / o.coef_dim, d = e - j * o.coef_dim;
+        o.out_coefs[e] = o.coef[(size_t)fs.s_a[j] * o.coef_dim + d];
     }
     YM_NMS_STAMP(w.counters, 4);
+}
+
+template <int LPL>
+__global__ __launch_bounds__(NT) void k_final_select(const NmsWs w0, int ncls, int max_det, const FinalOut o0, size_t ws_stride, int N) {
+    const NmsWs w = image_ws(w0, ws_stride, blockIdx.y);
+    const FinalOut o = image_out(o0, blockIdx.y, max_det, N);
+    __shared__ FinalShared fs;
+    if (w.counters[0] == 0) {
+        if (threadIdx.x == 0) o.out_count[0] = 0;
+        return;
+    }
+    final_stage<LPL>(w, ncls, max_det, o, fs);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -874,19 +950,19 @@ extern "C" int ym_detect_fast_nms_batch(const float* class_pred, const float* bo
     const int ncls = cfg->num_classes - 1;
     hipLaunchKernelGGL(k_class_topk_iou, dim3(ncls, B), dim3(NT), 0, st, w, cfg->num_anchors, cfg->top_k, cfg->iou_thre, stride);
     const size_t merge_lds = (size_t)ncls * DET_CAP * sizeof(uint32_t);          // <= 255 * 128 * 4 = 130 KB
-    const int lpl = (ncls + 63) / 64;                    // lists per lane of the merging wave (1..4: num_classes <= 256)
-#define YM_MERGE(L_)                                                                                                              \
+    const int lpl = (ncls + 63) / 64;                    // classes per lane group of the final select (1..4: num_classes <= 256)
+    const FinalOut fo = {coef_pred, cfg->coef_dim, out_count, out_ids, out_scores, out_boxes, out_coefs};
+#define YM_FINAL(L_)                                                                                                              \
     do {                                                                                                                          \
         static size_t set_ = 0;                                                                                                   \
         if (merge_lds > set_) {                                                                                                   \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_final_merge<L_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)merge_lds); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_final_select<L_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)merge_lds); \
             set_ = merge_lds;                                                                                                     \
         }                                                                                                                         \
-        hipLaunchKernelGGL(k_final_merge<L_>, dim3(1, B), dim3(NT), merge_lds, st, w, ncls, cfg->max_det, coef_pred, cfg->coef_dim, \
-                           out_count, out_ids, out_scores, out_boxes, out_coefs, stride, cfg->num_anchors);                       \
+        hipLaunchKernelGGL(k_final_select<L_>, dim3(1, B), dim3(NT), merge_lds, st, w, ncls, cfg->max_det, fo, stride, cfg->num_anchors); \
     } while (0)
-    if (lpl <= 1) YM_MERGE(1); else if (lpl == 2) YM_MERGE(2); else if (lpl == 3) YM_MERGE(3); else YM_MERGE(4);
-#undef YM_MERGE
+    if (lpl <= 1) YM_FINAL(1); else if (lpl == 2) YM_FINAL(2); else if (lpl == 3) YM_FINAL(3); else YM_FINAL(4);
+#undef YM_FINAL
     return ym_check_launch("fast_nms");
 }
 

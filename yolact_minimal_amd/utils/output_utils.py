@@ -21,6 +21,7 @@ from .. import hip
 
 _anchor_cache = {}
 _ws_cache = {}
+_plan_cache = {}
 
 
 def _anchors_on(anchors, device):
@@ -169,27 +170,43 @@ def nms_batch(class_pred, box_pred, coef_pred, proto_out, anchors, cfg):
     anchors_t = _anchors_on(anchors, device)
     if anchors_t.shape[0] != n_anchors:
         raise RuntimeError(f'{anchors_t.shape[0]} anchors for {n_anchors} predictions')
-    ncfg = hip.NmsCfg(n_anchors, n_classes, coef_pred.shape[2], int(cfg.top_k), int(cfg.max_detections),
-                      float(cfg.nms_score_thre), float(cfg.nms_iou_thre), float(getattr(cfg, 'img_size', 544)))
-    md = ncfg.max_det
+    # everything that depends only on the shapes and the thresholds is built once: an eager call spends its time between the
+    # caller's line and the first launch HERE (~20 us of Python against ~68 us of device time: bench.post_bench's two columns)
+    pkey = (device.index, batch, n_anchors, n_classes, coef_pred.shape[2], cfg.top_k, cfg.max_detections, cfg.nms_score_thre,
+            cfg.nms_iou_thre, getattr(cfg, 'img_size', 544))
+    plan = _plan_cache.get(pkey)
     L = hip.lib()
-    nbytes = L.ym_nms_batch_workspace_bytes(ctypes.byref(ncfg), batch)
-    if nbytes == 0:
-        raise RuntimeError('ym_nms_batch_workspace_bytes: ' + L.ym_last_error().decode())
-    key = ('batch', str(device), torch.cuda.current_stream(device).cuda_stream, batch, n_anchors, n_classes)
-    ws = _ws_cache.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = _ws_cache[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
-    counts = torch.empty(batch, dtype=torch.int32, device=device)
-    ids = torch.empty(batch, md, dtype=torch.int64, device=device)
-    scores = torch.empty(batch, md, dtype=torch.float32, device=device)
-    boxes = torch.empty(batch, md, 4, dtype=torch.float32, device=device)
-    coefs = torch.empty(batch, md, ncfg.coef_dim, dtype=torch.float32, device=device)
-    with torch.cuda.device(device):
+    if plan is None:
+        ncfg = hip.NmsCfg(n_anchors, n_classes, coef_pred.shape[2], int(cfg.top_k), int(cfg.max_detections),
+                          float(cfg.nms_score_thre), float(cfg.nms_iou_thre), float(getattr(cfg, 'img_size', 544)))
+        nbytes = L.ym_nms_batch_workspace_bytes(ctypes.byref(ncfg), batch)
+        if nbytes == 0:
+            raise RuntimeError('ym_nms_batch_workspace_bytes: ' + L.ym_last_error().decode())
+        plan = _plan_cache[pkey] = (ncfg, ctypes.byref(ncfg), nbytes)
+    ncfg, ncfg_ref, nbytes = plan
+    md = ncfg.max_det
+    other_device = torch.cuda.current_device() != device.index
+    if other_device:
+        prev = torch.cuda.current_device()
+        torch.cuda.set_device(device)
+    try:
+        stream = torch.cuda.current_stream().cuda_stream
+        key = ('batch', device.index, stream, batch, n_anchors, n_classes)      # (scratch is per STREAM, like _nms_buffers)
+        ws = _ws_cache.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = _ws_cache[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        counts = torch.empty(batch, dtype=torch.int32, device=device)
+        ids = torch.empty(batch, md, dtype=torch.int64, device=device)
+        scores = torch.empty(batch, md, dtype=torch.float32, device=device)
+        boxes = torch.empty(batch, md, 4, dtype=torch.float32, device=device)
+        coefs = torch.empty(batch, md, ncfg.coef_dim, dtype=torch.float32, device=device)
         hip.check(L.ym_detect_fast_nms_batch(hip.ptr(class_pred.contiguous()), hip.ptr(box_pred.contiguous()), hip.ptr(coef_pred.contiguous()),
-                                             hip.ptr(anchors_t), ctypes.byref(ncfg), batch, hip.ptr(counts, torch.int32),
+                                             hip.ptr(anchors_t), ncfg_ref, batch, hip.ptr(counts, torch.int32),
                                              hip.ptr(ids, torch.int64), hip.ptr(scores), hip.ptr(boxes), hip.ptr(coefs),
-                                             ctypes.c_void_p(ws.data_ptr()), ws.numel(), hip.stream_ptr()), 'ym_detect_fast_nms_batch')
+                                             ctypes.c_void_p(ws.data_ptr()), ws.numel(), ctypes.c_void_p(stream)), 'ym_detect_fast_nms_batch')
+    finally:
+        if other_device:
+            torch.cuda.set_device(prev)
     return BatchDetections(counts, ids, scores, boxes, coefs, proto_out)
 
 
