@@ -1,5 +1,6 @@
 // Shared between the two convolution kernels (LDS-tiled workgroup kernel, wave-private kernel).
 #pragma once
+#include <cstdlib>
 #include "ym_common.h"
 
 namespace ymk {
@@ -92,9 +93,13 @@ struct ConvP {
     FastDiv cls_fd_hw[4], cls_fd_w[4];
     int cls_kh0[4], cls_kw0[4], cls_nkw[4];   // first tap (then every second one), taps per filter row
     int cls_nkt[4], cls_ktps[4], cls_tail_ktps[4];   // K tiles of the class, per K slice of a main / tail tile
-    int m_fastest;     // tile order inside an XCD's chunk: 0 = n fastest (neighbours share the input panel), 1 = m fastest (neighbours
-                       // share the WEIGHT panel: chosen when the weights are the larger operand, so that the 8 XCD L2s partition them)
-    FastDiv fd_tiles_m;
+    // Tile order.  The XCD remap (ym_xcd_remap) hands every XCD a contiguous chunk of the tile ids; ids run n-fastest inside GROUPS of
+    // `fd_gn.d` tile columns, group after group (ym_tile_decode).  One group = the plain n-fastest order: an XCD's chunk is a band of
+    // tile rows across ALL columns, so each of the 8 L2s fetches its eighth of the input and the WHOLE filter (A + 8 W bytes leave
+    // the fabric); groups of one column = m-fastest: the L2s partition the filter and each reads the whole input (8 A + W); g
+    // groups in between give every XCD a (rows / (8 / g)) x (columns / g) block: g A + (8 / g) W.  ym_set_tile_order picks g.
+    int n_groups;
+    FastDiv fd_grp, fd_gn, fd_gn_last;   // tiles per group (tiles_m x group width), group width, width of the last group
     long long* trace;  // debug builds (-DYM_TRACE, tools/conv_trace.py): per-workgroup s_memtime stamps [grid][4]
     const int* trace_epoch;  // debug builds: stamps go to region (*trace_epoch % trace_ring) of `trace` ([ring][grid][4]) so that the last
     int trace_ring;          // `ring` replays of a captured launch stay readable (tools/overlap_trace.py); null / 0: one region
@@ -107,6 +112,50 @@ struct ConvP {
     int vec;   // 1: single segment, plain NHWC [M][Cout], Cout % 4 == 0, 16-byte aligned -> vectorised epilogue
     SegDev seg[3];
 };
+
+// id -> (tile_m, tile_n) under the group order above (block-uniform: two multiply-shift divisions)
+__device__ __forceinline__ void ym_tile_decode(const ConvP& p, int id, int& tile_m, int& tile_n) {
+    const unsigned g = p.fd_grp.div((unsigned)id);
+    const unsigned r = (unsigned)id - g * p.fd_grp.d;
+    const bool last = (int)g == p.n_groups - 1;
+    const unsigned w = last ? p.fd_gn_last.d : p.fd_gn.d;
+    const unsigned tm = last ? p.fd_gn_last.div(r) : p.fd_gn.div(r);
+    tile_m = (int)tm;
+    tile_n = (int)(g * p.fd_gn.d + (r - tm * w));
+}
+
+// Host side: choose the number of column groups from the bytes of the two operands (p.tiles_m / tiles_n / in_bytes / w_bytes set).
+// `groups` > 0 forces it (1 = n-fastest, >= tiles_n = m-fastest); 0 = the traffic model: g in {1, 2, 4, 8} minimising
+// g A + (8 / g) W, a change of order only for a gain of >= 5 %.  YM_TILE_GROUPS overrides (experiments; "legacy" = rounds 1-4:
+// m-fastest iff the filter is the larger operand).
+inline void ym_set_tile_order(ConvP& p, int groups, bool allow_model) {
+    const int tn = p.tiles_n > 0 ? p.tiles_n : 1, tm = p.tiles_m > 0 ? p.tiles_m : 1;
+    static const char* env = getenv("YM_TILE_GROUPS");
+    if (groups <= 0) {
+        const double a = (double)p.in_bytes, w = (double)p.w_bytes;
+        if (env && env[0] == 'l') groups = (allow_model && w > a) ? tn : 1;
+        else if (env && atoi(env) > 0) groups = allow_model ? atoi(env) : 1;
+        else {
+            groups = 1;
+            double best = a + 8.0 * w;
+            // (only where both operands are small enough to sit in the L2s next to the output -- the batch-1 regime, where every tile
+            //  of the launch is in flight at once; larger launches keep the order they were tuned with: measured neutral to -0.7 %)
+            const bool small = a + w <= 8.0 * 1024 * 1024;
+            if (allow_model && !small && w > a) groups = tn;
+            for (int g = 2; g <= 8 && allow_model && small; g *= 2) {
+                if (tn < g) break;
+                const double t = g * a + (8.0 / g) * w;
+                if (t < 0.95 * best) { best = t; groups = g; }
+            }
+        }
+    }
+    if (groups > tn) groups = tn;
+    const int gw = (tn + groups - 1) / groups;            // group width in tile columns
+    p.n_groups = (tn + gw - 1) / gw;
+    p.fd_gn = FastDiv::make((unsigned)gw);
+    p.fd_gn_last = FastDiv::make((unsigned)(tn - (p.n_groups - 1) * gw));
+    p.fd_grp = FastDiv::make((unsigned)(tm * gw));
+}
 
 // Phase stamps for tools/conv_trace.py (only in the -DYM_TRACE debug build: `make -C yolact_minimal_amd/csrc trace`).
 #ifdef YM_TRACE

@@ -83,8 +83,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
         }
     }
     int tile_m, tile_n;
-    if (p.m_fastest) { tile_n = (int)p.fd_tiles_m.div((unsigned)id); tile_m = id - tile_n * p.tiles_m; }
-    else { tile_m = (int)p.fd_tiles_n.div((unsigned)id); tile_n = id - tile_m * p.tiles_n; }
+    ym_tile_decode(p, id, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // stride-2 data gradient: the parity class of this tile's rows (conv_common.h) -- its first GEMM row, its taps, its K range
@@ -1140,11 +1139,9 @@ extern "C" int ym_conv2d_fwd(const ym_conv_desc* d, void* workspace, size_t work
     p.tail_split = pl.tail_tiles > 0 ? pl.tail_split : 1;
     p.tail_ktps = pl.tail_tiles > 0 ? pl.tail_ktps : pl.nkt;
     p.fd_ksplit = FastDiv::make((unsigned)pl.ksplit); p.fd_tail = FastDiv::make((unsigned)p.tail_split);
-    p.fd_tiles_n = FastDiv::make((unsigned)pl.tiles_n); p.fd_tiles_m = FastDiv::make((unsigned)pl.tiles_m);
-    {
-        const char* e = getenv("YM_TILE_ORDER");          // experiment knob: 0 / 1 force, default = larger operand decides
-        p.m_fastest = e ? atoi(e) : (p.w_bytes > p.in_bytes && pl.tail_tiles == 0 ? 1 : 0);
-    } p.fd_howo = FastDiv::make((unsigned)(d->Ho * d->Wo));
+    p.fd_tiles_n = FastDiv::make((unsigned)pl.tiles_n);
+    ym_set_tile_order(p, 0, pl.tail_tiles == 0);          // (a tail keeps the plain order: its tiles are the LAST rows of the output)
+    p.fd_howo = FastDiv::make((unsigned)(d->Ho * d->Wo));
     p.fd_wo = FastDiv::make((unsigned)d->Wo); p.fd_cin = FastDiv::make((unsigned)d->Cin); p.fd_kw = FastDiv::make((unsigned)d->KW);
     p.ws_bytes = (unsigned)(need < 0xFFFFFFF0ull ? need : 0);
     if (d->bn_sum) {

@@ -93,8 +93,7 @@ __global__ __launch_bounds__(256) void conv_igemm_pers(const ConvP p) {
             p.fd_tail.divmod((unsigned)(b - p.main_blocks), q, r);
             it.id = p.main_tiles + (int)q; it.ks = (int)r; it.nks = p.tail_split; ktps = p.tail_ktps;
         }
-        if (p.m_fastest) { it.tile_n = (int)p.fd_tiles_m.div((unsigned)it.id); it.tile_m = it.id - it.tile_n * p.tiles_m; }
-        else { it.tile_m = (int)p.fd_tiles_n.div((unsigned)it.id); it.tile_n = it.id - it.tile_m * p.tiles_n; }
+        ym_tile_decode(p, it.id, it.tile_m, it.tile_n);
         it.kt_beg = it.ks * ktps;
         it.kt_end = min(p.nkt, it.kt_beg + ktps);
         return it;

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_wdma_f32(const ConvP p) {
     }
     const bool tile_ok = tile < p.tiles_m * p.tiles_n;
     int tile_m = 0, tile_n = 0;
-    if (tile_ok) { tile_m = (int)p.fd_tiles_n.div((unsigned)tile); tile_n = tile - tile_m * p.tiles_n; }
+    if (tile_ok) ym_tile_decode(p, tile, tile_m, tile_n);
     const int m0 = tile_m * WM, n0 = tile_n * WN;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
@@ -557,6 +557,7 @@ int launch_dma(ConvP p, hipStream_t st) {
     p.tiles_m = ym_cdiv(p.M, 32 * TM);
     p.tiles_n = ym_cdiv(p.Cout, 32 * TN);
     p.fd_tiles_n = FastDiv::make((unsigned)p.tiles_n);
+    ym_set_tile_order(p, 0, true);           // (the wave tiles differ from the planner's: the order is chosen for THIS tiling)
     p.ksplit = 1;
     int grid = ym_cdiv(p.tiles_m * p.tiles_n, TPB);
     if (TM * TN == 1 && KW == 4 && WPB == 4) {           // (the caller planned the tail: main_tiles / tail_split / tail_ktps / counters)
