@@ -122,6 +122,27 @@ def test_nms_ties_against_stable_oracle(golden_dir):
     _check_nms(out, r)
 
 
+@pytest.mark.parametrize('ncls,top_k,max_det', [(3, 200, 100), (64, 200, 100), (65, 50, 7), (130, 200, 128), (200, 200, 100), (255, 17, 100)])
+def test_nms_class_counts_and_limits(ncls, top_k, max_det):
+    """The final select is instantiated per 64 classes (1..4 lists per lane group) and the reference's limits are config values
+    (config.py: top_k, max_detections): every instantiation, cut-offs below / at the caps, scores quantised so that ties cross
+    class boundaries and sit on the max_det cut -- against the oracle with a stable sort, bit for bit."""
+    gen = torch.Generator().manual_seed(1000 + ncls)
+    anchors = R.anchors_for(128, [24, 48, 96, 192, 384])
+    n = anchors.shape[0]
+    logits = torch.randn(1, n, ncls + 1, generator=gen) * 3.0
+    logits[..., 0] += 1.0
+    cls = torch.round(torch.softmax(logits, -1) * 32.0) / 32.0            # 33 score levels: ties everywhere
+    box = torch.randn(1, n, 4, generator=gen) * 0.5
+    coef = torch.tanh(torch.randn(1, n, 32, generator=gen))
+    proto = torch.randn(1, 32, 32, 32, generator=gen)
+    cfg = _cfg(img_size=128, top_k=top_k, max_detections=max_det)
+    out = _gpu_nms(cls, box, coef, proto, anchors, cfg)
+    r = R.nms(cls, box, coef, proto, anchors, top_k=top_k, max_det=max_det, img_size=128, stable=True, exp='cr')
+    assert r[0] is not None and r[0].numel() == min(max_det, r[0].numel())
+    _check_nms(out, r)
+
+
 @pytest.mark.parametrize('seed,bg,tag', [(1, 4.0, 'dense544'), (2, 9.0, 'sparse544')])
 def test_nms_full_size(golden_dir, seed, bg, tag):
     """BASELINE full geometry: 18 525 anchors, 136x136x32 prototypes, ~17.8k / ~300 candidates."""
