@@ -807,7 +807,11 @@ class InferEngine:
             torch.cuda.synchronize()
             try:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # thread_local: only THIS thread's calls are checked against the capture.  In the default global mode an event query
+                # from any other thread while the capture is open is an error -- and the process group's watchdog thread polls the
+                # events of its collectives exactly like that (seen once as an abort of `bench.py` under torchrun: the barrier's
+                # work object was still being polled when the first engine captured its plan).
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):
                     self._launch_all(self.static_img)
                 self.graph = g
             except Exception as exc:                       # still the HIP kernels, just launched one by one
