@@ -1,5 +1,6 @@
 """GPU parity of the single ops behind the C-ABI against plain PyTorch fp32 on the CPU."""
 import ctypes
+import os
 
 import pytest
 import torch
@@ -449,6 +450,68 @@ def test_conv_wave_dma_ring_tail_split(case):
     for _ in range(3):
         assert torch.equal(got, run_conv(x, wt, scale, shift, res, stride, pad, act, repeat=30, **kw))
     assert int(counters.abs().sum()) == 0
+
+
+_TILE_ORDER_PROBE = r"""
+import sys, torch
+sys.path.insert(0, {repo!r})
+from tests.test_gpu_ops import run_conv, _dev
+from yolact_minimal_amd import hip
+g = torch.Generator().manual_seed(77)
+out = []
+# (cin, h, w, cout, k, pad, kwargs): tile columns that the group counts 2 / 3 / 4 / 8 do not divide, a tail, a K split, the walker
+cases = [
+    (64, 34, 34, 160, 3, 1, dict(tile=(32, 32), kwaves=4, stages=22)),                       # 37 x 5 wave tiles
+    (256, 34, 34, 288, 1, 0, dict(tile=(32, 32), kwaves=4, stages=22, tail=(77, 4))),        # 37 x 9 = 333 tiles, 77 of them in the tail
+    (128, 34, 34, 224, 1, 0, dict(tile=(32, 32), kwaves=1, stages=22, grid_wgs=1)),          # one-wave workgroups, 37 x 7
+    (64, 40, 40, 320, 3, 1, dict(tile=(64, 64), ksplit=1, stages=22)),                       # conv_igemm_f32, 25 x 5
+    (256, 20, 20, 448, 1, 0, dict(tile=(64, 64), ksplit=3, stages=22)),                      # K slices meet in the fused finish, 7 x 7
+    (64, 40, 40, 320, 3, 1, dict(tile=(64, 64), ksplit=1, stages=43, grid_wgs=16)),          # conv_igemm_pers
+]
+for cin, h, w, cout, k, pad, kw in cases:
+    x = torch.randn(1, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    counters = torch.zeros(hip.TILE_COUNTERS, device=_dev(), dtype=torch.int32)
+    y = run_conv(x, wt, sc, sh, None, 1, pad, 1, counters=counters, **kw)
+    assert not torch.isnan(y).any() and int(counters.abs().sum()) == 0
+    out.append(y.contiguous())
+torch.save(out, sys.argv[1])
+"""
+
+
+def test_tile_order_groups_do_not_change_results(tmp_path):
+    """The order in which tile ids map to (tile row, tile column) (csrc/conv_common.h: ym_tile_decode, groups of tile columns chosen per
+    launch from the operand bytes) decides which workgroup computes a tile, never how: every forced group count -- including ones
+    that leave a narrower last group -- must reproduce the default's outputs bit for bit, for the wave kernels (one-wave
+    workgroups too), the per-item kernel (with K slices) and the persistent walker.  One exception by construction: with a TAIL
+    split the last tile ids are computed slice by slice (another summation order than a whole tile's), and which tiles those are
+    depends on the order -- there the outputs agree to rounding, not to the bit (the per-item kernel keeps the plain order under a
+    tail for that reason).  YM_TILE_GROUPS is read once per process, hence the subprocesses."""
+    import subprocess
+    import sys
+    from tests.conftest import REPO
+    seen = {}
+    for setting in (None, '1', '2', '3', '4', '8', '64', 'legacy'):
+        env = dict(os.environ)
+        env.pop('YM_TILE_GROUPS', None)
+        if setting is not None:
+            env['YM_TILE_GROUPS'] = setting
+        path = str(tmp_path / f'out_{setting}.pt')
+        out = subprocess.run([sys.executable, '-c', _TILE_ORDER_PROBE.format(repo=REPO), path], env=env, capture_output=True, text=True,
+                             timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        seen[setting] = torch.load(path)
+    base = seen[None]
+    assert len(base) == 6
+    for setting, outs in seen.items():
+        for i, (a, b) in enumerate(zip(outs, base)):
+            if i == 1:                                     # the launch with a tail
+                torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6, msg=f'YM_TILE_GROUPS={setting}, case {i}')
+            else:
+                assert torch.equal(a, b), (setting, i, float((a - b).abs().max()))
+    # and the tail case is not vacuous: some forced order does move tiles into / out of the tail
+    assert any(not torch.equal(outs[1], base[1]) for outs in seen.values())
 
 
 def test_conv_wave_dma_ring_rejects_what_it_does_not_cover():
