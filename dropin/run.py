@@ -16,6 +16,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 
+# Requests / batches in flight (yolact_minimal_amd.pipeline.RequestPipeline) and the weight-gradient side stream run on separate HIP
+# streams; ROCm multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable when the runtime
+# starts, i.e. before the script's `import torch` touches HIP.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 
 def main():
     if len(sys.argv) < 2:

@@ -7,9 +7,12 @@
                                     and strided samples of every parameter gradient + stem running stats
   train_res101_coco_544_b8.npz      config 3's per-GPU training step at full size (same content)
   train_res101_coco_544_b16.npz     config 4's per-GPU training step (batch 16): 4 losses + fp32 gradient digests
+  train_res101_coco_544_b8_wellcond.npz config 3's shape, residual branches damped (R.damp_residual_branches_) and the backbone's ReLU
+                                    zero crossings moved to -3 sigma (R.shift_bn_bias_: no sign flips inside the rounding noise): the fp32
+                                    reference sits within ~1e-5 of fp64, the HIP step is held to 1e-3 of max|g| per tensor / 1 % on the digests
 
 Every case also pins oracle/yolact_ref.py's restatement bit for bit against the reference.  TEST INFRASTRUCTURE ONLY.
-Run from the repo root:  python -m oracle.make_golden_fullsize [forward] [train256] [train544] [train544res50] [train544b16]
+Run from the repo root:  python -m oracle.make_golden_fullsize [forward] [train256] [train544] [train544res50] [train544b16] [train544wellcond]
 """
 import os
 import sys
@@ -63,13 +66,15 @@ def grad_sample(g):
     return f[:: max(1, f.numel() // 64)][:64].clone()
 
 
-def gen_train(ref_config, ref_yolact, name, size, batch, seed, damp=False, fp64=True):
+def gen_train(ref_config, ref_yolact, name, size, batch, seed, damp=False, fp64=True, tag='', shift=0.0):
     cfg = ref_cfg(ref_config, name, size, mode='train')
     torch.manual_seed(seed)
     net = ref_yolact.Yolact(cfg).train()
     if damp:                                  # well-conditioned variant: near-identity residual blocks (see the docstring there)
         sd = net.state_dict()
         R.damp_residual_branches_(sd, seed + 400)
+        if shift:
+            R.shift_bn_bias_(sd, shift)              # ReLU zero crossings at -shift sigma: no sign flips inside the rounding noise
         net.load_state_dict(sd)
     sd0 = {k: v.clone() for k, v in net.state_dict().items()}
     img = torch.randn(batch, 3, size, size, generator=torch.Generator().manual_seed(seed + 300))
@@ -121,7 +126,7 @@ def gen_train(ref_config, ref_yolact, name, size, batch, seed, damp=False, fp64=
           f'p90 {np.quantile(e, 0.9):.2e} max {e.max():.2e} ({keys[int(e.argmax())]}); '
           f'loss rel err {max(abs(float(a) - float(b)) / abs(float(b)) for a, b in zip(losses, l64)):.2e}', flush=True)
     np.savez_compressed(
-        os.path.join(OUT, f'train_{name}_{size}_b{batch}.npz'), seed=np.array(seed),
+        os.path.join(OUT, f'train_{name}_{size}_b{batch}{tag}.npz'), seed=np.array(seed),
         losses=np.array([float(l.detach()) for l in losses], dtype=np.float64),
         losses_fp64=np.array([float(l.detach()) for l in l64], dtype=np.float64),
         grad_keys=np.array(keys), grad_digest=np.stack([tensor_digest(grads[k]) for k in keys]),
@@ -144,6 +149,8 @@ def main():
         gen_train(ref_config, ref_yolact, 'res101_coco', 544, 8, 72)
     if 'train544res50' in what:       # the second ResNet depth at the benchmarked size (bench: extra.res50_coco_bs8 / CPU baseline config 1)
         gen_train(ref_config, ref_yolact, 'res50_coco', 544, 8, 74)
+    if 'train544wellcond' in what:    # the WELL-CONDITIONED full-size step: config 3's shape, near-identity residual blocks, ReLU crossings at -3 sigma
+        gen_train(ref_config, ref_yolact, 'res101_coco', 544, 8, 75, damp=True, shift=3.0, tag='_wellcond')
     if 'train544b16' in what:         # BASELINE config 4's per-GPU batch
         gen_train(ref_config, ref_yolact, 'res101_coco', 544, 16, 73, fp64=False)
 

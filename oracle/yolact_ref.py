@@ -393,6 +393,22 @@ def damp_residual_branches_(sd, seed=13, scale=0.05):
     return sd
 
 
+def shift_bn_bias_(sd, k=2.0):
+    """Every backbone BatchNorm gets beta = k * |gamma|: the ReLU behind it switches at -k sigma of its input instead of at the mode.
+    Why: what makes a random-init YOLACT step "ill-conditioned" in fp32 is not rounding that grows with depth but DISCRETE ReLU
+    sign flips — a unit whose pre-activation lies inside the forward rounding noise (~1e-6 of the scale; ~0.4 * 1e-6 of all units
+    when the zero crossing sits at the mode of a normalised activation) comes out on the other side in another fp32 implementation,
+    which changes that channel's BatchNorm-backward sums by 1 / (samples per channel) and everything below it.  Measured with the
+    CPU oracle (fp32 vs fp64, damped res50 256 px bs=4): the error is 6e-6 of max|g| in layer4's last block, jumps to 8e-2 in ONE
+    tensor (layers.3.1.conv2) and is 5e-4 (median) in every tensor below; with the crossings at -2 sigma (2.3 % of the units still
+    switch off, so the mask paths of backward stay exercised) the whole backbone is at 2e-6.  Used by the well-conditioned
+    full-size goldens (oracle/make_golden_fullsize.py train544wellcond, oracle/make_golden_loop.py)."""
+    for key in sorted(sd):
+        if key.startswith('backbone') and key.endswith('.bias') and key[:-4] + 'running_mean' in sd:
+            sd[key].copy_(k * sd[key[:-4] + 'weight'].abs())
+    return sd
+
+
 def randomize_bias_(sd, seed=11):
     """Conv biases are zero-initialised by the reference; make them non-zero so the bias path is exercised."""
     g = torch.Generator().manual_seed(seed)

@@ -1,0 +1,134 @@
+"""SURVEY §8b, training leg of the drop-in boundary: the reference's own loop — `optim.SGD(net.parameters(), ...)` (AdamW for
+swin_tiny_coco), `DDP(net.cuda(), [local_rank], output_device=local_rank, broadcast_buffers=True)` on a one-rank RCCL group,
+`net(images, targets, masks)`, `dist.all_reduce(all_loss)`, `optimizer.zero_grad()`, `loss_total.backward()`, `optimizer.step()`,
+then the `evaluate`-style eval forward on `net.module` (/root/reference/train.py:44-48,60-63,76,102-130,165-166; restated in
+dropin/reference_loops.py, bound through `dropin/` exactly as `dropin/run.py train.py` binds it) — on the HIP path, against
+
+  (i)  the build's own `Trainer.step` on the same seed and inputs (same kernels, other plumbing: flat gradient buffer, side
+       stream, deferred slab reductions, FlatGradReducer, one-launch optimizer), and
+  (ii) the REAL reference running the same statements on the CPU (tests/golden/loop_*.npz, oracle/make_golden_loop.py).
+
+Each case runs in a process of its own (tests/run_reference_loop.py): train.py's `get_config` joins a process group."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(tmp_path, cfg, size, bs, seed, steps=3, extra=()):
+    out = str(tmp_path / f'loop_{cfg}_{size}.npz')
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'YM_FORCE_DIST'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'tests', 'run_reference_loop.py'), '--cfg', cfg, '--img_size', str(size),
+                        '--train_bs', str(bs), '--steps', str(steps), '--seed', str(seed), '--out', out, *extra],
+                       cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and 'REFERENCE_LOOP_OK' in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+    return np.load(out)
+
+
+def _check_against_trainer(d, exact=True):
+    """(i) the reference loop and Trainer.step agree.  SGD: BIT FOR BIT at every step — losses, every parameter, the BatchNorm
+    buffers, the eval forward on the trained weights: both paths run the same kernels on the same numbers (gradients land in fresh
+    tensors + DDP bucket copies + torch.optim.SGD on one side, in the flat buffer + FlatGradReducer + `ym_sgd_step`, which repeats
+    torch.optim.SGD's roundings, on the other).  AdamW (Swin-T): the parameters to 2e-5 of max|p| at every step and the losses to
+    1e-5; the UPDATES are not comparable element by element — the key bias of every attention block has a mathematically zero
+    gradient (softmax is invariant to it), i.e. pure rounding noise, which Adam's g / (|g| + eps) turns into +-lr steps, and the
+    relative-position-bias gradient is summed with float atomics (run-to-run rounding differences feed that noise)."""
+    assert str(d['wrapper']) == 'DistributedDataParallel' and int(d['grads_none']) == 0
+    q = np.quantile(d['update_rel_diff'], [0.5, 0.9, 1.0])
+    print(f'reference loop vs Trainer: losses max rel {np.abs(d["losses_loop"] / d["losses_trainer"] - 1).max():.2e}; per step: update diff / '
+          f'max|update| {d["step_update_diff"]}, parameter diff / max|p| {d["step_param_diff"]}; per tensor after the last step: update diff '
+          f'median {q[0]:.2e} p90 {q[1]:.2e} max {q[2]:.2e} ({d["keys"][int(d["update_rel_diff"].argmax())]}); buffers '
+          f'{float(d["buffer_rel_diff"]):.2e}; eval outputs {d["eval_loop_vs_trainer"]}')
+    assert int(d['num_batches_tracked']) == int(d['num_batches_tracked_trainer']) == int(d['end_step']) or int(d['num_batches_tracked']) == -1
+    if exact:
+        assert np.array_equal(d['losses_loop'], d['losses_trainer'])
+        assert float(d['step_update_diff'].max()) == 0.0 and float(d['step_param_diff'].max()) == 0.0
+        assert float(d['buffer_rel_diff']) == 0.0 and float(d['eval_loop_vs_trainer'].max()) == 0.0
+    else:
+        np.testing.assert_allclose(d['losses_loop'], d['losses_trainer'], rtol=1e-5)
+        assert float(d['step_param_diff'].max()) <= 2e-5
+        assert q[0] <= 1e-3, q
+        assert float(d['eval_loop_vs_trainer'].max()) <= 1e-4
+
+
+def _check_against_reference(d, g, loss_rtol, digest_tol, sample_tol):
+    """(ii) the REAL reference's loop on the CPU: learning rates exactly, losses step by step, every parameter's UPDATE (what the
+    three optimizer steps did to it) by robust norms and strided samples, the stem's running statistics, the eval forward."""
+    assert [str(k) for k in g['keys']] == [str(k) for k in d['keys']]
+    np.testing.assert_allclose(d['lrs'], g['lrs'], rtol=1e-12)
+    for s, tol in enumerate(loss_rtol):
+        np.testing.assert_allclose(d['losses_loop'][s], g['losses'][s], rtol=tol, err_msg=f'step {s}')
+    bad, errs = [], []
+    for i, k in enumerate(d['keys']):
+        dg, rg = d['update_digest'][i], g['update_digest'][i]
+        e = np.abs(d['update_sample'][i] - g['update_sample'][i]).max() / (float(g['update_absmax'][i]) + 1e-30)
+        errs.append(e)
+        if abs(dg[1] - rg[1]) > digest_tol * rg[1] + 1e-12 or abs(dg[2] - rg[2]) > 2 * digest_tol * rg[2] + 1e-20 or e > sample_tol:
+            bad.append((str(k), float(e), dg.tolist(), rg.tolist()))
+    print(f'reference loop vs the REAL reference (CPU): losses rel {np.abs(d["losses_loop"] / g["losses"] - 1).max(axis=1)}, parameter-update '
+          f'samples / max|update|: median {np.median(errs):.2e} max {np.max(errs):.2e}; {len(bad)} of {len(errs)} tensors outside the bar')
+    assert not bad, (len(bad), [(b[0], round(b[1], 4), [round(x / y - 1, 4) for x, y in zip(b[2][1:], b[3][1:])]) for b in bad[:8]])
+    if int(g['num_batches_tracked']) >= 0:
+        assert int(d['num_batches_tracked']) == int(g['num_batches_tracked'])
+        np.testing.assert_allclose(d['run_mean_stem'], g['run_mean_stem'], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(d['run_var_stem'], g['run_var_stem'], rtol=1e-4, atol=1e-6)
+
+
+def test_reference_train_loop_res50_256(tmp_path, golden_dir):
+    d = _run(tmp_path, 'res50_coco', 256, 4, 71, extra=('--wellcond',))
+    assert str(d['optimizer']) == 'SGD'
+    _check_against_trainer(d)
+    g = np.load(os.path.join(golden_dir, 'loop_res50_coco_256_b4.npz'))
+    _check_against_reference(d, g, (1e-5, 1e-4, 5e-4), 0.05, 0.10)
+
+
+def test_reference_train_loop_res101_544_bs8(tmp_path, golden_dir):
+    """BASELINE config 3's per-GPU shape, the step bench.py times as `extra.train_reference_loop`."""
+    d = _run(tmp_path, 'res101_coco', 544, 8, 72, extra=('--wellcond',))
+    assert str(d['optimizer']) == 'SGD'
+    _check_against_trainer(d)
+    g = np.load(os.path.join(golden_dir, 'loop_res101_coco_544_b8.npz'))
+    _check_against_reference(d, g, (1e-5, 5e-4, 1e-2), 0.05, 0.15)
+
+
+def test_reference_train_loop_swin_tiny_adamw(tmp_path, golden_dir):
+    """train.py:62-63: AdamW(weight_decay=0.05) for swin_tiny_coco (stochastic depth off: the reference draws DropPath masks from
+    the global generator of its own device, which no other device reproduces)."""
+    d = _run(tmp_path, 'swin_tiny_coco', 128, 2, 73, extra=('--no_drop_path',))
+    assert str(d['optimizer']) == 'AdamW'
+    _check_against_trainer(d, exact=False)
+    g = np.load(os.path.join(golden_dir, 'loop_swin_tiny_coco_128_b2.npz'))
+    # AdamW's first steps move every weight by ~lr * sign(g): the update of an element whose gradient is inside the rounding noise
+    # flips sign, so samples are held loosely and the robust norms carry the comparison
+    _check_against_reference(d, g, (3e-4, 1e-2, 2e-2), 0.05, 2.5)
+
+
+def test_partial_backward_fails_loudly_instead_of_dropping_gradients():
+    """GradJoin 'pass' consumers park their gradient for a 'take' consumer; a backward over part of the graph
+    (`loss_s.backward()`) never reaches the taker.  Outside Trainer.step that used to drop the parked gradient in silence: now every
+    backward that parks a gradient ends with the drain check (a callback on the autograd engine)."""
+    import torch
+    from oracle import yolact_ref as R
+    from yolact_minimal_amd.config import build_cfg
+    from yolact_minimal_amd.modules.yolact import Yolact
+    cfg = build_cfg('res50_coco', 'train', 64)
+    torch.manual_seed(0)
+    net = Yolact(cfg).train().cuda()
+    img = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(1)).cuda()
+    boxes, masks = R.synth_targets(2, 64, seed=3)
+    losses = net(img, [b.cuda() for b in boxes], [m.cuda() for m in masks])
+    with pytest.raises(RuntimeError, match='never consumed'):
+        losses[3].backward()                                 # semantic loss alone: P3's taker (protonet) is not in this graph
+    # the whole graph still works, and twice in a row (the guard re-arms per backward)
+    for _ in range(2):
+        net.zero_grad()
+        losses = net(img, [b.cuda() for b in boxes], [m.cuda() for m in masks])
+        sum(losses).backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())

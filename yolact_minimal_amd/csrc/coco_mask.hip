@@ -207,11 +207,8 @@ int launch(const double* xy, const uint32_t* runs, const int32_t* item_off, cons
         gws = (uint32_t*)workspace;
         lds = 0;
     }
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[SRC]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ann_to_mask<SRC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET);
-        attr_set[SRC] = true;
-    }
+    static YmLdsAttr attr = {};                                   // (one per SRC instantiation of this function template)
+    if (int rc = ym_ensure_dyn_lds(attr, reinterpret_cast<const void*>(k_ann_to_mask<SRC>), LDS_BUDGET, what)) return rc;
     hipLaunchKernelGGL(k_ann_to_mask<SRC>, dim3(n), dim3(NT), lds, (hipStream_t)s, xy, runs, item_off, ann_off, H, W, col_stride(H), masks, gws);
     return ym_check_launch(what);
 }

@@ -923,7 +923,8 @@ int make_plan(const ym_conv_desc* d, Plan* pl, bool allow_cls = true) {
         const bool ok = shape_ok && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->Cin % 32 == 0 && d->k_pad == d->Cin &&
                         d->nlevels == 0 && d->kwaves == 0 && d->mma == 0 && d->bnb_y == nullptr && vec_epilogue(d) &&
                         (act == YM_ACT_NONE || act == YM_ACT_RELU) && (size_t)bn * d->Cin * 4 <= (64u << 10) &&
-                        ym_conv_ws_lds_bytes(bm, bn, pl->nkt, d->stages - 50) <= (160u << 10) && (unsigned long long)M * d->Cout * 4ull < 0xFFFFFFF0ull;
+                        ym_conv_ws_lds_bytes(bm, bn, pl->nkt, d->stages - 50) <= (160u << 10) && (unsigned long long)M * d->Cout * 4ull < 0xFFFFFFF0ull &&
+                        (unsigned long long)M * d->Cin * 4ull < 0xFFFFFFF0ull;      // (conv_ws.hip forms A and C offsets in 32 bits)
         if (ok) {
             pl->bm = bm; pl->bn = bn; pl->tiles_m = ym_cdiv(pl->M, bm); pl->tiles_n = ym_cdiv(d->Cout, bn);
             pl->ksplit = 1; pl->kt_per_split = pl->nkt;
@@ -1017,12 +1018,8 @@ void launch(const ConvP& p, int grid, hipStream_t st) {
     size_t lds = SPL ? (size_t)2 * (BM + BN) * SPL * 80 : (size_t)NS * (BM + BN) * (DL ? 32 : PITCH) * sizeof(float);
     const size_t epi = (size_t)BM * (BN + 4) * sizeof(float);          // accumulator staging of the vector epilogue
     if (lds < epi) lds = epi;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_f32<BM, BN, MODE, NS, DL, PF, RG, SPL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static YmLdsAttr attr = {};       // (a refusal leaves its message in ym_last_error; the launch below then fails and is reported)
+    (void)ym_ensure_dyn_lds(attr, reinterpret_cast<const void*>(conv_igemm_f32<BM, BN, MODE, NS, DL, PF, RG, SPL>), lds, "conv_igemm_f32");
     hipLaunchKernelGGL((conv_igemm_f32<BM, BN, MODE, NS, DL, PF, RG, SPL>), dim3(grid), dim3(256), lds, st, p);
 }
 

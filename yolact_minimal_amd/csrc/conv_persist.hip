@@ -522,12 +522,8 @@ __global__ __launch_bounds__(256) void conv_igemm_pers(const ConvP p) {
 template <int BM, int BN, int MODE, int NS, bool DEFER, bool ALIGNED>
 int launch_pers(const ConvP& p, int grid, hipStream_t st) {
     const size_t lds = ym_conv_pers_lds_bytes(BM, BN, NS, DEFER);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_pers<BM, BN, MODE, NS, DEFER, ALIGNED>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static YmLdsAttr attr = {};
+    if (int rc = ym_ensure_dyn_lds(attr, reinterpret_cast<const void*>(conv_igemm_pers<BM, BN, MODE, NS, DEFER, ALIGNED>), lds, "conv_igemm_pers")) return rc;
     hipLaunchKernelGGL((conv_igemm_pers<BM, BN, MODE, NS, DEFER, ALIGNED>), dim3(grid), dim3(256), lds, st, p);
     return ym_check_launch("conv_igemm_pers");
 }

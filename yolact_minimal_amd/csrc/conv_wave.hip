@@ -528,12 +528,8 @@ int launch(ConvP p, hipStream_t st) {
     p.ksplit = 1;
     const int grid = ym_cdiv(p.tiles_m * p.tiles_n, TPB);
     const size_t lds = (size_t)WPB * 32 * TM * (32 * TN + 4) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wave_f32<TM, TN, KW, WPB>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static YmLdsAttr attr = {};
+    if (int rc = ym_ensure_dyn_lds(attr, reinterpret_cast<const void*>(conv_wave_f32<TM, TN, KW, WPB>), lds, "conv_wave_f32")) return rc;
     hipLaunchKernelGGL((conv_wave_f32<TM, TN, KW, WPB>), dim3(grid), dim3(WPB * 64), lds, st, p);
     return ym_check_launch("conv_wave_f32");
 }
@@ -565,11 +561,8 @@ int launch_dma(ConvP p, hipStream_t st) {
         grid = p.main_tiles + (p.tiles_m * p.tiles_n - p.main_tiles) * p.tail_split;
     }
     const size_t lds = (size_t)WPB * NS * (32 * TM + 32 * TN) * 32 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wdma_f32<TM, TN, KW, NS, WPB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static YmLdsAttr attr = {};
+    if (int rc = ym_ensure_dyn_lds(attr, reinterpret_cast<const void*>(conv_wdma_f32<TM, TN, KW, NS, WPB>), lds, "conv_wdma_f32")) return rc;
     hipLaunchKernelGGL((conv_wdma_f32<TM, TN, KW, NS, WPB>), dim3(grid), dim3(WPB * 64), lds, st, p);
     return ym_check_launch("conv_wdma_f32");
 }

@@ -567,18 +567,19 @@ int wgrad_slabs(const ym_wgrad_desc* d, const WPlan& pl, void* workspace, size_t
     // 22: DMA, 32 pixels x ring of 2 (64 KB); 23: DMA, 16 pixels x ring of 3 (48 KB); 24: DMA, 16 pixels x ring of 4 (64 KB)
     const size_t lds = pl.nb == 22 ? (size_t)2 * 32 * (pl.tbn + 128) * 4 : pl.nb == 23 ? (size_t)2 * 3 * 16 * DP * 4
                      : pl.nb == 24 ? (size_t)2 * 4 * 16 * DP * 4 : (size_t)2 * pl.nb * TBM * LP * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        const int big = (int)((size_t)4 * TBM * LP * sizeof(float));
-#define YM_WG_ATTR(I, T, N) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_f32<I, T, N>), hipFuncAttributeMaxDynamicSharedMemorySize, big)
+    {
+        // every instantiation gets the same ceiling, once per device (ym_ensure_dyn_lds)
+        const size_t big = (size_t)4 * TBM * LP * sizeof(float);
+        static YmLdsAttr attrs[12] = {};
+        int ai = 0, rc = YM_OK;
+#define YM_WG_ATTR(I, T, N) if (!rc) rc = ym_ensure_dyn_lds(attrs[ai++], reinterpret_cast<const void*>(conv_wgrad_f32<I, T, N>), big, "conv_wgrad_f32")
         YM_WG_ATTR(0, 128, 2); YM_WG_ATTR(1, 128, 2); YM_WG_ATTR(0, 64, 2); YM_WG_ATTR(1, 64, 2);
         YM_WG_ATTR(0, 128, 1); YM_WG_ATTR(1, 128, 1); YM_WG_ATTR(0, 64, 1); YM_WG_ATTR(1, 64, 1);
 #undef YM_WG_ATTR
-#define YM_WG_ATTR_DL(N, T) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_dma<N, T>), hipFuncAttributeMaxDynamicSharedMemorySize, big)
-        YM_WG_ATTR_DL(2, 32); YM_WG_ATTR_DL(3, 16); YM_WG_ATTR_DL(4, 16);
+#define YM_WG_ATTR_DL(...) if (!rc) rc = ym_ensure_dyn_lds(attrs[ai++], reinterpret_cast<const void*>(conv_wgrad_dma<__VA_ARGS__>), big, "conv_wgrad_dma")
+        YM_WG_ATTR_DL(2, 32); YM_WG_ATTR_DL(3, 16); YM_WG_ATTR_DL(4, 16); YM_WG_ATTR_DL(2, 32, 64);
 #undef YM_WG_ATTR_DL
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_dma<2, 32, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-        attr_set = true;
+        if (rc) return rc;
     }
     // incremental coordinates need: (rows advanced per step) + 1 < 2 * Ho, so that two conditional wraps suffice
     p.incr = (TBM / d->Wo + 2 <= 2 * d->Ho) ? 1 : 0;

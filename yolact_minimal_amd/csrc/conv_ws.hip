@@ -243,11 +243,8 @@ __global__ __launch_bounds__(256) void conv1x1_ws(const ConvP p, int nslices, in
 
 template <int WM, int WN, int NSTG, bool RES>
 int launch_ws_r(const ConvP& p, int nslices, int mblocks, int gm, size_t lds, hipStream_t st) {
-    static size_t attr = 0;
-    if (lds > attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_ws<WM, WN, NSTG, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = lds;
-    }
+    static YmLdsAttr attr = {};
+    if (int rc = ym_ensure_dyn_lds(attr, reinterpret_cast<const void*>(conv1x1_ws<WM, WN, NSTG, RES>), lds, "conv1x1_ws")) return rc;
     hipLaunchKernelGGL((conv1x1_ws<WM, WN, NSTG, RES>), dim3(nslices * gm), dim3(256), lds, st, p, nslices, mblocks, gm);
     return ym_check_launch("conv1x1_ws");
 }

@@ -954,11 +954,8 @@ extern "C" int ym_detect_fast_nms_batch(const float* class_pred, const float* bo
     const FinalOut fo = {coef_pred, cfg->coef_dim, out_count, out_ids, out_scores, out_boxes, out_coefs};
 #define YM_FINAL(L_)                                                                                                              \
     do {                                                                                                                          \
-        static size_t set_ = 0;                                                                                                   \
-        if (merge_lds > set_) {                                                                                                   \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_final_select<L_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)merge_lds); \
-            set_ = merge_lds;                                                                                                     \
-        }                                                                                                                         \
+        static YmLdsAttr set_ = {};                                                                                               \
+        if (int rc_ = ym_ensure_dyn_lds(set_, reinterpret_cast<const void*>(k_final_select<L_>), merge_lds, "final_select")) return rc_; \
         hipLaunchKernelGGL(k_final_select<L_>, dim3(1, B), dim3(NT), merge_lds, st, w, ncls, cfg->max_det, fo, stride, cfg->num_anchors); \
     } while (0)
     if (lpl <= 1) YM_FINAL(1); else if (lpl == 2) YM_FINAL(2); else if (lpl == 3) YM_FINAL(3); else YM_FINAL(4);

@@ -160,11 +160,8 @@ extern "C" int ym_stem_conv_bn_relu_maxpool(const float* img_nchw, const float* 
     const int tiles_h = ym_cdiv(Hp, PH), tiles_w = ym_cdiv(Wp, PW);
     const long long grid = (long long)B * tiles_h * tiles_w;
     YM_REQUIRE(grid < (1ll << 31), "stem: grid too large");
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stem_pool), hipFuncAttributeMaxDynamicSharedMemorySize, (int)STEM_LDS);
-        attr_set = true;
-    }
+    static YmLdsAttr attr = {};
+    if (int rc = ym_ensure_dyn_lds(attr, reinterpret_cast<const void*>(k_stem_pool), STEM_LDS, "stem_conv_bn_relu_maxpool")) return rc;
     hipLaunchKernelGGL(k_stem_pool, dim3((unsigned)grid), dim3(256), STEM_LDS, (hipStream_t)s, img_nchw, w_packed, scale, shift, out,
                        H, W, Ho, Wo, Hp, Wp, tiles_w, tiles_h * tiles_w);
     return ym_check_launch("stem_conv_bn_relu_maxpool");

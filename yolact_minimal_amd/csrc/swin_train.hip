@@ -610,11 +610,8 @@ extern "C" int ym_swin_window_attention_bwd(const float* qkv, const float* qkv_b
     if (nblk > wgs_needed) nblk = wgs_needed;
     p.nblk = (int)nblk;
     const size_t lds = (size_t)4 * 4 * MAT * sizeof(float);          // 144 KB: one workgroup (4 waves) per CU
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_window_attention_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static YmLdsAttr attr = {};
+    if (int rc = ym_ensure_dyn_lds(attr, reinterpret_cast<const void*>(k_window_attention_bwd), lds, "window_attention_bwd")) return rc;
     hipLaunchKernelGGL(k_window_attention_bwd, dim3((int)(nblk * heads)), dim3(512), lds, (hipStream_t)s, p);
     return ym_check_launch("window_attention_bwd");
 }

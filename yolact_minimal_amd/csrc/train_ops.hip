@@ -514,11 +514,16 @@ __global__ __launch_bounds__(256) void k_pack_weights_batch(const ym_pack_item* 
 //   g = grad + wd * p ; buf = first ? g : mom * buf + g ; p -= lr * buf
 __global__ __launch_bounds__(256) void k_sgd(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
                                               size_t n, float lr, float mom, float wd, int first) {
+#pragma clang fp contract(off)          // (HIP's __fmul_rn / __fadd_rn are plain operators: only the pragma keeps the product and the sum apart)
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const float gg = g[i] + wd * p[i];
-        const float b = first ? gg : mom * buf[i] + gg;
+        // the roundings of torch.optim.SGD's own device kernels, so that the reference loop (train.py:61,130) and this launch give
+        // the same bits: grad.add(param, alpha=wd) and param.add_(buf, alpha=-lr) are one fused multiply-add each, while
+        // buf.mul_(momentum).add_(grad) rounds the product before the sum (tests/test_gpu_reference_loop.py)
+        const float gg = __builtin_fmaf(wd, p[i], g[i]);
+        const float mb = mom * buf[i];
+        const float b = first ? gg : mb + gg;
         buf[i] = b;
-        p[i] -= lr * b;
+        p[i] = __builtin_fmaf(-lr, b, p[i]);
     }
 }
 

@@ -29,6 +29,27 @@ static inline int ym_check_launch(const char* what) {
 
 static inline int ym_cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to ONE DEVICE's copy of a kernel: a process that drives a second GPU (nms_batch
+// and the request pipeline accept tensors on a non-current device) must raise it there as well.  One slot per (call site, device),
+// raised when a launch asks for more than was granted; a refusal is reported instead of surfacing as an opaque launch failure.
+struct YmLdsAttr { size_t granted[32]; };
+static inline int ym_ensure_dyn_lds(YmLdsAttr& a, const void* fn, size_t bytes, const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) {
+        ym_set_error("%s: no current HIP device (or device index >= 32)", what);
+        return YM_EINVAL;
+    }
+    if (bytes > a.granted[dev]) {
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) {
+            ym_set_error("%s: %zu bytes of dynamic LDS refused on device %d: %s", what, bytes, dev, hipGetErrorString(e));
+            return YM_EINVAL;
+        }
+        a.granted[dev] = bytes;
+    }
+    return YM_OK;
+}
+
 // Bijective XCD-aware remap (cdna guide T1): hardware places block b on XCD b % 8; give each XCD a
 // contiguous chunk of the logical tile space so neighbouring tiles share one L2.
 __device__ __forceinline__ int ym_xcd_remap(int bid, int nwg) {

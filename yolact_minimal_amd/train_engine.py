@@ -978,11 +978,31 @@ def _join_add(join):
     return add
 
 
+_drain_armed = [False]
+
+
+def _arm_drain_check():
+    """Every backward that parks a gradient ends with `check_links_drained()`, whoever called `.backward()`: a callback queued on the
+    running autograd engine (it fires when this backward's graph task has finished and raises out of `.backward()` /
+    `autograd.grad`).  A PARTIAL backward — `loss_s.backward()`, `torch.autograd.grad` of one loss term, one backward per loss —
+    never reaches the 'take' consumer of a tensor whose 'pass' consumers did run; without this the parked gradient was dropped in
+    silence outside `Trainer.step`.  For partial backward set YM_GRAD_JOIN=0 YM_FUSE_RES_GRAD=0 (autograd's own sums)."""
+    if _drain_armed[0]:
+        return
+    _drain_armed[0] = True
+
+    def _cb():
+        _drain_armed[0] = False
+        check_links_drained()
+    torch.autograd.Variable._execution_engine.queue_callback(_cb)
+
+
 def _join_result(join, role, dx):
     """'pass': park the running sum and return nothing to autograd; 'take' / no join: the gradient itself."""
     if join is not None and role == 'pass':
         join.grad = dx
         grad_join_passes[0] += 1
+        _arm_drain_check()
         return None
     return dx
 
@@ -1078,6 +1098,7 @@ class ConvBn(torch.autograd.Function):
         if ctx.link is not None:
             if ctx.role == 'give' and has_res:
                 ctx.link.grad, dres = dres, None                  # handed to the consumer that shares the tensor
+                _arm_drain_check()
             elif ctx.role == 'take' and need_dx:
                 add, ctx.link.grad = ctx.link.grad, None
         if need_dx and ctx.xjoin is not None:
@@ -1172,6 +1193,7 @@ def train_features(net, img):
     hip.nchw_to_nhwc4(img.contiguous().float(), x)
     _stats_pool.begin(img.device)
     _live_links.clear()                                          # (links of a forward whose backward never ran)
+    _drain_armed[0] = False                                      # (a backward that died before its callbacks ran)
     bb = net.backbone
     if hasattr(bb, 'patch_embed'):                                # Swin-T (modules/swin_transformer.py)
         from .swin_train import swin_backbone_train
