@@ -218,11 +218,11 @@ def post_bench(net, cfg, device, img_size, iters=30):
     return out
 
 
-def chained_bench(cfg_name, img_size, device, inflight, steps=100):
-    """eval.py:45-52 as ONE chain: `nms` / `after_nms` consume the forward's OWN outputs.  A random-init network gives degenerate
-    detections, so the shared conf layer is reshaped like oracle/make_golden_chained.py does (weight x 10, bias = minus the spatial
-    mean of every (anchor, class) logit + N(0, 1) + a background offset found by bisection for ~400 candidates over the score
-    threshold); the golden test of that recipe is tests/test_gpu_pipeline.py::test_chained_forward_nms_after_nms_matches_the_reference."""
+def detecting_net(cfg_name, img_size, device):
+    """A random-init network gives degenerate detections, so the shared conf layer is reshaped like oracle/make_golden_chained.py
+    does (weight x 10, bias = minus the spatial mean of every (anchor, class) logit + N(0, 1) + a background offset found by
+    bisection for ~400 candidates over the score threshold); the golden test of that recipe is
+    tests/test_gpu_pipeline.py::test_chained_forward_nms_after_nms_matches_the_reference.  Returns (net, cfg, img)."""
     net, cfg = build_net(cfg_name, img_size, device, seed=71)
     conv = net.prediction_layers.conf_layer
     with torch.no_grad():
@@ -247,6 +247,12 @@ def chained_bench(cfg_name, img_size, device, inflight, steps=100):
         conv.bias.copy_(nb.reshape(-1).float())
     net.mark_weights_changed()
     net._engines.clear()
+    return net, cfg, img
+
+
+def chained_bench(cfg_name, img_size, device, inflight, steps=100):
+    """eval.py:45-52 as ONE chain: `nms` / `after_nms` consume the forward's OWN outputs (network: `detecting_net`)."""
+    net, cfg, img = detecting_net(cfg_name, img_size, device)
     out = {}
     for s_ in sorted({1, inflight}):
         w = Workload(net, cfg, 1, img_size, device, with_post=True, inflight=s_, chained=True)
@@ -258,6 +264,136 @@ def chained_bench(cfg_name, img_size, device, inflight, steps=100):
     out['workload'] = 'forward + nms + after_nms(480x640) on the forward\'s own outputs (~400 candidates over the score threshold)'
     net._engines.clear()
     return out
+
+
+def _dropin_loops():
+    """dropin/reference_loops.py (the statements of the reference's train.py / eval.py), imported the way dropin/run.py binds them."""
+    for q in (os.path.join(REPO, 'dropin'),):
+        if q not in sys.path:
+            sys.path.insert(0, q)
+    import reference_loops
+    return reference_loops
+
+
+def eval_loop_bench(cfg_name, img_size, device, images=40, h=480, w=640):
+    """The reference-shaped evaluation loop (eval.py:36-69 through `dropin/`: forward -> nms -> after_nms -> metric, ONE image at a
+    time, every stage fenced by a device synchronize as `utils.timer.counter` does) on `detecting_net`, 15 synthetic ground-truth
+    instances per image.  Three metric branches: `prep_metrics` (eval.py:69, tensors stay on the device: the default), `--coco_api`
+    as the reference writes it (eval.py:60-67: boxes + the DENSE fp32 masks cross PCIe, then one `add_mask` per detection), and the
+    same records with device-side RLE (`coco_api='device'`: no dense D2H).  `value` of the headline line is NOT this loop: it
+    keeps 4 requests in flight and no host read of masks."""
+    from yolact_minimal_amd.utils.synthetic import synth_eval_case
+    L = _dropin_loops()
+    net, cfg, img = detecting_net(cfg_name, img_size, device)
+    _, _, _, _, gt, gt_masks, _, _ = synth_eval_case(1, 40, 15, h, w, 10)
+    gt, gt_masks = gt.to(device), gt_masks.to(device)
+    out = dict(workload=f'{cfg_name} {img_size}x{img_size}, one image at a time, after_nms at {h}x{w}, 15 gt instances per image; inputs '
+                        f'resident in HBM (img.cuda() is a no-op), statements of eval.py:36-69')
+
+    def loader(n):
+        return [(img, gt.clone(), gt_masks, h, w) for _ in range(n)]
+    for key, kw, n in (('prep_metrics', dict(coco_api=False), images), ('prep_metrics_no_stage_fences', dict(coco_api=False, sync_stages=False), images),
+                       ('coco_api_dense_masks_over_pcie', dict(coco_api=True), max(4, images // 5)), ('coco_api_device_rle', dict(coco_api='device'), images)):
+        L.eval_loop(net, cfg, loader(3), **kw)                        # warm-up (plans, graph capture, allocator)
+        _, mj, seen, secs = L.eval_loop(net, cfg, loader(n), **kw)
+        row = dict(img_s=round(n / secs, 1), ms_per_img=round(secs / n * 1e3, 3), images=n, images_with_detections=seen)
+        if kw.get('sync_stages', True):
+            t = L.timer.get_times(['forward', 'nms', 'after_nms', 'metric'])
+            row['stage_ms'] = dict(forward=round(t[0] * 1e3, 3), nms=round(t[1] * 1e3, 3), after_nms=round(t[2] * 1e3, 3), metric=round(t[3] * 1e3, 3))
+        if mj is not None:
+            row['records_per_image'] = round(len(mj.mask_data) / max(1, n), 1)
+        out[key] = row
+    # what bounds the dense branch: the D2H of the image's masks (pageable destination, as `.cpu()` allocates it)
+    n_det = out['coco_api_dense_masks_over_pcie'].get('records_per_image') or 100
+    m = torch.zeros(int(round(n_det)), h, w, device=device)
+    m.cpu()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        m.cpu()
+    t_d2h = (time.perf_counter() - t0) / 5
+    out['dense_mask_d2h'] = dict(mb_per_image=round(m.numel() * 4 / 1e6, 1), ms=round(t_d2h * 1e3, 3), gb_s=round(m.numel() * 4 / t_d2h / 1e9, 2),
+                                 note='`masks_p.cpu()` of eval.py:62 alone (pageable host memory): the floor of the dense --coco_api branch')
+    out['bounds'] = ('prep_metrics: host-side stage fences + python around ~2.5 ms of device work per image; coco_api dense: PCIe D2H of '
+                     'n x H x W fp32 masks, then one RLE call per mask; coco_api device RLE: one ym_rle_encode launch + a few KB D2H per image')
+    net._engines.clear()
+    return out
+
+
+def train_reference_loop_bench(cfg_name, img_size, batch, steps, warmup, local_rank, device):
+    """The reference's OWN training step on the HIP path (train.py:60-63,76,102-130 through `dropin/`): `optim.SGD(net.parameters())`
+    (AdamW for swin_tiny_coco), `DDP(net.cuda(), [local_rank], output_device=local_rank, broadcast_buffers=True)` on a one-rank RCCL
+    group, `net(images, targets, masks)`, `dist.all_reduce(all_loss)`, `zero_grad()`, `loss_total.backward()`, `optimizer.step()` —
+    not the build's `Trainer` (`extra.train`).  Same synthetic batch as `train_bench`; bit-identical results to `Trainer.step` are
+    tests/test_gpu_reference_loop.py's business.  What it lacks against `Trainer`: gradients land in fresh tensors that DDP copies
+    into its buckets (no flat buffer), weight gradients stay on the main stream (their side stream needs the flat slots), one
+    foreach-SGD kernel group instead of one launch."""
+    import torch.distributed as dist
+    from yolact_minimal_amd.utils.synthetic import synth_targets
+    from yolact_minimal_amd.config import build_cfg
+    from yolact_minimal_amd.modules.yolact import Yolact
+    L = _dropin_loops()
+    own_group = not dist.is_initialized()
+    if own_group:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group(backend='nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1)
+    try:
+        cfg = build_cfg(cfg_name, 'train', img_size, train_bs=batch, bs_per_gpu=batch)
+        torch.manual_seed(0)
+        net = Yolact(cfg)
+        net.train()
+        optimizer = L.make_optimizer(net, cfg)
+        net = L.wrap_ddp(net, local_rank)
+        g = torch.Generator().manual_seed(100)
+        img = torch.randn(batch, 3, img_size, img_size, generator=g)
+        boxes, masks = synth_targets(batch, img_size, seed=0)
+        res, stages = {}, {}
+        last = []
+        for key, to_dev in (('inputs_resident', True), ('inputs_from_host', False)):
+            im = img.to(device) if to_dev else img
+            bx = [b.to(device) if to_dev else b for b in boxes]
+            mk = [m.to(device) if to_dev else m for m in masks]
+
+            def loader(n):
+                return ((im, [b.clone() for b in bx], mk) for _ in range(n))
+            marks = []
+
+            def keep(step, losses, lr):          # (no host read per step)
+                last[:] = [losses]
+                marks.append(time.perf_counter())
+            # ONE call of the loop, like train.py: its timer starts at the second iteration, and from then on every phase of a step
+            # is fenced by `timer.counter`'s device synchronizes (utils/timer.py:63-76) -- the published loop never overlaps phases
+            L.train_loop(net, optimizer, cfg, loader(warmup + steps), max_steps=warmup + steps, on_step=keep)
+            torch.cuda.synchronize()
+            res[key] = (time.perf_counter() - marks[warmup - 1]) / steps
+            stages[key] = [round(v * 1e3, 2) for v in L.timer.get_times(['for+loss', 'backward', 'update'])]
+        # the same loop with the timer left stopped (no fences): what the loop could do if it did not time its phases
+        marks = []
+        L.train_loop(net, optimizer, cfg, ((img.to(device), [b.to(device) for b in boxes], [m.to(device) for m in masks]) for _ in range(warmup + steps)),
+                     max_steps=warmup + steps, on_step=lambda *a: marks.append(time.perf_counter()), fences=False)
+        torch.cuda.synchronize()
+        t_nofence = (time.perf_counter() - marks[warmup - 1]) / steps
+        t = res['inputs_resident']
+        flops_img = 3.0 * {'res101': 157.2e9, 'res50_': 113.4e9, 'swin_t': 119.2e9}.get(cfg_name[:6], 157.2e9)
+        losses = last[0]
+        return dict(img_s=round(batch / t, 2), ms_per_step=round(t * 1e3, 2), steps=steps, warmup=warmup, batch_per_gpu=batch,
+                    optimizer=type(optimizer).__name__, wrapper=type(net).__name__, world_size=dist.get_world_size(), backend=dist.get_backend(),
+                    frac_f32_mfma_peak=round(batch / t * flops_img / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                    stage_ms=dict(zip(('for+loss', 'backward', 'update'), stages['inputs_resident'])),
+                    without_timer_fences=dict(img_s=round(batch / t_nofence, 2), ms_per_step=round(t_nofence * 1e3, 2)),
+                    module_train_state=getattr(net.module, '_train_state', None) is not None,
+                    inputs_from_host=dict(img_s=round(batch / res['inputs_from_host'], 2), ms_per_step=round(res['inputs_from_host'] * 1e3, 2),
+                                          note='CPU tensors handed to train.py:112-114 (`images.cuda()`: pageable H2D of images + masks inside the step)'),
+                    last_losses=[round(float(l.detach()), 4) for l in losses], finite=all(bool(torch.isfinite(l)) for l in losses),
+                    note='train.py\'s own statements (torch DDP + torch.optim, phases fenced by its timer) on the HIP autograd path; the module brings '
+                         'its own flat gradient slots / side stream / reducer (train_state.py; round 5, without them: 72.3 ms per step). '
+                         '`extra.train` is the build\'s Trainer')
+    finally:
+        if own_group:
+            dist.destroy_process_group()
 
 
 def eval_metrics_bench(device, n=100, g=15, h=480, w=640, iters=20, cpu=True):
@@ -706,10 +842,21 @@ def main():
                 w2.engine.set_mma(0)
             extra['split_bf16'] = split
             extra['eval_metrics'] = eval_metrics_bench(device, cpu=not args.no_cpu_baseline)
+            if args.batch == 1 and not args.no_post:
+                try:
+                    extra['eval_loop'] = eval_loop_bench(args.cfg, args.img_size, device)
+                except Exception as e:
+                    extra['eval_loop'] = dict(error=f'{type(e).__name__}: {e}'[:400])
             extra['train_aug'] = train_aug_bench(device, cpu=not args.no_cpu_baseline)
             extra['ann_to_mask'] = ann_to_mask_bench(device, cpu=not args.no_cpu_baseline)
             if not args.no_train and args.cfg != 'swin_tiny_coco':
                 net._engines.clear()
+                torch.cuda.empty_cache()
+                try:
+                    extra['train_reference_loop'] = train_reference_loop_bench(args.cfg, args.img_size, args.train_batch, args.train_steps, 2,
+                                                                               local_rank, device)
+                except Exception as e:
+                    extra['train_reference_loop'] = dict(error=f'{type(e).__name__}: {e}'[:400])
                 torch.cuda.empty_cache()
                 extra['train_swin_tiny_coco'] = train_bench('swin_tiny_coco', args.img_size, args.train_batch, args.train_steps, 2, 1,
                                                             local_rank, device, lambda: None)

@@ -17,6 +17,7 @@ from torch.nn.parallel import DistributedDataParallel as DDP
 from utils import timer                                                       # noqa: E402  (dropin/)
 from utils.output_utils import after_nms, nms                                 # noqa: E402
 from utils.common_utils import APDataObject, MakeJson, prep_metrics, calc_map  # noqa: E402
+from yolact_minimal_amd.utils.common_utils import rle_encode                 # noqa: E402  (coco_api='device' only)
 
 
 def make_optimizer(net, cfg):
@@ -35,11 +36,17 @@ def wrap_ddp(net, local_rank):
     return DDP(net.cuda(), [local_rank], output_device=local_rank, broadcast_buffers=True)
 
 
-def train_loop(net, optimizer, cfg, data_loader, start_step=0, max_steps=None, on_step=None, val_interval=-1, evaluate=None):
-    """train.py:102-130 (+ :162-168 when `val_interval` > 0): `net` is what train.py:76 left in `net` (the DDP wrapper when
+def train_loop(net, optimizer, cfg, data_loader, start_step=0, max_steps=None, on_step=None, val_interval=-1, evaluate=None,
+               fences=True):
+    """train.py:88-90,102-136 (+ :162-177 when `val_interval` > 0): `net` is what train.py:76 left in `net` (the DDP wrapper when
     cfg.cuda).  Returns the per-step loss 4-tuples as python floats (one host read per step, as train.py:147-150 does every
-    tenth step) and the step counter."""
+    tenth step) and the step counter.
+
+    `fences`: the reference starts its timer at the second iteration (train.py:176-177: `step == val_step + 1`), and from then on
+    every `timer.counter` block synchronizes the device on entry and exit (utils/timer.py:63-76) — the loop as published never has
+    two phases of a step in flight at once.  False leaves the timer stopped for the whole run (the fences are the only difference)."""
     step, history = start_step, []
+    val_step = start_step
     timer.reset()
     for images, targets, masks in data_loader:
         if cfg.warmup_until > 0 and step <= cfg.warmup_until:  # warm up learning rate.
@@ -76,11 +83,21 @@ def train_loop(net, optimizer, cfg, data_loader, start_step=0, max_steps=None, o
         else:
             history.append([float(l.detach()) for l in (loss_c, loss_b, loss_m, loss_s)])
 
+        time_this = time.time()
+        if step > start_step:
+            batch_time = time_this - time_last
+            timer.add_batch_time(batch_time)
+        time_last = time_this
+
         if val_interval > 0 and step % val_interval == 0 and step != start_step and evaluate is not None:
+            val_step = step
             net.eval()
             evaluate(net.module if cfg.cuda else net, cfg, step)
             net.train()
-            timer.reset()
+            timer.reset()  # training timer and val timer share the same Obj, so reset it to avoid conflict
+
+        if fences and step == val_step + 1:
+            timer.start()  # the first iteration after validation should not be included
 
         step += 1
         if max_steps is not None and step - start_step >= max_steps:
@@ -93,7 +110,8 @@ IOU_THRES = [x / 100 for x in range(50, 100, 5)]                              # 
 
 def eval_loop(net, cfg, data_loader, image_ids=None, coco_api=False, make_json=None, sync_stages=True):
     """eval.py:35-69 for every `(img, gt, gt_masks, img_h, img_w)` of `data_loader`, one image at a time.  `coco_api`: the
-    `--coco_api` branch (eval.py:60-67: boxes and the dense fp32 masks cross PCIe, `MakeJson.add_bbox/add_mask`); otherwise
+    `--coco_api` branch (eval.py:60-67: boxes and the dense fp32 masks cross PCIe, `MakeJson.add_bbox/add_mask`; 'device' = the
+    same records with the RLE strings made on the GPU); otherwise
     `prep_metrics` on the device tensors (eval.py:69).  `sync_stages`: the reference's `timer.counter` fences every stage with a
     device synchronize (utils/timer.py:63-76); False leaves the fences out (the loop is otherwise unchanged).
     Returns (ap_data, make_json, images with detections, seconds)."""
@@ -126,7 +144,17 @@ def eval_loop(net, cfg, data_loader, image_ids=None, coco_api=False, make_json=N
             ids_p = list(ids_p.cpu().numpy().astype(int))
             class_p = list(class_p.cpu().numpy().astype(float))
 
-            if coco_api:
+            if coco_api == 'device':
+                # the build's variant of the same branch: RLE strings are made on the GPU for the image's masks at once
+                # (`ym_rle_encode`), so a few hundred bytes per mask cross PCIe instead of img_h * img_w * 4
+                boxes_p = boxes_p.cpu().numpy()
+                rles = rle_encode(masks_p)
+                for j in range(len(rles)):
+                    if (boxes_p[j, 3] - boxes_p[j, 1]) * (boxes_p[j, 2] - boxes_p[j, 0]) > 0:
+                        image_id = image_ids[i] if image_ids is not None else i
+                        make_json.add_bbox(image_id, ids_p[j], boxes_p[j, :], class_p[j])
+                        make_json.add_mask(image_id, ids_p[j], rles[j], class_p[j])
+            elif coco_api:
                 boxes_p = boxes_p.cpu().numpy()
                 masks_p = masks_p.cpu().numpy()
 

@@ -98,6 +98,7 @@ def main():
     data_loader = [(img, [b.clone() for b in boxes], [m.clone() for m in masks]) for _ in range(steps)]      # CPU tensors, like train_collate
 
     # ---- A. the reference's loop: torch optimizer + torch DDP around the module -------------------------------------------------
+    os.environ['YM_FORCE_DIST'] = '1'                        # one rank: the module's own gradient reducer still takes part (train_state.py)
     net = build()
     p0 = {k: v.detach().clone() for k, v in net.named_parameters()}
     optimizer = L.make_optimizer(net, cfg)                   # train.py:60-65
@@ -127,7 +128,6 @@ def main():
 
     # ---- B. the build's own Trainer on the same seed / inputs -------------------------------------------------------------------
     from yolact_minimal_amd.trainer import Trainer
-    os.environ['YM_FORCE_DIST'] = '1'                        # one-rank RCCL group: FlatGradReducer takes part
     net_b = build()
     tr = Trainer(net_b, cfg, torch.device('cuda', args.local_rank), world=1, local_rank=args.local_rank)
     img_d, boxes_d, masks_d = img.cuda(), [b.cuda() for b in boxes], [m.cuda() for m in masks]

@@ -174,3 +174,71 @@ def test_ddp_block_reports_what_the_scaling_record_needs():
     assert blk['allreduce_exposed_ms'] == 1.25 and blk['buffer_broadcast_ms'] == 0.05 and blk['world_size_seen'] == 1
     ref = blk['vs_1gpu_reference_img_s']
     assert ref is None or (ref > 0 and abs(blk['scaling_vs_1gpu'] - round(1400.0 / ref, 3)) < 1e-9 and blk['reference_source'].startswith('profiles/'))
+
+
+def _worker8(rank, world, port, q):
+    """One of 8 gloo ranks: res101_coco's REAL parameter list (50 M floats -> the trainer's 8 gradient buckets), gradient hooks firing
+    in a DIFFERENT order on every rank, rank 0 late for the second step (train.py:162-174: only the main rank runs `evaluate` at
+    val_interval while the others walk into the next step's collectives)."""
+    import time
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from yolact_minimal_amd import trainer
+    from yolact_minimal_amd.config import build_cfg
+    from yolact_minimal_amd.modules.yolact import Yolact
+    trainer.init_distributed(backend='gloo')
+    assert dist.get_world_size() == 8
+    torch.manual_seed(100 + rank)                                    # different initial weights per rank
+    net = Yolact(build_cfg('res101_coco', 'train', 544, train_bs=64, bs_per_gpu=8))
+    opt = trainer.FlatSGD(net.parameters(), lr=1e-3)
+    dist.broadcast(opt.flat, 0)                                      # what Trainer.__init__ does
+    flat_buffers = trainer.flatten_buffers(net)
+    red = trainer.FlatGradReducer(opt, world)                        # default 25 MB buckets
+    sizes = [round((e - a) * 4 / 2 ** 20, 1) for a, e, _ in red.buckets]
+    assert len(red.buckets) == 8 and min(sizes[:-1]) >= 25 and sum(len(b[2]) for b in red.buckets) == len(opt.params), sizes      # (the tail: stem + layer1, 4 MB)
+    n = len(opt.params)
+    coef = lambda r, i, step: float(((r + 1) * 37 + i * 11 + step * 5) % 23) / 7.0 - 1.0      # noqa: E731  d(loss)/d(p_i) on rank r
+    for step in range(2):
+        if step == 1 and rank == 0:
+            time.sleep(2.0)                                          # rank 0 is still in `evaluate`; the others are already here
+        dist.broadcast(flat_buffers, 0)                              # Trainer.step: BN running statistics follow rank 0
+        opt.zero_grad()
+        # every rank builds its loss terms in its own order, so AccumulateGrad (and the reducer's hooks) fire in a different order on
+        # every rank; the bucket collectives must still be issued in the same order everywhere
+        order = torch.randperm(n, generator=torch.Generator().manual_seed(1000 * step + rank)).tolist()
+        loss = sum(opt.params[i].sum() * coef(rank, i, step) for i in order)
+        all_loss = torch.stack([loss.detach()] * 4)
+        dist.all_reduce(all_loss)                                    # the 16-byte logging collective sits between forward and backward
+        loss.backward()
+        red.finish()
+        log = red.last_launch_log
+        assert [b for b, _, _ in log] == list(range(8)), log         # bucket order, whatever order the hooks came in
+        for i in (0, 1, n // 3, n // 2, n - 2, n - 1):               # averaged gradient of a few parameters, exactly
+            want = sum(coef(r, i, step) for r in range(world)) / world
+            got = opt.params[i]._ym_grad_slot
+            assert abs(float(got.reshape(-1)[0]) - want) < 1e-6 and abs(float(got.reshape(-1)[-1]) - want) < 1e-6, (i, want)
+        with torch.no_grad():                                        # (the HIP optimizer launch has no CPU path: a plain SGD update)
+            opt.flat.add_(opt.grad, alpha=-1e-3)
+    digest = torch.stack([opt.flat.double().sum(), opt.flat.double().abs().sum(), flat_buffers.double().sum()])
+    gathered = [torch.zeros_like(digest) for _ in range(world)]
+    dist.all_gather(gathered, digest)
+    assert all(torch.equal(gathered[0], g) for g in gathered)        # replicas identical after two steps
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, sizes))
+
+
+def test_eight_rank_gloo_reducer_with_res101_bucket_layout():
+    """The first 8-GPU run's host logic, without the hardware: 8 processes, res101's real 200 MB / 8-bucket gradient layout, uneven
+    hook order per rank, a late rank 0 — no dead-lock, bucket order identical on every rank, exact averages, identical replicas."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    got = [q.get(timeout=5) for _ in range(8)]
+    assert sorted(r for r, _ in got) == list(range(8)) and len({tuple(s) for _, s in got}) == 1

@@ -132,3 +132,19 @@ def test_partial_backward_fails_loudly_instead_of_dropping_gradients():
         losses = net(img, [b.cuda() for b in boxes], [m.cuda() for m in masks])
         sum(losses).backward()
         assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+@pytest.mark.parametrize('cfg_name', ['res50_coco', 'swin_tiny_coco'])
+def test_reference_loop_two_ranks_keep_replicas_identical(cfg_name):
+    """The reference's loop with TWO real ranks (torch.distributed.run, gloo so that both may share this box's GPU): torch's DDP
+    wraps the module, which reduces its own gradients and broadcasts its own buffers (train_state.py; DDP is told to ignore them).
+    Different shards and different initial seeds per rank -> after 3 steps both ranks hold bit-identical parameters, optimizer state
+    and BatchNorm statistics (weights broadcast from rank 0 at the first forward, gradients averaged bucket by bucket, running
+    statistics following rank 0)."""
+    env = dict(os.environ, YM_DIST_BACKEND='gloo', YM_CHECK_CFG=cfg_name, YM_CHECK_LOOP='reference', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29553', os.path.join(REPO, 'tools', 'ddp_check.py')]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    line = [l for l in out.stdout.splitlines() if l.startswith('DDP_CHECK')][-1]
+    assert ' OK ' in line and 'world 2' in line and 'reference loop' in line, line

@@ -1133,6 +1133,22 @@ def test_two_rank_training_keeps_replicas_identical(cfg_name):
     assert ' OK ' in line and 'world 2' in line, line
 
 
+def test_eight_ranks_with_rank0_validating_mid_run_neither_dead_lock_nor_diverge():
+    """The 8-GPU job's control flow on one GPU (8 gloo ranks share it): different shards and seeds per rank, and after step 1 rank 0
+    alone runs an eval forward and stays away for 3 s (`evaluate` at val_interval, train.py:162-174) while ranks 1-7 enter the next
+    step's collectives — the run completes and all 8 replicas hold bit-identical parameters and momentum."""
+    import subprocess
+    import sys
+    from tests.conftest import REPO
+    env = dict(os.environ, YM_DIST_BACKEND='gloo', YM_CHECK_CFG='res50_coco', YM_CHECK_VAL_AT='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
+           '--master-port', '29549', os.path.join(REPO, 'tools', 'ddp_check.py')]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    line = [l for l in out.stdout.splitlines() if l.startswith('DDP_CHECK')][-1]
+    assert ' OK ' in line and 'world 8' in line, line
+
+
 def test_gradient_buckets_are_reduced_while_backward_is_still_running():
     """res101_coco at 256 px under torch.distributed.run with backend nccl (= RCCL; one rank, the only RCCL configuration a 1-GPU
     box allows): the 200 MB of gradients form >= 3 buckets, and every bucket but the last is handed to `all_reduce(async_op=True)`
@@ -1157,6 +1173,31 @@ def test_gradient_buckets_are_reduced_while_backward_is_still_running():
     in_backward = [e for e in log if not e[2]]
     assert len(in_backward) >= rec['buckets'] - 1, log                        # at most the last bucket waits for finish()
     assert log[0][1] < 0.5 * rec['params'], log                               # first message leaves with most of backward ahead
+
+
+def test_bench_eight_ranks_control_flow():
+    """`python bench.py --gpus 8` as the driver's full-node run issues it, with 8 gloo ranks sharing this box's GPU (small images):
+    ONE JSON line, `extra.ddp.world_size_seen == 8`, the 8-rank training leg and BASELINE config 4's bs=16-per-GPU leg
+    (`extra.train_bs16_per_gpu_ddp8`, which only a world of 8 walks)."""
+    import json
+    import subprocess
+    import sys
+    from tests.conftest import REPO
+    env = dict(os.environ, YM_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
+    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '8', '--steps', '3', '--warmup', '1', '--cfg', 'res50_coco',
+           '--img_size', '128', '--train-batch', '2', '--train-steps', '2', '--lean']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['value'] > 0 and d['config']['global_batch'] == 8
+    ddp = d['extra']['ddp']
+    assert ddp['world_size_seen'] == 8 and ddp['backend'] == 'gloo' and abs(ddp['per_gpu'] * 8 - ddp['train_img_s']) < 0.05
+    assert d['extra']['train']['global_batch'] == 16 and d['extra']['train']['finite']
+    t16 = d['extra']['train_bs16_per_gpu_ddp8']
+    assert t16['batch_per_gpu'] == 16 and t16['global_batch'] == 128 and t16['finite'] and t16['ddp']['world_size_seen'] == 8
 
 
 def test_bench_two_ranks_control_flow():

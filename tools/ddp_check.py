@@ -24,6 +24,8 @@ def main():
     size = int(os.environ.get('YM_CHECK_SIZE', '128'))
     cfg = build_cfg(name, 'train', size, train_bs=2 * world, bs_per_gpu=2)
     torch.manual_seed(100 + rank)                       # DIFFERENT initial weights per rank: the trainer must broadcast rank 0's
+    if os.environ.get('YM_CHECK_LOOP', 'trainer') == 'reference':
+        return reference_loop(cfg, dev, rank, world, local_rank % ndev, size)
     tr = Trainer(Yolact(cfg), cfg, dev, world, local_rank % ndev)
     for blk in (b for l in getattr(tr.net.backbone, 'layers', []) for b in getattr(l, 'blocks', [])):
         blk.drop_prob = 0.0                             # (Swin) DropPath masks are per-rank random numbers
@@ -31,8 +33,20 @@ def main():
     boxes, masks = synth_targets(2, size, seed=50 + 10 * rank)
     boxes, masks = [b.to(dev) for b in boxes], [m.to(dev) for m in masks]
     losses = None
-    for _ in range(3):
+    val_at = int(os.environ.get('YM_CHECK_VAL_AT', '-1'))
+    for step in range(3):
         losses = tr.step(img, boxes, masks)
+        if step == val_at and rank == 0:
+            # train.py:162-174: only the main rank validates (`net.eval(); evaluate(net.module, ...); net.train()`) while the other ranks
+            # go on into the next step, whose first collective (the buffer broadcast from rank 0) is where they wait for it
+            import time
+            tr.net.eval()
+            with torch.no_grad():
+                out = tr.module(img[:1])
+            torch.cuda.synchronize()
+            assert all(bool(torch.isfinite(o).all()) for o in out)
+            time.sleep(float(os.environ.get('YM_CHECK_VAL_SLEEP', '3')))
+            tr.net.train()
     torch.cuda.synchronize()
     digest = torch.stack([tr.opt.flat.double().sum(), tr.opt.flat.double().abs().sum(), tr.opt.buf.double().abs().sum(),
                           tr.opt.flat[::997].double().pow(2).sum()])
@@ -52,6 +66,49 @@ def main():
             import json
             print('DDP_LAUNCH_LOG', json.dumps(dict(params=len(tr.opt.params), buckets=len(tr.reducer.buckets), backend=dist.get_backend(),
                                                     log=tr.reducer.last_launch_log)))
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+def reference_loop(cfg, dev, rank, world, local_rank, size):
+    """The same check through the reference's own statements (train.py:60-63,76,102-130 = dropin/reference_loops.py): torch DDP around
+    the module + torch.optim, i.e. the module's own gradient reducer / buffer broadcast (train_state.py) instead of `Trainer`."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'dropin'))
+    import reference_loops as L
+    net = Yolact(cfg)
+    net.train()
+    for blk in (b for l in getattr(net.backbone, 'layers', []) for b in getattr(l, 'blocks', [])):
+        blk.drop_prob = 0.0
+    optimizer = L.make_optimizer(net, cfg)
+    cfg.cuda = True
+    net = L.wrap_ddp(net, local_rank)
+    img = torch.randn(2, 3, size, size, generator=torch.Generator().manual_seed(7 + rank))
+    boxes, masks = synth_targets(2, size, seed=50 + 10 * rank)
+    hist = []
+    L.train_loop(net, optimizer, cfg, [(img, [b.clone() for b in boxes], masks) for _ in range(3)], max_steps=3,
+                 on_step=lambda step, losses, lr: hist.append([float(l.detach()) for l in losses]))
+    torch.cuda.synchronize()
+    st = net.module._train_state
+    flat = torch.cat([p.detach().reshape(-1) for p in net.module.parameters()])
+    mom = torch.cat([optimizer.state[p]['momentum_buffer'].reshape(-1) if 'momentum_buffer' in optimizer.state[p] else
+                     optimizer.state[p]['exp_avg'].reshape(-1) for p in net.module.parameters()])
+    # (the running statistics were last updated from each rank's OWN batch; the next train-mode forward starts by broadcasting rank 0's,
+    #  DDP(broadcast_buffers=True) -- do that part of it here, then they must agree)
+    st.sync_before_forward(True)
+    bufs = torch.cat([b.detach().double().reshape(-1) for b in net.module.buffers()])
+    digest = torch.stack([flat.double().sum(), flat.double().abs().sum(), mom.double().abs().sum(), bufs.sum()])
+    if dist.get_backend() != 'nccl':
+        digest = digest.cpu()
+    gathered = [torch.zeros_like(digest) for _ in range(world)]
+    dist.all_gather(gathered, digest)
+    gathered = [g.cpu() for g in gathered]
+    ok = all(torch.equal(gathered[0], g) for g in gathered) and all(all(v == v for v in h) for h in hist)
+    ok = ok and st is not None and (st.reducer is not None) == (world > 1 or os.environ.get('YM_FORCE_DIST', '0') == '1')
+    if rank == 0:
+        print('DDP_CHECK', 'OK' if ok else 'MISMATCH', 'world', world, 'reference loop; module reducer launches',
+              st.reducer.launches if st and st.reducer else None, 'buckets', len(st.reducer.buckets) if st and st.reducer else None,
+              [g.tolist() for g in gathered])
     dist.barrier()
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)

@@ -109,6 +109,27 @@ class Yolact(nn.Module):
 
         self._engines = {}
         self._weights_epoch = 0
+        self._train_state = None          # train_state.ModuleTrainState, created at the first train-mode forward on the GPU
+        self._ddp_wrapped = False
+
+    # ---- torch.nn.parallel.DistributedDataParallel around this module (reference train.py:76) ------------------------------------
+    @property
+    def _ddp_params_and_buffers_to_ignore(self):
+        """The attribute torch's DDP constructor reads to learn which tensors of a module it must NOT manage.  This module reduces
+        its own gradients (flat buffer, >= 25 MB buckets all-reduced on the RCCL stream during backward) and broadcasts its own
+        BatchNorm statistics (one message): `train_state.ModuleTrainState`.  Reading the attribute is also how the module learns that
+        it has been wrapped — without a wrapper it never touches a process group.  With YM_AUTO_FLAT=0 the attribute does not exist
+        and torch's DDP manages everything itself."""
+        from ..train_state import AUTO, DDP_KEEPS
+        if not AUTO or self.cfg.mode != 'train':
+            raise AttributeError('_ddp_params_and_buffers_to_ignore')
+        self._ddp_wrapped = True
+        return [n for n, _ in self.named_parameters() if n != DDP_KEEPS] + [n for n, _ in self.named_buffers()]
+
+    def _drop_train_state(self):
+        if self._train_state is not None:
+            self._train_state.release()
+            self._train_state = None
 
     # ---- weights -----------------------------------------------------------------------------
     def mark_weights_changed(self):
@@ -121,6 +142,8 @@ class Yolact(nn.Module):
         return out
 
     def _apply(self, fn, *args, **kwargs):
+        if getattr(self, '_train_state', None) is not None:
+            self._drop_train_state()             # parameters and buffers are about to be re-allocated
         out = super()._apply(fn, *args, **kwargs)
         if hasattr(self, '_engines'):
             self._engines.clear()
@@ -136,6 +159,21 @@ class Yolact(nn.Module):
         self.load_state_dict(state_dict, strict=True)
         print(f'Model loaded with {weight}.\n')
         print(f'Number of all parameters: {sum(p.numel() for p in self.parameters())}\n')
+
+    def _own_train_state(self, device):
+        """The module's own training plumbing (flat gradient slots, side stream, gradient reducer: train_state.py) unless a
+        `Trainer` owns the parameters (its FlatSGD installed the slots) or gradients are off."""
+        from ..train_state import AUTO, ModuleTrainState
+        st = self._train_state
+        if st is not None:
+            return st
+        if not AUTO or not torch.is_grad_enabled():
+            return None
+        first = next(self.parameters())
+        if getattr(first, '_ym_grad_slot', None) is not None:
+            return None                          # trainer-owned
+        st = self._train_state = ModuleTrainState(self, device)
+        return st
 
     # ---- forward -----------------------------------------------------------------------------
     CONV_MODES = {'f32': 0, 'bf16x3': 3, 'bf16x6': 6}
@@ -183,11 +221,18 @@ class Yolact(nn.Module):
                                'test infrastructure).')
         if self.training:
             # train branch of the reference forward (:158-161): head logits + semantic-seg conv + compute_loss
-            from ..train_engine import train_features
+            from ..train_engine import train_features, weights_changed
             from ..loss import compute_loss
             if isinstance(self.anchors, list):
                 self.anchors = torch.tensor(self.anchors, device=img.device).reshape(-1, 4)    # like reference :171-172
+            state = self._own_train_state(img.device)
+            if state is not None:
+                weights_changed()                # a torch optimizer stepped since the last forward: one batched re-pack
+                state.begin_forward()
+                state.sync_before_forward(self._ddp_wrapped)
             class_p, box_p, coef_p, proto_p, seg_p = train_features(self, img)
+            if state is not None:
+                state.after_forward()
             self.mark_weights_changed()          # the optimizer is about to change them; eval engines must repack
             return compute_loss(self.cfg, self.anchors, class_p, box_p, coef_p, proto_p, seg_p, box_classes, masks_gt)
         return self._engine(img).forward(img)

@@ -287,7 +287,9 @@ class _PackCache:
                 _pre_refresh_hooks.remove(ref)
             else:
                 obj.sync()
-        dead = [k for k, e in self.entries.items() if e['ref']() is None]
+        # (an owner that lost its gradient slot was re-allocated or released -- Module._apply, ModuleTrainState.release: its source
+        #  pointer is stale)
+        dead = [k for k, e in self.entries.items() if e['ref']() is None or getattr(e['ref'](), '_ym_grad_slot', None) is None]
         for k in dead:
             del self.entries[k]
             self.table = None
@@ -468,6 +470,13 @@ def _grad_slot(param, shape):
     autograd on the main stream, so it is always produced there — and when it is a SECOND gradient of a parameter whose slot was
     already handed out in this backward, the main stream first waits for the side stream (autograd is about to add the two)."""
     slot = getattr(param, '_ym_grad_slot', None) if param is not None else None
+    if slot is not None:
+        _auto_backward_begin(param)
+        owner = getattr(param, '_ym_owner', param)
+        if getattr(owner, '_ym_auto', None) is not None and owner.grad is not None:
+            # module-owned slots (train_state.ModuleTrainState): the gradient of an earlier backward is still in place (accumulation
+            # without zero_grad, or zero_grad(set_to_none=False)) -> a fresh tensor, which autograd adds to it
+            param._ym_slot_free = False
     if slot is not None and getattr(param, '_ym_slot_free', False):
         param._ym_slot_free = False           # a second use in the same step must accumulate into a fresh tensor
         v = slot.view_as(slot)                # a FRESH view: AccumulateGrad only adopts (instead of cloning) an unshared tensor
@@ -517,6 +526,39 @@ class wgrad_on_side_stream:
         _side_active[0] = self.prev
         join_wgrad_stream(self.device)
         return False
+
+
+# ---- a backward pass nobody brackets (the reference loop: a bare `loss_total.backward()`, train.py:127) ---------------------------
+# When the parameters' gradient slots belong to a `train_state.ModuleTrainState`, the first gradient request of a backward pass
+# (`_grad_slot` / `_conv_wgrad`) switches the weight-gradient side stream on and queues `_auto_backward_end` on the autograd engine,
+# which runs when this backward's graph task has finished (with the caller's current stream current): it joins the side stream
+# (pending slab reductions first), lets the module's gradient reducer wait for its buckets, and restores the switch.  `backward()`
+# therefore returns exactly like torch's own: every `p.grad` complete with respect to the caller's stream.
+_auto = [None]
+
+
+def _auto_backward_begin(param):
+    if _auto[0] is not None or param is None:
+        return
+    st = getattr(getattr(param, '_ym_owner', param), '_ym_auto', None)
+    if st is None:
+        return
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(_auto_backward_end)
+    except RuntimeError:                 # not inside a backward pass: nothing to bracket
+        return
+    _auto[0] = st
+    st.prev_side = _side_active[0]
+    _side_active[0] = _WGRAD_STREAM and st.side_stream
+
+
+def _auto_backward_end():
+    st, _auto[0] = _auto[0], None
+    if st is None:
+        return
+    _side_active[0] = st.prev_side
+    join_wgrad_stream(st.device)
+    st.end_backward()
 
 
 def _dev_key(device):
@@ -643,6 +685,7 @@ def flush_wgrad_reduces(device):
 
 def _conv_wgrad(x, dz, weight_shape, stride, pad, weight_param=None, dw=None, accumulate=False, segments=None, owners=None):
     """`owners`: the parameters a caller-owned `dw` (+ `segments` destinations) belong to (default: `weight_param`)."""
+    _auto_backward_begin(weight_param if weight_param is not None else (owners[0] if owners else None))
     if not _side_active[0] or not x.is_cuda:
         return _conv_wgrad_now(x, dz, weight_shape, stride, pad, weight_param, dw, accumulate, segments)
     cout, cin, kh, kw = weight_shape
@@ -989,12 +1032,15 @@ def _arm_drain_check():
     silence outside `Trainer.step`.  For partial backward set YM_GRAD_JOIN=0 YM_FUSE_RES_GRAD=0 (autograd's own sums)."""
     if _drain_armed[0]:
         return
-    _drain_armed[0] = True
 
     def _cb():
         _drain_armed[0] = False
         check_links_drained()
-    torch.autograd.Variable._execution_engine.queue_callback(_cb)
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(_cb)
+        _drain_armed[0] = True
+    except RuntimeError:                 # not inside a backward pass (a unit test calling the helpers directly)
+        pass
 
 
 def _join_result(join, role, dx):
@@ -1194,6 +1240,9 @@ def train_features(net, img):
     _stats_pool.begin(img.device)
     _live_links.clear()                                          # (links of a forward whose backward never ran)
     _drain_armed[0] = False                                      # (a backward that died before its callbacks ran)
+    if _auto[0] is not None:                                     # (likewise: its end-of-backward callback never ran)
+        _side_active[0] = _auto[0].prev_side
+        _auto[0] = None
     bb = net.backbone
     if hasattr(bb, 'patch_embed'):                                # Swin-T (modules/swin_transformer.py)
         from .swin_train import swin_backbone_train

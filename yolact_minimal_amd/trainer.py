@@ -169,6 +169,10 @@ class FlatAdamW(FlatSGD):
             p._ym_in_slot = False
 
 
+_REDUCE_AT_END = os.environ.get('YM_REDUCE_AT_END', '0') == '1'      # diagnostic: every bucket is all-reduced after backward (no overlap)
+_REDUCE_DRY = os.environ.get('YM_REDUCE_DRY', '0') == '1'            # diagnostic: the hooks and the bookkeeping run, the collectives do not
+
+
 class FlatGradReducer:
     """Bucketed gradient all-reduce overlapped with backward, zero-copy on the optimizer's flat gradient buffer.
 
@@ -180,8 +184,10 @@ class FlatGradReducer:
     their last gradient has landed (`register_post_accumulate_grad_hook`), asynchronously on the RCCL stream.
     """
 
-    def __init__(self, opt, world, bucket_bytes=25 << 20, group=None):
+    def __init__(self, opt, world, bucket_bytes=None, group=None):
         self.opt, self.world, self.group = opt, world, group
+        if bucket_bytes is None:
+            bucket_bytes = int(float(os.environ.get('YM_BUCKET_MB', '25')) * (1 << 20))
         self.buckets = []                            # [start, end, param indices]
         cur, size, end = [], 0, opt.flat.numel()
         for i in reversed(range(len(opt.params))):
@@ -216,7 +222,8 @@ class FlatGradReducer:
             b = self.bucket_of[i]
             self.pending[b] -= 1
             self.grads_seen += 1
-            self._launch_ready()
+            if not _REDUCE_AT_END:
+                self._launch_ready()
         return hook
 
     def _launch_ready(self):
@@ -227,6 +234,10 @@ class FlatGradReducer:
             # everything else (BN / bias gradients) on the main one -> issue it from the side stream after making that wait for
             # the main stream; the main stream itself is not held up
             flat = self.opt.grad
+            if _REDUCE_DRY:
+                self.launch_log.append((self.next_bucket, self.grads_seen, self.in_finish))
+                self.next_bucket += 1
+                continue
             side = wgrad_stream_if_used(flat.device) if flat.is_cuda else None
             if side is not None:
                 side.wait_stream(torch.cuda.current_stream(flat.device))
@@ -290,6 +301,8 @@ def flatten_buffers(module):
 class Trainer:
     def __init__(self, net, cfg, device, world=1, local_rank=0):
         self.net, self.cfg, self.device, self.world = net.train().to(device), cfg, device, world
+        if getattr(self.net, '_train_state', None) is not None:
+            self.net._drop_train_state()             # the module's own plumbing (train_state.py) gives way to this trainer's
         release_wgrad_scratch()                      # (per-layer scratch of a previous trainer in this process)
         if cfg.__class__.__name__ == 'swin_tiny_coco':           # optimizer choice of the reference (train.py:60-63)
             self.opt = FlatAdamW(self.net.parameters(), cfg.lr, weight_decay=0.05)
