@@ -659,6 +659,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
     local_rank %= torch.cuda.device_count()          # (tests run two gloo ranks on a 1-GPU box; one rank per GPU otherwise)
+    # stdout carries ONE line, the JSON record: everything else a library prints there (RCCL's version banner, written through C
+    # stdio and flushed at exit, i.e. AFTER the record) goes to stderr -- file descriptor 1 is re-pointed for the whole run and the
+    # record is written to the saved descriptor at the end
+    sys.stdout.flush()
+    record_fd = os.dup(1)
+    os.dup2(2, 1)
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     dist = None
@@ -910,7 +916,7 @@ def main():
         }
     barrier()
     if rank == 0:
-        print(json.dumps(out))
+        os.write(record_fd, (json.dumps(out) + '\n').encode())
     if dist is not None:
         torch.cuda.synchronize()          # nothing in flight when the process group (and its watchdog thread) is torn down
         dist.destroy_process_group()

@@ -79,12 +79,19 @@ class RequestPipeline:
         """Capture every slot's hipGraph (first run of an engine) and push `rounds` requests through every slot, outside any timed
         region: the first requests of a pipeline allocate their result tensors (123 MB of masks per request at 480x640) with
         hipMalloc until the caching allocator holds enough blocks for `depth` requests in flight plus the results the caller
-        still owns, and the part ramps its clocks; a server is warm, so the pipeline warms itself.  Counters start at zero after."""
+        still owns, and the part ramps its clocks; a server is warm, so the pipeline warms itself.
+
+        Side effects the caller should know: `submitted`, `detections` and `latencies_ms` are RESET to zero / empty afterwards
+        (statistics collected before the call are discarded), and with the default `head_outputs=None` the warm-up requests
+        post-process the network's own outputs (a random-init net: degenerate detection counts, full-size mask tensors all the
+        same).  `rounds=0` captures the graphs only (the cost of the pipeline before round 5)."""
         torch.cuda.synchronize(self.device)
         for e, st in zip(self.engines, self.streams):
             with torch.cuda.stream(st):
                 e.run(img)
         torch.cuda.synchronize(self.device)
+        if rounds <= 0:
+            return
         timed, self.timed = self.timed, False
         for _ in range(rounds * self.depth):
             self.submit(img, head_outputs)

@@ -673,6 +673,8 @@ def flush_wgrad_reduces(device):
             dst.first_block = at
             at += it.blocks
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        if len(_reduce_tables) >= 64:                               # (a gradient reducer's bucket timing can regroup the flushes: bounded)
+            _reduce_tables.clear()
         ent = _reduce_tables[key] = (host.to(device), at)          # (pageable H2D: synchronous, once per table)
     table, total = ent
     side = _side_streams[device]

@@ -347,6 +347,13 @@ class Trainer:
     def module(self):
         return self.net
 
+    def close(self):
+        """Give back what training holds beyond the parameters: the per-layer slab scratch of the deferred weight-gradient
+        reductions (~2 GB for res101 at batch 8, growing with the batch; YM_WGRAD_REDUCE_BATCH=0 never allocates it) and the cached
+        reduction tables.  Call when the process goes on to evaluate / serve; the next training step re-allocates them."""
+        torch.cuda.synchronize(self.device)
+        release_wgrad_scratch()
+
     # ---- full-state checkpoint (SURVEY §8f row 4: the reference's save_latest/save_best keep only net.state_dict(),
     # utils/common_utils.py:41-63, so a resumed run restarts the momentum buffers and the LR warm-up) -------------------
     def state_dict(self):
