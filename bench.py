@@ -396,6 +396,34 @@ def train_reference_loop_bench(cfg_name, img_size, batch, steps, warmup, local_r
             dist.destroy_process_group()
 
 
+def other_sizes_bench(cfg_name, device, sizes=(320, 736)):
+    """The tuned table is keyed on exact layer shapes of the 544 px plans; any other `--img_size` (detect.py, eval.py) runs on the
+    planner's fallback.  Forward-only, bs=1, one request at a time (graph replay): the fallback at 320 / 736 px, and — the size of
+    the cliff — the 544 px plan with the table switched off next to the tuned one."""
+    from yolact_minimal_amd import engine as E
+    out = {}
+
+    def run(size):
+        net, cfg = build_net(cfg_name, size, device)
+        w = Workload(net, cfg, 1, size, device, with_post=False)
+        t = min(timed(w, 60, 5, lambda: None), timed(w, 60, 0, lambda: None)) / 60
+        fl = w.engine.total_flops
+        return dict(forward_ms=round(t * 1e3, 3), img_s=round(1.0 / t, 1), gflop_per_img=round(fl / 1e9, 1),
+                    frac_f32_mfma_peak=round(fl / t / 1e12 / F32_MFMA_PEAK_TFLOPS, 4), conv_launches=len(w.engine.convs))
+    for size in sizes:
+        out[f'{size}px_fallback'] = run(size)
+    out['544px_tuned'] = run(544)
+    saved = E._tuned
+    E._tuned = {}
+    try:
+        out['544px_fallback'] = run(544)
+    finally:
+        E._tuned = saved
+    out['note'] = ('planner fallback = yolact_minimal_amd.engine heuristics without table rows; the 544 px pair is the same network and '
+                   'kernels, only the per-shape tile / split / kernel-family choice differs')
+    return out
+
+
 def eval_metrics_bench(device, n=100, g=15, h=480, w=640, iters=20, cpu=True):
     """Next-row f2: `prep_metrics` (mask IoU 100 x 15 masks at 480x640 + box IoU + matching over 10 thresholds) per image.
     HBM roofline of the mask-IoU kernel: every mask is read once = (n + g) * h * w * 4 bytes."""
@@ -848,6 +876,11 @@ def main():
                 w2.engine.set_mma(0)
             extra['split_bf16'] = split
             extra['eval_metrics'] = eval_metrics_bench(device, cpu=not args.no_cpu_baseline)
+            if args.batch == 1:
+                try:
+                    extra['other_sizes'] = other_sizes_bench(args.cfg, device)
+                except Exception as e:
+                    extra['other_sizes'] = dict(error=f'{type(e).__name__}: {e}'[:400])
             if args.batch == 1 and not args.no_post:
                 try:
                     extra['eval_loop'] = eval_loop_bench(args.cfg, args.img_size, device)
