@@ -587,7 +587,7 @@ def ddp_block(tr, timing, img_s, world, cfg_name, batch):
     collectives cost where backward could not hide them, and what the process group actually saw."""
     import torch.distributed as dist
     ref, ref_src = None, None
-    for r in (5, 4, 3):
+    for r in (6, 5, 4, 3):
         q = os.path.join(REPO, 'profiles', f'r0{r}_bench_line.json')
         if os.path.exists(q):
             try:
@@ -778,7 +778,7 @@ def main():
         flops, conv_secs, launches, layers = conv_roofline(fw.engine, fw.img)
         achieved = flops / conv_secs / 1e12
         traffic, traffic_src = None, None
-        pmc_path = next((q for q in (os.path.join(REPO, 'profiles', f'r0{r}_pmc_hbm_infer_bs1_res101.json') for r in (5, 4, 3))
+        pmc_path = next((q for q in (os.path.join(REPO, 'profiles', f'r0{r}_pmc_hbm_infer_bs1_res101.json') for r in (6, 5, 4, 3))
                          if os.path.exists(q)), '')
         if args.cfg == 'res101_coco' and args.batch == 1 and pmc_path:
             # HBM-side bytes per conv launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2

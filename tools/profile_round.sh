@@ -28,6 +28,9 @@ db=$(run infer_bs8 $BENCH --batch 8 --steps 20 --warmup 5)
 [ -n "$db" ] && python $R/tools/prof_summary.py "$db" "$OUT/${TAG}_infer_bs8_res101_kernel_stats.md" > /dev/null
 db=$(run train python $R/tools/train_profile.py --steps 10)
 [ -n "$db" ] && python $R/tools/prof_summary.py "$db" "$OUT/${TAG}_train_res101_bs8_kernel_stats.md" > /dev/null && python $R/tools/gap_summary.py "$db" 30 k_sgd > "$OUT/${TAG}_train_res101_bs8_gaps.txt"
+# the reference's own training loop (torch DDP + torch.optim through dropin/, timer fences): tools/ref_loop_profile.py
+db=$(run ref_loop python $R/tools/ref_loop_profile.py --steps 8)
+[ -n "$db" ] && python $R/tools/prof_summary.py "$db" "$OUT/${TAG}_reference_loop_res101_bs8_kernel_stats.md" > /dev/null && python $R/tools/gap_summary.py "$db" 30 k_nchw_to_nhwc4 > "$OUT/${TAG}_reference_loop_res101_bs8_gaps.txt"
 # HBM-side bytes per conv launch (separate PMC passes, kernel-trace only)
 rm -rf "$OUT/raw_pmc_f" "$OUT/raw_pmc_w"
 YM_GRAPH=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/raw_pmc_f" -o f -- $BENCH --steps 20 --warmup 5 > /dev/null 2>&1      # (eager launches: rocprofv3 --pmc crashes on hipGraph replays on this pool)

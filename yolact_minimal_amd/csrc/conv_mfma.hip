@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
         // last K group's MFMAs (with their lgkmcnt wait) below the raw s_barrier — so a wave could sit at the barrier with
         // ds_reads of that buffer still queued while a faster wave's DMA overwrote it (WAR; cdna guide "restage a buffer 1 phase
         // after its last ds_read only when an lgkmcnt before the barrier retired those reads").  Seen with the ring of 2 as one
-        // wrong 16-byte operand chunk (32 wrong outputs) in ~1 % of the launches of a 2610-tile conv: tools/race_probe.py.
+        // wrong 16-byte operand chunk (32 wrong outputs) in ~1 % of the launches of a 2610-tile conv.
         static_assert((AR + BR) * (D - 1) < 16, "vmcnt field");
         constexpr int WAIT = 0x070 | ((AR + BR) * (D - 1));
         const int nt = kt_end - kt_beg;

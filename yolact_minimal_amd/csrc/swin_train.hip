@@ -280,26 +280,40 @@ __device__ __forceinline__ void attn_mm(const float* a, int row, int h, const f3
     }
 }
 
-__global__ __launch_bounds__(512) void k_window_attention_bwd(const AttnBwdP p) {
+// SLOTS = units (window, head) a workgroup works on at a time, a PAIR of waves each: 4 = one 144 KB workgroup per CU (default), 2 =
+// two 72 KB workgroups per CU whose staging / compute phases are not coupled by a common barrier (YM_ATTN_BWD_SLOTS=2).  Measured in
+// the Swin-T bs=8 training step, round 6: 34.27 ms with 4 slots, 34.55-34.61 with 2 -- alone on the chip the staging round trip of a
+// unit is exposed (MFMA-busy 0.24), in the step the weight-gradient stream runs in those holes and the decoupling buys nothing.
+template <int SLOTS>
+__global__ __launch_bounds__(128 * SLOTS, 2) void k_window_attention_bwd(const AttnBwdP p) {
+    constexpr int NT = 128 * SLOTS;
     __shared__ float s_bias[176], s_dbias[176], s_dpad[3][32];
-    __shared__ int s_tok[4][64], s_reg[4][64];
-    __shared__ float s_mx[4][64], s_inv[4][64], s_rs[4][64];
-    extern __shared__ __attribute__((aligned(16))) float s_mat[];       // [4 waves][4 matrices][64][MP]
-    const int lane = threadIdx.x & 63, wv = (threadIdx.x >> 6) >> 1, half = (threadIdx.x >> 6) & 1;   // wv = unit slot 0..3
+    __shared__ int s_tok[SLOTS][64], s_reg[SLOTS][64];
+    __shared__ float s_mx[SLOTS][64], s_inv[SLOTS][64], s_rs[SLOTS][64];
+    extern __shared__ __attribute__((aligned(16))) float s_mat[];       // [SLOTS][4 matrices][64][MP]
+    const int lane = threadIdx.x & 63, wv = (threadIdx.x >> 6) >> 1, half = (threadIdx.x >> 6) & 1;   // wv = unit slot
     const int head = blockIdx.x % p.heads, k0 = blockIdx.x / p.heads;
     const int C3 = 3 * p.C;
     const long long nwin = (long long)p.B * p.nWh * p.nWw;
-    for (int i = threadIdx.x; i < NREL; i += 512) { s_bias[i] = p.table[i * p.heads + head]; s_dbias[i] = 0.f; }
-    for (int i = threadIdx.x; i < 4 * 4 * MAT; i += 512) s_mat[i] = 0.f;       // (rows 49..63 of every tile stay zero)
+    for (int i = threadIdx.x; i < NREL; i += NT) { s_bias[i] = p.table[i * p.heads + head]; s_dbias[i] = 0.f; }
+    for (int i = threadIdx.x; i < SLOTS * 4 * MAT; i += NT) s_mat[i] = 0.f;     // (rows 49..63 of every tile stay zero)
     if (threadIdx.x < 96) s_dpad[threadIdx.x >> 5][threadIdx.x & 31] = 0.f;
     __syncthreads();
+    // relative-position-bias gradient: element (key, q) of dS^T always lives in the same (register, lane) of a phase-T wave, so the
+    // sum over the workgroup's units is kept in registers and scattered to the 169 bins ONCE (it used to be 2401 LDS atomics per
+    // unit on 169 addresses)
+    f32x16 dbacc[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dbacc[kt][r] = 0.f;
     float* const mq = s_mat + wv * 4 * MAT;
     const float *const mk = mq + M_K * MAT, *const mv = mq + M_V * MAT, *const mdo = mq + M_DO * MAT;
     const int row = lane & 31, h = lane >> 5;
     const int* tokrow = s_tok[wv];
     const int qc = head * HD, kc = p.C + head * HD, vc = 2 * p.C + head * HD;
     // every wave runs the same number of iterations (the pair of a unit meets at workgroup barriers): a slot past the last window idles
-    for (long long base = (long long)k0 * 4; base < nwin; base += (long long)p.nblk * 4) {
+    for (long long base = (long long)k0 * SLOTS; base < nwin; base += (long long)p.nblk * SLOTS) {
         const long long win = base + wv;
         const bool valid = win < nwin;
         long long t = valid ? win : 0;
@@ -413,10 +427,7 @@ __global__ __launch_bounds__(512) void k_window_attention_bwd(const AttnBwdP p) 
                     const bool live = key < NTOK && q < NTOK;
                     const float ds = live ? st[kt][r] * (dpt[kt][r] - rs) : 0.f;
                     dpt[kt][r] = ds;
-                    if (live) {
-                        const int kiy = key / WS, kix = key - kiy * WS;
-                        atomicAdd(&s_dbias[(qiy - kiy + WS - 1) * (2 * WS - 1) + (qix - kix + WS - 1)], ds);
-                    }
+                    dbacc[kt][r] += ds;
                 }
             {
                 float kk[2][16];
@@ -493,8 +504,22 @@ __global__ __launch_bounds__(512) void k_window_attention_bwd(const AttnBwdP p) 
         }
         __syncthreads();                      // both waves are done with the unit's tiles before the next one is staged
     }
+    {
+        const int row = lane & 31, h = lane >> 5, q = half * 32 + row;          // this wave's phase-T coordinates (query tile `half`)
+        const int qiy = q / WS, qix = q - qiy * WS;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (key < NTOK && q < NTOK) {
+                    const int kiy = key / WS, kix = key - kiy * WS;
+                    atomicAdd(&s_dbias[(qiy - kiy + WS - 1) * (2 * WS - 1) + (qix - kix + WS - 1)], dbacc[kt][r]);
+                }
+            }
+    }
     __syncthreads();
-    for (int i = threadIdx.x; i < NREL; i += 512)
+    for (int i = threadIdx.x; i < NREL; i += NT)
         if (s_dbias[i] != 0.f) atomicAdd(p.dtable + i * p.heads + head, s_dbias[i]);
     if (threadIdx.x < 96) {
         const float v = s_dpad[threadIdx.x >> 5][threadIdx.x & 31];
@@ -604,15 +629,22 @@ extern "C" int ym_swin_window_attention_bwd(const float* qkv, const float* qkv_b
     p.Hp = p.nWh * WS; p.Wp = p.nWw * WS;
     p.scale = 1.0f / sqrtf((float)HD);
     const long long nwin = (long long)B * p.nWh * p.nWw;
-    const long long wgs_needed = (nwin + 3) / 4;               // one window per wave, 4 waves of one head per workgroup
-    long long nblk = 256 / heads;                              // one workgroup per CU (its operand tiles fill the LDS): the grid must
-    if (nblk < 1) nblk = 1;                                    // not exceed 256, or its last few workgroups run as a second round
+    static int slots = 0;                                      // YM_ATTN_BWD_SLOTS=2: two half-size workgroups per CU (A/B; see the kernel)
+    if (slots == 0) { const char* e = getenv("YM_ATTN_BWD_SLOTS"); slots = (e && atoi(e) == 2) ? 2 : 4; }
+    const long long wgs_needed = (nwin + slots - 1) / slots;   // one unit (window, head) per pair of waves, `slots` units per workgroup
+    long long nblk = (256 * (4 / slots)) / heads;              // workgroups resident at once (their operand tiles fill the LDS): the grid
+    if (nblk < 1) nblk = 1;                                    // must not exceed them, or its last few workgroups run as a second round
     if (nblk > wgs_needed) nblk = wgs_needed;
     p.nblk = (int)nblk;
-    const size_t lds = (size_t)4 * 4 * MAT * sizeof(float);          // 144 KB: one workgroup (4 waves) per CU
-    static YmLdsAttr attr = {};
-    if (int rc = ym_ensure_dyn_lds(attr, reinterpret_cast<const void*>(k_window_attention_bwd), lds, "window_attention_bwd")) return rc;
-    hipLaunchKernelGGL(k_window_attention_bwd, dim3((int)(nblk * heads)), dim3(512), lds, (hipStream_t)s, p);
+    const size_t lds = (size_t)slots * 4 * MAT * sizeof(float);      // 72 KB (2 slots: two workgroups per CU) / 144 KB (4 slots)
+    static YmLdsAttr attr2 = {}, attr4 = {};
+    if (slots == 4) {
+        if (int rc = ym_ensure_dyn_lds(attr4, reinterpret_cast<const void*>(k_window_attention_bwd<4>), lds, "window_attention_bwd")) return rc;
+        hipLaunchKernelGGL(k_window_attention_bwd<4>, dim3((int)(nblk * heads)), dim3(512), lds, (hipStream_t)s, p);
+    } else {
+        if (int rc = ym_ensure_dyn_lds(attr2, reinterpret_cast<const void*>(k_window_attention_bwd<2>), lds, "window_attention_bwd")) return rc;
+        hipLaunchKernelGGL(k_window_attention_bwd<2>, dim3((int)(nblk * heads)), dim3(256), lds, (hipStream_t)s, p);
+    }
     return ym_check_launch("window_attention_bwd");
 }
 
