@@ -64,6 +64,7 @@ def parse():
     ap.add_argument('--train-steps', type=int, default=6)
     ap.add_argument('--no-train', action='store_true', help='skip the DDP training measurement')
     ap.add_argument('--local_rank', type=int, default=None)
+    ap.add_argument('--leg', default='', help=argparse.SUPPRESS)        # internal: one leg in a process of its own (prints a JSON dict)
     return ap.parse_args()
 
 
@@ -676,6 +677,13 @@ def spawn_ranks(n):
 
 def main():
     args = parse()
+    if args.leg == 'train_reference_loop':
+        torch.cuda.set_device(0)
+        fd = os.dup(1)
+        os.dup2(2, 1)
+        out = train_reference_loop_bench(args.cfg, args.img_size, args.train_batch, args.train_steps, 2, 0, torch.device('cuda', 0))
+        os.write(fd, (json.dumps(out) + '\n').encode())
+        return
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -892,8 +900,16 @@ def main():
                 net._engines.clear()
                 torch.cuda.empty_cache()
                 try:
-                    extra['train_reference_loop'] = train_reference_loop_bench(args.cfg, args.img_size, args.train_batch, args.train_steps, 2,
-                                                                               local_rank, device)
+                    # a process of its own: this one started HIP with GPU_MAX_HW_QUEUES=8 for the request pipeline, and the reference's
+                    # training loop (torch DDP + RCCL + side stream) wants the default 4 (dropin/run.py::hw_queues_for)
+                    import subprocess
+                    env = {k: v for k, v in os.environ.items() if k not in ('GPU_MAX_HW_QUEUES', 'RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+                    env['GPU_MAX_HW_QUEUES'] = '4'
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), '--leg', 'train_reference_loop', '--cfg', args.cfg, '--img_size',
+                                        str(args.img_size), '--train-batch', str(args.train_batch), '--train-steps', str(max(args.train_steps, 10))],
+                                       env=env, capture_output=True, text=True, timeout=900)
+                    extra['train_reference_loop'] = json.loads(r.stdout.strip().splitlines()[-1])
+                    extra['train_reference_loop']['GPU_MAX_HW_QUEUES'] = 4
                 except Exception as e:
                     extra['train_reference_loop'] = dict(error=f'{type(e).__name__}: {e}'[:400])
                 torch.cuda.empty_cache()

@@ -16,16 +16,26 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 
-# Requests / batches in flight (yolact_minimal_amd.pipeline.RequestPipeline) and the weight-gradient side stream run on separate HIP
-# streams; ROCm multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable when the runtime
-# starts, i.e. before the script's `import torch` touches HIP.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
+
+def hw_queues_for(script):
+    """ROCm multiplexes HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable when the runtime
+    starts, i.e. before the script's `import torch` touches HIP.  Serving (eval.py / detect.py: requests in flight on separate
+    streams, yolact_minimal_amd.pipeline.RequestPipeline) wants 8 — two request streams that share a queue do not overlap.  Training
+    wants the default: the part has four compute pipes, and torch DDP + RCCL + the weight-gradient side stream keep more than four
+    queues busy once they each have one; measured on res101 bs=8 with the timer fences removed: 54.7 ms per step with 8 queues, 42.7
+    with 4 (profiles/r06_reference_loop_timings.txt).  An exported GPU_MAX_HW_QUEUES always wins."""
+    name = os.path.basename(script)
+    return '8' if name.startswith(('eval', 'detect')) else None
 
 
 def main():
     if len(sys.argv) < 2:
         raise SystemExit(__doc__)
     script = os.path.abspath(sys.argv[1])
+    q = hw_queues_for(script)
+    if q is not None:
+        os.environ.setdefault('GPU_MAX_HW_QUEUES', q)
     checkout = os.path.dirname(script)
     rest = [p for p in sys.path if os.path.abspath(p or os.getcwd()) not in (HERE, REPO, checkout)]
     sys.path[:] = [HERE, REPO, checkout] + rest

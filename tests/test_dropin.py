@@ -65,3 +65,11 @@ def test_launcher_runs_a_script_inside_a_checkout_unmodified(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(REPO, 'dropin', 'run.py'), 'eval_like.py', '--weight', 'w.pth'],
                        cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and 'DROPIN_OK' in r.stdout and "FALL 41 ['--weight', 'w.pth']" in r.stdout, r.stderr[-2000:]
+
+
+def test_launcher_picks_hardware_queues_by_script():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('_dropin_run', os.path.join(REPO, 'dropin', 'run.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.hw_queues_for('/x/eval.py') == '8' and mod.hw_queues_for('detect.py') == '8' and mod.hw_queues_for('/x/train.py') is None

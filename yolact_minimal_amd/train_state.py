@@ -2,8 +2,8 @@
 (`/root/reference/train.py:60-63,76,102-130`: `optim.SGD(net.parameters())`, `DDP(net.cuda(), [local_rank], ...)`,
 `net(images, targets, masks)`, `optimizer.zero_grad()`, `loss_total.backward()`, `optimizer.step()` — not a line of it changed).
 
-Measured on one MI355X, res101_coco 544 px batch 8 (profiles/r06_reference_loop_*): that loop took 72.5 ms per step against 41.7 for
-`Trainer.step` with bit-identical results.  Where the 31 ms went: 28 of them inside torch's DistributedDataParallel — per step 323
+Measured on one MI355X, res101_coco 544 px batch 8 (profiles/r06_reference_loop_*): that loop took 72.3 ms per step against 41.6 for
+`Trainer.step` with bit-identical results; with this module 46.3 (fenced by the reference's timer) / 43.1 (fences removed).  Where the 31 ms went: 28 of them inside torch's DistributedDataParallel — per step 323
 `mul` launches (gradient / world size into the bucket), 419 bucket -> gradient copies, and the coalesced broadcast of the 416
 BatchNorm buffers (flatten + 416 copies back) — all issued one by one from the autograd thread; the rest: one weight re-pack launch
 per conv and direction (no pack cache without an owner), weight gradients on the main stream, 104 `num_batches_tracked += 1` launches.
@@ -26,6 +26,11 @@ per conv and direction (no pack cache without an owner), weight gradients on the
     (`prediction_layers.bbox_layer.bias`), because it refuses to wrap a module it has nothing to do for.
 
 `YM_AUTO_FLAT=0` switches all of it off (torch DDP then does everything itself, as in round 5).
+
+Hardware queues: keep GPU_MAX_HW_QUEUES at its default (4) for training.  With 8 (what the serving pipeline wants) the default
+stream, the side stream, RCCL's stream and DDP's own streams each get a queue, more than the part's four compute pipes: the reference
+loop without its timer fences then takes 54.7 instead of 43.1 ms per step and the one-rank reducer costs 5 ms instead of 0.3
+(profiles/r06_reference_loop_timings.txt; `dropin/run.py` exports 8 for eval.py / detect.py only).
 """
 import os
 
