@@ -268,3 +268,55 @@ print('EVAL_LOOP_OK', len(mj_dense.mask_data), seen3)
 '''
     r = subprocess.run([sys.executable, '-c', f'REPO = {REPO!r}\n' + code], cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and 'EVAL_LOOP_OK' in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_ddp_no_sync_accumulates_locally(tmp_path):
+    """`with ddp.no_sync():` (gradient accumulation) under the module-owned reducer: the backward inside leaves the gradients local
+    (no collective is launched), the next synchronised backward accumulates into them and all-reduces the sum — torch's own contract.
+    One RCCL rank with the reducer forced on; the accumulated gradient must equal g(batch A) + g(batch B) from two separate runs."""
+    code = r'''
+import os, sys, socket
+sys.path[:0] = [os.path.join(REPO, 'dropin'), REPO]
+os.environ['YM_FORCE_DIST'] = '1'
+import torch, torch.distributed as dist
+from torch.nn.parallel import DistributedDataParallel as DDP
+from yolact_minimal_amd.config import build_cfg
+from yolact_minimal_amd.modules.yolact import Yolact
+from yolact_minimal_amd.utils.synthetic import synth_targets
+with socket.socket() as sk:
+    sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]
+dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1)
+cfg = build_cfg('res50_coco', 'train', 64, train_bs=2, bs_per_gpu=2)
+torch.manual_seed(0)
+net = Yolact(cfg); net.train()
+ddp = DDP(net.cuda(), [0], output_device=0, broadcast_buffers=True)
+def batch(seed):
+    img = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(seed)).cuda()
+    b, m = synth_targets(2, 64, seed=seed)
+    return img, [x.cuda() for x in b], [x.cuda() for x in m]
+def grads():
+    return {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+singles = []
+for seed in (1, 2):                                   # each batch on its own (BatchNorm statistics are per forward either way)
+    net.zero_grad()
+    sum(ddp(*batch(seed))).backward()
+    singles.append(grads())
+red = net._train_state.reducer
+assert red is not None and red.launches == 2 * len(red.buckets)
+net.zero_grad()
+before = red.launches
+with ddp.no_sync():
+    sum(ddp(*batch(1))).backward()
+assert red.launches == before, 'a collective was launched inside no_sync()'
+local = grads()
+assert all(torch.equal(local[n], singles[0][n]) for n in local)
+sum(ddp(*batch(2))).backward()                        # synchronised: accumulates, then reduces
+assert red.launches == before + len(red.buckets)
+acc = grads()
+worst = max(float((acc[n] - (singles[0][n] + singles[1][n])).abs().max() / ((singles[0][n] + singles[1][n]).abs().max() + 1e-30)) for n in acc)
+assert worst < 1e-6, worst
+print('NO_SYNC_OK', worst)
+dist.destroy_process_group()
+'''
+    r = subprocess.run([sys.executable, '-c', f'REPO = {REPO!r}\n' + code], cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'NO_SYNC_OK' in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

@@ -111,6 +111,7 @@ class Yolact(nn.Module):
         self._weights_epoch = 0
         self._train_state = None          # train_state.ModuleTrainState, created at the first train-mode forward on the GPU
         self._ddp_wrapped = False
+        self._ddp_wrapper = None
 
     # ---- torch.nn.parallel.DistributedDataParallel around this module (reference train.py:76) ------------------------------------
     @property
@@ -124,6 +125,16 @@ class Yolact(nn.Module):
         if not AUTO or self.cfg.mode != 'train':
             raise AttributeError('_ddp_params_and_buffers_to_ignore')
         self._ddp_wrapped = True
+        # the wrapper itself (the caller of this property is its constructor), kept weakly: `DDP.no_sync()` works by clearing
+        # `require_backward_grad_sync` on it, and the module's reducer has to honour that (train_state.ModuleTrainState.sync_wanted)
+        try:
+            import inspect
+            import weakref
+            caller = inspect.currentframe().f_back.f_locals.get('self')
+            if caller is not None and getattr(caller, 'module', self) is self or type(caller).__name__ == 'DistributedDataParallel':
+                self._ddp_wrapper = weakref.ref(caller)
+        except Exception:
+            pass
         return [n for n, _ in self.named_parameters() if n != DDP_KEEPS] + [n for n, _ in self.named_buffers()]
 
     def _drop_train_state(self):
@@ -229,7 +240,8 @@ class Yolact(nn.Module):
             if state is not None:
                 weights_changed()                # a torch optimizer stepped since the last forward: one batched re-pack
                 state.begin_forward()
-                state.sync_before_forward(self._ddp_wrapped)
+                wrapper = self._ddp_wrapper() if self._ddp_wrapper is not None else None
+                state.sync_before_forward(self._ddp_wrapped, getattr(wrapper, 'require_backward_grad_sync', True))
             class_p, box_p, coef_p, proto_p, seg_p = train_features(self, img)
             if state is not None:
                 state.after_forward()

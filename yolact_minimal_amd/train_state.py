@@ -98,11 +98,15 @@ class ModuleTrainState:
             return False
         return dist.get_world_size() > 1 or os.environ.get('YM_FORCE_DIST', '0') == '1'
 
-    def sync_before_forward(self, wrapped):
+    def sync_before_forward(self, wrapped, grad_sync=True):
+        """`grad_sync`: the wrapper's `require_backward_grad_sync` at this forward — False inside `DDP.no_sync()` (gradient
+        accumulation): the coming backward then leaves its gradients local, as torch's reducer would; the next synchronised backward
+        accumulates into them and all-reduces the sum."""
         if not self.distributed(wrapped):
             return
         if self.reducer is None:
             self.reducer = FlatGradReducer(self, dist.get_world_size())
+        self.reducer.enabled = bool(grad_sync)
         if not self.synced_params:
             # what DDP's constructor does for the tensors it manages (_sync_module_states): every replica starts from rank 0's weights
             if dist.get_world_size() > 1:

@@ -204,6 +204,7 @@ class FlatGradReducer:
         self.avg_op = backend == 'nccl'                # RCCL averages in the collective; gloo has no AVG -> SUM then scale
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(opt.params)]
         self.launches = 0
+        self.enabled = True        # False: this backward keeps its gradients local (DDP.no_sync(); see train_state.ModuleTrainState)
         self.reset()
 
     def reset(self):
@@ -216,6 +217,8 @@ class FlatGradReducer:
 
     def _make_hook(self, i):
         def hook(p):
+            if not self.enabled:
+                return
             FlatSGD.gather(p)
             if p.grad is not None and p.grad.data_ptr() != p._ym_grad_slot.data_ptr():
                 p.grad = p._ym_grad_slot.view_as(p._ym_grad_slot)     # the reduced value is what the caller must see
@@ -253,6 +256,9 @@ class FlatGradReducer:
     def finish(self):
         """After backward: reduce what is left (parameters that received no gradient count as zeros), wait for every
         bucket, and leave the AVERAGED gradients in the flat buffer."""
+        if not self.enabled:
+            self.reset()
+            return
         self.in_finish = True
         for b in range(self.next_bucket, len(self.buckets)):
             for i in self.buckets[b][2]:
