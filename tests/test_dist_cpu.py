@@ -242,3 +242,95 @@ def test_eight_rank_gloo_reducer_with_res101_bucket_layout():
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     got = [q.get(timeout=5) for _ in range(8)]
     assert sorted(r for r, _ in got) == list(range(8)) and len({tuple(s) for _, s in got}) == 1
+
+
+def test_module_train_state_surface():
+    """Host logic of train_state.ModuleTrainState (what a Yolact brings along for the reference's own loop), on the CPU: slot layout,
+    the one parameter left to torch's DDP, the ignore list DDP reads, release()."""
+    from yolact_minimal_amd.config import build_cfg
+    from yolact_minimal_amd.modules.yolact import Yolact
+    from yolact_minimal_amd.train_state import ModuleTrainState, DDP_KEEPS
+    torch.manual_seed(0)
+    net = Yolact(build_cfg('res50_coco', 'train', 64))
+    names = dict(net.named_parameters())
+    bufs = dict(net.named_buffers())
+    assert not net._ddp_wrapped
+    ignore = net._ddp_params_and_buffers_to_ignore                       # (what DDP's constructor does)
+    assert net._ddp_wrapped and DDP_KEEPS in names and DDP_KEEPS not in ignore
+    assert set(ignore) == (set(names) - {DDP_KEEPS}) | set(bufs)
+    assert not hasattr(Yolact(build_cfg('res50_coco', 'val', 64)), '_ddp_params_and_buffers_to_ignore')
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    st = ModuleTrainState(net, torch.device('cpu'))
+    assert len(st.params) == len(names) - 1 and all(p is not names[DDP_KEEPS] for p in st.params)
+    assert all(a % 16 == 0 for a, _ in st.offsets) and st.offsets[-1][1] <= st.grad.numel()
+    assert all(p._ym_grad_slot.data_ptr() == st.grad.data_ptr() + 4 * a and p._ym_grad_slot.shape == p.shape
+               for p, (a, _) in zip(st.params, st.offsets))
+    assert not hasattr(names[DDP_KEEPS], '_ym_grad_slot')
+    # BatchNorm statistics / counters became views of flat tensors without changing a value or a state-dict key
+    after = net.state_dict()
+    assert list(after) == list(before) and all(torch.equal(after[k], before[k]) for k in before)
+    assert st.buffers_flat.numel() == sum(b.numel() for b in net.buffers() if b.is_floating_point())
+    bn = net.backbone.bn1
+    st.buffers_flat.fill_(3.0)
+    assert float(bn.running_mean[0]) == 3.0 and bn._ym_nbt_flat
+    st.after_forward()
+    assert int(bn.num_batches_tracked) == 1
+    assert not st.distributed(True)                                       # no process group: the module never touches one
+    st.release()
+    assert not bn._ym_nbt_flat and not any(hasattr(p, '_ym_grad_slot') or hasattr(p, '_ym_auto') for p in net.parameters())
+
+
+def _worker_state(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from yolact_minimal_amd import trainer
+    from yolact_minimal_amd.config import build_cfg
+    from yolact_minimal_amd.modules.yolact import Yolact
+    from yolact_minimal_amd.train_state import ModuleTrainState
+    trainer.init_distributed(backend='gloo')
+    torch.manual_seed(100 + rank)                                         # different initial weights per rank
+    net = Yolact(build_cfg('res50_coco', 'train', 64))
+    net.backbone.bn1.running_mean.fill_(float(rank + 1))
+    st = ModuleTrainState(net, torch.device('cpu'))
+    st.sync_before_forward(True)                                          # first forward under DDP: parameters + buffers follow rank 0
+    assert st.reducer is not None and st.synced_params and float(net.backbone.bn1.running_mean[0]) == 1.0
+    n = len(st.params)
+    coef = lambda r, i: float(((r + 1) * 13 + i * 7) % 11) - 5.0          # noqa: E731
+    # gradient accumulation: a backward inside DDP.no_sync() stays local ...
+    st.begin_forward()
+    st.sync_before_forward(True, grad_sync=False)
+    sum(st.params[i].sum() * coef(rank, i) for i in range(n)).backward()
+    st.end_backward()
+    assert st.reducer.launches == 0 and abs(float(st.params[3].grad.reshape(-1)[0]) - coef(rank, 3)) < 1e-6
+    # ... the next one accumulates into it and the SUM is averaged over the ranks
+    st.begin_forward()
+    st.sync_before_forward(True)
+    order = torch.randperm(n, generator=torch.Generator().manual_seed(rank)).tolist()
+    sum(st.params[i].sum() * coef(rank, i) for i in order).backward()
+    st.end_backward()
+    assert st.reducer.launches == len(st.reducer.buckets)
+    for i in (0, 3, n // 2, n - 1):
+        want = sum(2 * coef(r, i) for r in range(world)) / world
+        assert abs(float(st.params[i].grad.reshape(-1)[-1]) - want) < 1e-5, (i, want)
+    digest = torch.stack([torch.cat([p.detach().reshape(-1) for p in net.parameters()]).double().sum(), st.buffers_flat.double().sum()])
+    gathered = [torch.zeros_like(digest) for _ in range(world)]
+    dist.all_gather(gathered, digest)
+    assert all(torch.equal(gathered[0], g) for g in gathered)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, 'ok'))
+
+
+def test_module_train_state_two_rank_gloo():
+    """The module's own DDP plumbing with two gloo ranks on the CPU: initial parameter broadcast, per-forward buffer broadcast, local
+    accumulation under no_sync, bucketed averaging of the accumulated sum, identical replicas."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_state, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(q.get(timeout=5)[0] for _ in range(2)) == [0, 1]

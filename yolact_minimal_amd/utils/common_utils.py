@@ -202,7 +202,9 @@ def _replace_checkpoint(prefix, cfg_name, new_name, net):
     for p in old:
         os.remove(p)
     print(f"\nSaving the {prefix} model as '{new_name}'.\n")
-    torch.save(net.state_dict(), f'weights/{new_name}')
+    # (clones: under a Trainer / the module's own training state parameters and BatchNorm buffers are views of flat buffers, and
+    #  torch.save would write each flat storage whole and share it between the entries; the reference's files hold one storage per key)
+    torch.save({k: v.detach().clone() for k, v in net.state_dict().items()}, f'weights/{new_name}')
 
 
 def save_best(net, mask_map, cfg_name, step):
