@@ -534,31 +534,36 @@ class wgrad_on_side_stream:
 # which runs when this backward's graph task has finished (with the caller's current stream current): it joins the side stream
 # (pending slab reductions first), lets the module's gradient reducer wait for its buckets, and restores the switch.  `backward()`
 # therefore returns exactly like torch's own: every `p.grad` complete with respect to the caller's stream.
-_auto = [None]
+_auto = []            # the ModuleTrainStates whose parameters took part in the backward pass that is running (usually one)
+_auto_prev_side = [False]
 
 
 def _auto_backward_begin(param):
-    if _auto[0] is not None or param is None:
+    if param is None:
         return
     st = getattr(getattr(param, '_ym_owner', param), '_ym_auto', None)
-    if st is None:
+    if st is None or st in _auto:
         return
-    try:
-        torch.autograd.Variable._execution_engine.queue_callback(_auto_backward_end)
-    except RuntimeError:                 # not inside a backward pass: nothing to bracket
-        return
-    _auto[0] = st
-    st.prev_side = _side_active[0]
-    _side_active[0] = _WGRAD_STREAM and st.side_stream
+    if not _auto:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_auto_backward_end)
+        except RuntimeError:             # not inside a backward pass: nothing to bracket
+            return
+        _auto_prev_side[0] = _side_active[0]
+    _auto.append(st)
+    _side_active[0] = _side_active[0] or (_WGRAD_STREAM and st.side_stream)
 
 
 def _auto_backward_end():
-    st, _auto[0] = _auto[0], None
-    if st is None:
+    states = list(_auto)
+    del _auto[:]
+    if not states:
         return
-    _side_active[0] = st.prev_side
-    join_wgrad_stream(st.device)
-    st.end_backward()
+    _side_active[0] = _auto_prev_side[0]
+    for dev in {st.device for st in states}:
+        join_wgrad_stream(dev)
+    for st in states:
+        st.end_backward()
 
 
 def _dev_key(device):
@@ -1242,9 +1247,9 @@ def train_features(net, img):
     _stats_pool.begin(img.device)
     _live_links.clear()                                          # (links of a forward whose backward never ran)
     _drain_armed[0] = False                                      # (a backward that died before its callbacks ran)
-    if _auto[0] is not None:                                     # (likewise: its end-of-backward callback never ran)
-        _side_active[0] = _auto[0].prev_side
-        _auto[0] = None
+    if _auto:                                                    # (likewise: its end-of-backward callback never ran)
+        _side_active[0] = _auto_prev_side[0]
+        del _auto[:]
     bb = net.backbone
     if hasattr(bb, 'patch_embed'):                                # Swin-T (modules/swin_transformer.py)
         from .swin_train import swin_backbone_train

@@ -66,7 +66,6 @@ class ModuleTrainState:
         self.bns = [m for m in net.modules() if getattr(m, '_ym_nbt_flat', False)]
         self.reducer = None
         self.synced_params = False
-        self.prev_side = False
         self.side_stream = os.environ.get('YM_AUTO_SIDE_STREAM', '1') != '0'
         self.begin_forward()
 
