@@ -292,27 +292,58 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
     };
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (fixed_c && i < total) load_channel((int)(i % C4));
-    for (; i < total; i += stride) {
-        if (!fixed_c) load_channel((int)(i % C4));
-        f32x4 dz = *reinterpret_cast<const f32x4*>(dout + i * 4);
-        const f32x4 yy = *reinterpret_cast<const f32x4*>(y + i * 4);
+    auto one = [&](size_t at, f32x4 dz, const f32x4 yy, const f32x4 o) __attribute__((always_inline)) {
         if (relu && out) {
-            const f32x4 o = *reinterpret_cast<const f32x4*>(out + i * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) dz[e] = o[e] > 0.f ? dz[e] : 0.f;
         } else if (relu) {                                        // no saved `out`: the same affine as the forward pass
 #pragma unroll
             for (int e = 0; e < 4; ++e) dz[e] = bn_affine(yy[e], mu[e], is[e], g[e], bt[e]) > 0.f ? dz[e] : 0.f;
         }
-        if (dres) *reinterpret_cast<f32x4*>(dres + i * 4) = dz;
+        if (dres) *reinterpret_cast<f32x4*>(dres + at * 4) = dz;
         f32x4 r;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float xh = (yy[e] - mu[e]) * is[e];
             r[e] = g[e] * is[e] * (dz[e] - dbf[e] * invM - xh * dgf[e] * invM);
         }
-        *reinterpret_cast<f32x4*>(dy + i * 4) = r;
+        *reinterpret_cast<f32x4*>(dy + at * 4) = r;
+    };
+    // U quads per thread with ALL their loads issued first (2-3 x U 16-byte loads in flight per lane): in the training step this pass
+    // shares the CUs with the weight-gradient stream and gets few resident waves, so its bandwidth comes from loads per wave, not
+    // from the number of waves (one quad per thread ran 2x its stand-alone time there).  Same arithmetic per element.
+    constexpr int U = 4;
+    if (fixed_c) {
+        for (; i + (size_t)(U - 1) * stride < total; i += (size_t)U * stride) {
+            f32x4 dz[U], yy[U], o[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t at = i + (size_t)u * stride;
+                dz[u] = *reinterpret_cast<const f32x4*>(dout + at * 4);
+                yy[u] = *reinterpret_cast<const f32x4*>(y + at * 4);
+                if (relu && out) o[u] = *reinterpret_cast<const f32x4*>(out + at * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) one(i + (size_t)u * stride, dz[u], yy[u], o[u]);
+        }
     }
+    for (; i < total; i += stride) {
+        if (!fixed_c) load_channel((int)(i % C4));
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if (relu && out) o = *reinterpret_cast<const f32x4*>(out + i * 4);
+        one(i, *reinterpret_cast<const f32x4*>(dout + i * 4), *reinterpret_cast<const f32x4*>(y + i * 4), o);
+    }
+}
+
+// grid of the BatchNorm-backward apply pass: four quads per thread (see the kernel), a multiple of 2 blocks so that the grid stride stays
+// a multiple of C / 4 for every channel count of the nets (<= 2048)
+inline int bn_apply_grid(size_t total) {
+    static int per_thread = 0;                       // YM_BN_APPLY_QUADS=1: one quad per thread, the launch shape of rounds 1-5 (A/B)
+    if (per_thread == 0) { const char* e = getenv("YM_BN_APPLY_QUADS"); per_thread = (e && atoi(e) > 0) ? atoi(e) : 4; }
+    size_t g = (total + 256 * (size_t)per_thread - 1) / (256 * (size_t)per_thread);
+    if (g > 8192) g = 8192;
+    if (g < 2) g = 2;
+    return (int)((g + 1) & ~(size_t)1);
 }
 
 __global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ dy, const float* __restrict__ y, int act,
@@ -623,7 +654,7 @@ extern "C" int ym_bn_train_bwd(const float* dout, const float* out, const float*
         hipLaunchKernelGGL(k_col_reduce<1>, dim3(grid), dim3(256), 0, st, dout, out, y, save_mean, save_invstd, (long long)M, C,
                            relu, 0, db, dg, (double*)nullptr, gamma, beta);
     }
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid((size_t)M * (C / 4))), dim3(256), 0, st, dout, out, y, save_mean,
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(bn_apply_grid((size_t)M * (C / 4))), dim3(256), 0, st, dout, out, y, save_mean,
                        save_invstd, gamma, beta, db, dg, relu, dy, dres, (long long)M, C, dgamma, dbeta);
     return ym_check_launch("bn_train_bwd");
 }
@@ -635,7 +666,7 @@ extern "C" int ym_bn_train_bwd_apply(const float* dout, const float* out, const 
                "bn_train_bwd_apply: null pointer (relu needs `out`, or `beta` to re-derive the mask from y)");
     YM_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_train_bwd_apply: C %% 4 != 0");
     const double* db = (const double*)stats;
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid((size_t)M * (C / 4))), dim3(256), 0, (hipStream_t)s, dout, out, y, save_mean,
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(bn_apply_grid((size_t)M * (C / 4))), dim3(256), 0, (hipStream_t)s, dout, out, y, save_mean,
                        save_invstd, gamma, beta, db, db + C, relu, dy, dres, (long long)M, C, dgamma, dbeta);
     return ym_check_launch("bn_train_bwd_apply");
 }
