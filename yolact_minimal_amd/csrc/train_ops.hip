@@ -85,6 +85,29 @@ __global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ a,
                         }
                 }
             }
+            if (MODE == 2) {
+                // 4 independent rows in flight per lane (this pass runs beside the weight gradients, or on their stream, with about one
+                // resident wave per SIMD: one row at a time it waited on memory for 89 % of its cycles); rows are added in order
+                for (; m + 3 * stride < M; m += 4 * stride) {
+                    f32x4 d[4], y[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const size_t off = (size_t)(m + u * stride) * C + cq * 4;
+                        d[u] = *reinterpret_cast<const f32x4*>(a + off);
+                        if (act) y[u] = *reinterpret_cast<const f32x4*>(b + off);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (act) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                d[u][e] = act == YM_ACT_RELU ? (y[u][e] > 0.f ? d[u][e] : 0.f) : d[u][e] * (1.f - y[u][e] * y[u][e]);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) s0[e] += (double)d[u][e];
+                    }
+                }
+            }
             for (; m < M; m += stride) {
                 const size_t off = (size_t)m * C + cq * 4;
                 const f32x4 x = *reinterpret_cast<const f32x4*>(a + off);
