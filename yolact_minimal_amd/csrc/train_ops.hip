@@ -273,17 +273,30 @@ __global__ __launch_bounds__(256) void k_bn_finalize_apply(const float* __restri
     }
     const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + cq * 4), b = *reinterpret_cast<const f32x4*>(beta + cq * 4);
     const size_t total = (size_t)M * C4;
-    for (size_t i = gt; i < total; i += (size_t)gridDim.x * 256) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(y + i * 4);
+    const size_t stride = (size_t)gridDim.x * 256;
+    auto one = [&](size_t at, f32x4 v, const f32x4 r) __attribute__((always_inline)) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = bn_affine(v[e], mu[e], is[e], g[e], b[e]);
-        if (residual) v += *reinterpret_cast<const f32x4*>(residual + i * 4);
+        if (residual) v += r;
         if (relu) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];
         }
-        *reinterpret_cast<f32x4*>(out + i * 4) = v;
+        *reinterpret_cast<f32x4*>(out + at * 4) = v;
+    };
+    size_t i = gt;
+    for (; i + 3 * stride < total; i += 4 * stride) {          // four quads per lane, loads first
+        f32x4 v[4], r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v[u] = *reinterpret_cast<const f32x4*>(y + (i + u * stride) * 4);
+            r[u] = residual ? *reinterpret_cast<const f32x4*>(residual + (i + u * stride) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) one(i + u * stride, v[u], r[u]);
     }
+    for (; i < total; i += stride)
+        one(i, *reinterpret_cast<const f32x4*>(y + i * 4), residual ? *reinterpret_cast<const f32x4*>(residual + i * 4) : f32x4{0.f, 0.f, 0.f, 0.f});
 }
 
 // dy_raw = gamma*invstd * (dz - dbeta/M - xhat * dgamma/M); dres = dz
