@@ -36,6 +36,8 @@ ap.add_argument('--gain', type=float, default=0.08, help='ms per step a candidat
 ap.add_argument('--budget', type=float, default=600.0, help='seconds')
 ap.add_argument('--out', default='gpurun_out/insitu.json')
 ap.add_argument('--kinds', default='TWF', help='T: data gradients, W: weight gradients, F: forward convs')
+ap.add_argument('--only', default='', help='comma-separated substrings: only table rows whose key contains one of them')
+ap.add_argument('--splitk', action='store_true', help='candidates: the large tiles WITH a K split (128x128 / 128x64 x ksplit 2-4) only')
 args = ap.parse_args()
 
 dev = torch.device('cuda:0')
@@ -102,6 +104,20 @@ def candidates(key, info):
                     out.append([ms, nb])
         return out
     wgs64 = -(-info['M'] // 64) * -(-info['N'] // 64)
+    if args.splitk:
+        # a 64x64 tile moves 16 KB per 262 kFLOP of its K step through L2 -> LDS (16 FLOP/B: 9.8 TB/s at the MFMA peak), a 128x128 tile
+        # half of that: large tiles whose workgroup count is restored by a K split
+        for tm, tn in ((128, 128), (128, 64), (64, 128)):
+            if tn > 64 and info['N'] <= 64:
+                continue
+            for ks in (2, 3, 4, 6):
+                if ks * 2 > info['nkt']:
+                    continue
+                for stg in (22, 2):
+                    row = [tm, tn, ks, 0, stg, 0, 0]
+                    if row != cur:
+                        out.append(row)
+        return out
     for tm, tn in ((64, 64), (128, 64), (64, 128), (128, 128)):
         if tn > 64 and info['N'] <= 64:
             continue
@@ -117,7 +133,8 @@ def candidates(key, info):
 
 base = measure(3)
 print(f'baseline {base:.3f} ms/step, {len(seen)} table rows in use', flush=True)
-order = sorted((k for k in seen if seen[k]['kind'] in args.kinds), key=lambda k: -seen[k]['flops'])
+order = sorted((k for k in seen if seen[k]['kind'] in args.kinds and (not args.only or any(t in k for t in args.only.split(',')))),
+               key=lambda k: -seen[k]['flops'])
 t_start = time.time()
 accepted = {}
 best = base
