@@ -131,7 +131,8 @@ class Yolact(nn.Module):
             import inspect
             import weakref
             caller = inspect.currentframe().f_back.f_locals.get('self')
-            if caller is not None and getattr(caller, 'module', self) is self or type(caller).__name__ == 'DistributedDataParallel':
+            # (DDP.__init__ reads this before it sets `self.module`; anything else that merely probes the attribute is not a wrapper)
+            if caller is not None and type(caller).__name__ == 'DistributedDataParallel':
                 self._ddp_wrapper = weakref.ref(caller)
         except Exception:
             pass
