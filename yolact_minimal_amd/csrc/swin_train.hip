@@ -112,6 +112,80 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__
     }
 }
 
+// Rows of <= 128 floats (stage 1, C = 96: 74 % of the tokens): a HALF wave per row, U rows of each half in flight (x and dy of all of
+// them requested first).  One row per wave left 40 of the 64 lanes idle there and two dependent round trips per row.  Same arithmetic
+// per row as k_layernorm_bwd<0> (its xor-32 butterfly step adds zeros for such rows); the per-workgroup dgamma / dbeta partials sum
+// the rows in another order (rounding-level difference in those two vectors).
+template <int U>
+__global__ __launch_bounds__(256) void k_layernorm_bwd_small(const float* __restrict__ dy, const float* __restrict__ x,
+                                                              const float* __restrict__ gamma, float eps, float* __restrict__ dx,
+                                                              float* __restrict__ part /*[grid][2][C]*/, long long M, int C) {
+    __shared__ float s_red[8][2][128];
+    const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31, hwv = (threadIdx.x >> 6) * 2 + half;
+    const long long hw0 = ((((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6) << 1) + half;
+    const long long nhw = (((long long)gridDim.x * blockDim.x) >> 6) << 1;
+    const int C4 = C >> 2;
+    const bool on = l32 < C4;
+    f32x4 gm = {0.f, 0.f, 0.f, 0.f}, ag = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f};
+    if (on) gm = *reinterpret_cast<const f32x4*>(gamma + l32 * 4);
+    for (long long m0 = hw0; m0 < M; m0 += nhw * U) {
+        f32x4 v[U], d[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long m = m0 + u * nhw;
+            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            d[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (on && m < M) {
+                v[u] = *reinterpret_cast<const f32x4*>(x + (size_t)m * C + l32 * 4);
+                d[u] = *reinterpret_cast<const f32x4*>(dy + (size_t)m * C + l32 * 4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long m = m0 + u * nhw;
+            float sum = 0.f;
+            if (on) sum += v[u][0] + v[u][1] + v[u][2] + v[u][3];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            const float mean = sum / (float)C;
+            float sq = 0.f;
+            if (on) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float t = v[u][e] - mean; sq += t * t; }
+            }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+            const float rstd = 1.f / sqrtf(sq / (float)C + eps);
+            float c1 = 0.f, c2 = 0.f;
+            f32x4 xh = {0.f, 0.f, 0.f, 0.f}, g = {0.f, 0.f, 0.f, 0.f};
+            if (on && m < M) {
+                xh = (v[u] - mean) * rstd;
+                g = d[u] * gm;
+                ag += d[u] * xh;
+                ab += d[u];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { c1 += g[e]; c2 += g[e] * xh[e]; }
+            }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) { c1 += __shfl_xor(c1, o); c2 += __shfl_xor(c2, o); }
+            c1 /= (float)C; c2 /= (float)C;
+            if (on && m < M) *reinterpret_cast<f32x4*>(dx + (size_t)m * C + l32 * 4) = (g - c1 - xh * c2) * rstd;
+        }
+    }
+    if (on) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s_red[hwv][0][l32 * 4 + e] = ag[e]; s_red[hwv][1][l32 * 4 + e] = ab[e]; }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { a += s_red[r][0][c]; b += s_red[r][1][c]; }
+        part[((size_t)blockIdx.x * 2 + 0) * C + c] = a;
+        part[((size_t)blockIdx.x * 2 + 1) * C + c] = b;
+    }
+}
+
 // dgamma / dbeta = ordered sum of the per-workgroup partials [blocks][2][C]: 16 channels x 16 block slices per workgroup, slices
 // combined through LDS in a fixed order (deterministic).  (One thread per channel walking all the blocks in a dependent chain took
 // 68 us per call whatever the size: 2.1 ms of a Swin-T training step.)
@@ -559,8 +633,12 @@ extern "C" int ym_layernorm_bwd(const float* dy, const float* x, const float* ga
     YM_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && C <= 1536, "layernorm_bwd: C must be a multiple of 4, <= 1536");
     if (workspace_bytes < ym_layernorm_bwd_workspace_bytes(C)) { ym_set_error("layernorm_bwd: workspace too small"); return YM_ENOSPC; }
     const int blocks = ln_bwd_blocks(M);
-    hipLaunchKernelGGL(k_layernorm_bwd<0>, dim3(blocks), dim3(256), 0, (hipStream_t)s, dy, x, gamma, eps, dx, (float*)workspace,
-                       (long long)M, C, 0, 0, 0, 0);
+    if (C <= 128)
+        hipLaunchKernelGGL(k_layernorm_bwd_small<2>, dim3(blocks), dim3(256), 0, (hipStream_t)s, dy, x, gamma, eps, dx, (float*)workspace,
+                           (long long)M, C);
+    else
+        hipLaunchKernelGGL(k_layernorm_bwd<0>, dim3(blocks), dim3(256), 0, (hipStream_t)s, dy, x, gamma, eps, dx, (float*)workspace,
+                           (long long)M, C, 0, 0, 0, 0);
     hipLaunchKernelGGL(k_ln_param_grad, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)s, (const float*)workspace, blocks, C, dgamma, dbeta);
     return ym_check_launch("layernorm_bwd");
 }
