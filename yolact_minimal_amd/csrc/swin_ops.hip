@@ -242,13 +242,15 @@ __global__ __launch_bounds__(256) void k_window_attention(const AttnP p) {
 // row per wave per iteration means one 16-byte load in flight per lane (2.3 TB/s on the 114 MB of a stage-1 LayerNorm at batch 8).
 // Here a HALF wave owns a row and works on U rows at a time (2 U rows per wave in flight).  Bit-identical to k_layernorm<0>: there
 // the upper lanes hold zeros, so its xor-32 butterfly step adds nothing and the remaining steps are the ones below.
-template <int U>
+// LPR = lanes per row: 32 (C <= 128, two rows per wave) or 64 (C <= 256: Swin-T stage 2, one row per wave, still U rows in flight).
+template <int U, int LPR>
 __global__ __launch_bounds__(256) void k_layernorm_small(const float* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps, float* __restrict__ out,
                                                           long long M, int C) {
-    const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
-    const long long hw0 = ((((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6) << 1) + half;      // half-wave index
-    const long long nhw = (((long long)gridDim.x * blockDim.x) >> 6) << 1;
+    constexpr int RPW = 64 / LPR;                                       // rows per wave
+    const int lane = threadIdx.x & 63, half = lane / LPR, l32 = lane % LPR;
+    const long long hw0 = (((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * RPW + half;      // row-slot index
+    const long long nhw = (((long long)gridDim.x * blockDim.x) >> 6) * RPW;
     const int C4 = C >> 2;
     const bool on = l32 < C4;
     f32x4 g = {0.f, 0.f, 0.f, 0.f}, bb = {0.f, 0.f, 0.f, 0.f};
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(256) void k_layernorm_small(const float* __restrict
             float sum = 0.f;
             if (on) sum += v[u][0] + v[u][1] + v[u][2] + v[u][3];
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
             const float mean = sum / (float)C;
             float sq = 0.f;
             if (on) {
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(256) void k_layernorm_small(const float* __restrict
                 for (int e = 0; e < 4; ++e) { const float d = v[u][e] - mean; sq += d * d; }
             }
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+            for (int o = LPR / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
             const float rstd = 1.f / sqrtf(sq / (float)C + eps);
             if (on && m < M) *reinterpret_cast<f32x4*>(out + (size_t)m * C + l32 * 4) = (v[u] - mean) * rstd * g + bb;
         }
@@ -287,11 +289,13 @@ __global__ __launch_bounds__(256) void k_layernorm_small(const float* __restrict
 extern "C" int ym_layernorm(const float* x, const float* gamma, const float* beta, float eps, float* out, int64_t M, int C,
                             ym_stream_t s) {
     YM_REQUIRE(x && gamma && beta && out && M > 0 && C > 0 && C % 4 == 0 && C <= 1536, "layernorm: C must be a multiple of 4, <= 1536");
-    if (C <= 128) {
+    if (C <= 256) {
         constexpr int U = 4;
-        long long blocks = (M + 8 * U - 1) / (8 * U);          // 8 half-waves per workgroup, U rows each per iteration
+        const int rows_per_wg = C <= 128 ? 8 : 4;
+        long long blocks = (M + rows_per_wg * U - 1) / (rows_per_wg * U);          // U rows per row slot and iteration
         if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(k_layernorm_small<U>, dim3((int)blocks), dim3(256), 0, (hipStream_t)s, x, gamma, beta, eps, out, (long long)M, C);
+        if (C <= 128) hipLaunchKernelGGL((k_layernorm_small<U, 32>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, x, gamma, beta, eps, out, (long long)M, C);
+        else hipLaunchKernelGGL((k_layernorm_small<U, 64>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, x, gamma, beta, eps, out, (long long)M, C);
         return ym_check_launch("layernorm");
     }
     long long blocks = (M + 3) / 4;

@@ -116,14 +116,15 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__
 // them requested first).  One row per wave left 40 of the 64 lanes idle there and two dependent round trips per row.  Same arithmetic
 // per row as k_layernorm_bwd<0> (its xor-32 butterfly step adds zeros for such rows); the per-workgroup dgamma / dbeta partials sum
 // the rows in another order (rounding-level difference in those two vectors).
-template <int U>
+template <int U, int LPR>
 __global__ __launch_bounds__(256) void k_layernorm_bwd_small(const float* __restrict__ dy, const float* __restrict__ x,
                                                               const float* __restrict__ gamma, float eps, float* __restrict__ dx,
                                                               float* __restrict__ part /*[grid][2][C]*/, long long M, int C) {
-    __shared__ float s_red[8][2][128];
-    const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31, hwv = (threadIdx.x >> 6) * 2 + half;
-    const long long hw0 = ((((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6) << 1) + half;
-    const long long nhw = (((long long)gridDim.x * blockDim.x) >> 6) << 1;
+    constexpr int RPW = 64 / LPR, SLOTS = 4 * RPW;                      // LPR lanes per row (32: C <= 128, 64: C <= 256)
+    __shared__ float s_red[SLOTS][2][4 * LPR];
+    const int lane = threadIdx.x & 63, half = lane / LPR, l32 = lane % LPR, hwv = (threadIdx.x >> 6) * RPW + half;
+    const long long hw0 = (((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * RPW + half;
+    const long long nhw = (((long long)gridDim.x * blockDim.x) >> 6) * RPW;
     const int C4 = C >> 2;
     const bool on = l32 < C4;
     f32x4 gm = {0.f, 0.f, 0.f, 0.f}, ag = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f};
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd_small(const float* __rest
             float sum = 0.f;
             if (on) sum += v[u][0] + v[u][1] + v[u][2] + v[u][3];
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
             const float mean = sum / (float)C;
             float sq = 0.f;
             if (on) {
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd_small(const float* __rest
                 for (int e = 0; e < 4; ++e) { const float t = v[u][e] - mean; sq += t * t; }
             }
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+            for (int o = LPR / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
             const float rstd = 1.f / sqrtf(sq / (float)C + eps);
             float c1 = 0.f, c2 = 0.f;
             f32x4 xh = {0.f, 0.f, 0.f, 0.f}, g = {0.f, 0.f, 0.f, 0.f};
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd_small(const float* __rest
                 for (int e = 0; e < 4; ++e) { c1 += g[e]; c2 += g[e] * xh[e]; }
             }
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) { c1 += __shfl_xor(c1, o); c2 += __shfl_xor(c2, o); }
+            for (int o = LPR / 2; o > 0; o >>= 1) { c1 += __shfl_xor(c1, o); c2 += __shfl_xor(c2, o); }
             c1 /= (float)C; c2 /= (float)C;
             if (on && m < M) *reinterpret_cast<f32x4*>(dx + (size_t)m * C + l32 * 4) = (g - c1 - xh * c2) * rstd;
         }
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd_small(const float* __rest
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float a = 0.f, b = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) { a += s_red[r][0][c]; b += s_red[r][1][c]; }
+        for (int r = 0; r < SLOTS; ++r) { a += s_red[r][0][c]; b += s_red[r][1][c]; }
         part[((size_t)blockIdx.x * 2 + 0) * C + c] = a;
         part[((size_t)blockIdx.x * 2 + 1) * C + c] = b;
     }
@@ -634,7 +635,10 @@ extern "C" int ym_layernorm_bwd(const float* dy, const float* x, const float* ga
     if (workspace_bytes < ym_layernorm_bwd_workspace_bytes(C)) { ym_set_error("layernorm_bwd: workspace too small"); return YM_ENOSPC; }
     const int blocks = ln_bwd_blocks(M);
     if (C <= 128)
-        hipLaunchKernelGGL(k_layernorm_bwd_small<2>, dim3(blocks), dim3(256), 0, (hipStream_t)s, dy, x, gamma, eps, dx, (float*)workspace,
+        hipLaunchKernelGGL((k_layernorm_bwd_small<2, 32>), dim3(blocks), dim3(256), 0, (hipStream_t)s, dy, x, gamma, eps, dx, (float*)workspace,
+                           (long long)M, C);
+    else if (C <= 256)
+        hipLaunchKernelGGL((k_layernorm_bwd_small<2, 64>), dim3(blocks), dim3(256), 0, (hipStream_t)s, dy, x, gamma, eps, dx, (float*)workspace,
                            (long long)M, C);
     else
         hipLaunchKernelGGL(k_layernorm_bwd<0>, dim3(blocks), dim3(256), 0, (hipStream_t)s, dy, x, gamma, eps, dx, (float*)workspace,
