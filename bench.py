@@ -397,10 +397,12 @@ def train_reference_loop_bench(cfg_name, img_size, batch, steps, warmup, local_r
             dist.destroy_process_group()
 
 
-def other_sizes_bench(cfg_name, device, sizes=(320, 736)):
-    """The tuned table is keyed on exact layer shapes of the 544 px plans; any other `--img_size` (detect.py, eval.py) runs on the
-    planner's fallback.  Forward-only, bs=1, one request at a time (graph replay): the fallback at 320 / 736 px, and — the size of
-    the cliff — the 544 px plan with the table switched off next to the tuned one."""
+def other_sizes_bench(cfg_name, device, sizes=(320, 544, 736)):
+    """Any multiple of 32 is a valid `--img_size` (config.py:75, detect.py:24, eval.py:18); the tuned table is keyed on exact layer
+    shapes.  Forward-only, bs=1, one request at a time (graph replay), per size under three plan sources: `<size>px` = the shipped
+    table (rows for 256 ... 800 px; a shape without a row takes the nearest tuned shape's row, plan_transfer.py), `<size>px_transfer`
+    = transfers ONLY (`YM_TUNED_NEAREST=only`: every launch on a row re-derived from another shape -- what an unmeasured size
+    gets), `<size>px_fallback` = the planner heuristic without any row (what every other size ran on before round 6)."""
     from yolact_minimal_amd import engine as E
     out = {}
 
@@ -409,19 +411,31 @@ def other_sizes_bench(cfg_name, device, sizes=(320, 736)):
         w = Workload(net, cfg, 1, size, device, with_post=False)
         t = min(timed(w, 60, 5, lambda: None), timed(w, 60, 0, lambda: None)) / 60
         fl = w.engine.total_flops
+        src = {}
+        for c in w.engine.convs:
+            k = c.plan_source.split(':')[0]
+            src[k] = src.get(k, 0) + 1
         return dict(forward_ms=round(t * 1e3, 3), img_s=round(1.0 / t, 1), gflop_per_img=round(fl / 1e9, 1),
-                    frac_f32_mfma_peak=round(fl / t / 1e12 / F32_MFMA_PEAK_TFLOPS, 4), conv_launches=len(w.engine.convs))
-    for size in sizes:
-        out[f'{size}px_fallback'] = run(size)
-    out['544px_tuned'] = run(544)
-    saved = E._tuned
-    E._tuned = {}
+                    frac_f32_mfma_peak=round(fl / t / 1e12 / F32_MFMA_PEAK_TFLOPS, 4), conv_launches=len(w.engine.convs), plan_sources=src)
+    saved, saved_env = E._tuned, os.environ.get('YM_TUNED_NEAREST')
     try:
-        out['544px_fallback'] = run(544)
+        for size in sizes:
+            out[f'{size}px'] = run(size)
+            os.environ['YM_TUNED_NEAREST'] = 'only'
+            out[f'{size}px_transfer'] = run(size)
+            os.environ.pop('YM_TUNED_NEAREST')
+            E._tuned = {}
+            out[f'{size}px_fallback'] = run(size)
+            E._tuned = saved
     finally:
         E._tuned = saved
-    out['note'] = ('planner fallback = yolact_minimal_amd.engine heuristics without table rows; the 544 px pair is the same network and '
-                   'kernels, only the per-shape tile / split / kernel-family choice differs')
+        if saved_env is None:
+            os.environ.pop('YM_TUNED_NEAREST', None)
+        else:
+            os.environ['YM_TUNED_NEAREST'] = saved_env
+    out['544px_tuned'] = out['544px']           # (the key of earlier rounds' lines)
+    out['note'] = ('same network and kernels per size; only the per-shape tile / split / kernel-family choice differs between the three '
+                   'plan sources')
     return out
 
 

@@ -235,3 +235,76 @@ def test_other_class_counts_forward_post_and_loss(name):
     np.testing.assert_allclose(np.array([float(l.detach()) for l in losses]), np.array([float(l) for l in ref_losses]), rtol=5e-4)
     sum(losses).backward()
     assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+@pytest.mark.parametrize('size', [320, 832])
+def test_other_image_sizes_plan_sources_agree_with_the_oracle(size, monkeypatch):
+    """Any multiple of 32 is a valid `--img_size` (config.py:75).  Layer shapes without a row in the tuned table are planned from
+    the nearest tuned shape (plan_transfer.py).  The forward under the default plan (rows + transfers), under transfers ONLY
+    (`YM_TUNED_NEAREST=only`: every launch runs on a re-derived row) and under the planner heuristic (`YM_NO_TUNED=1`) each hold
+    the 1e-4 bar against the CPU oracle: the plan source selects among kernels, never the result."""
+    from yolact_minimal_amd import engine as E
+    net, cfg = make_net('res101_coco', size, 5)
+    img = torch.randn(1, 3, size, size, generator=torch.Generator().manual_seed(305))
+    with torch.no_grad():
+        feats = R.features(img, net.state_dict())
+    net = net.to(DEV)
+    seen = {}
+    for label, env in (('default', {}), ('transfers only', {'YM_TUNED_NEAREST': 'only'}), ('heuristic', {'YM_NO_TUNED': '1'})):
+        for k in ('YM_TUNED_NEAREST', 'YM_NO_TUNED'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        E._tuned = None
+        net._engines.clear()
+        with torch.no_grad():
+            net(img.to(DEV))
+        eng = net._engine(img.to(DEV))
+        torch.cuda.synchronize()
+        seen[label] = {s.split(':')[0] for s in (c.plan_source for c in eng.convs)}
+        _close(eng.class_logits, feats[0], f'{label}: class logits')
+        _close(eng.box_pred, feats[1], f'{label}: box')
+    monkeypatch.delenv('YM_NO_TUNED', raising=False)
+    E._tuned = None
+    net._engines.clear()
+    assert 'table' not in seen['transfers only'] and 'nearest' in seen['transfers only']
+    assert seen['heuristic'] == {'heuristic'}
+
+
+def test_autotune_on_first_use_keeps_rows_in_the_user_cache(tmp_path, monkeypatch):
+    """YM_AUTOTUNE=1 (off by default): the launches of a plan without a row of their own are measured when the engine is built,
+    the rows land in the per-user cache, and the next process (here: the next engine after dropping the in-memory table) plans
+    every launch from a row -- same rows, same bits; the result holds the 1e-4 bar against the oracle."""
+    from yolact_minimal_amd import engine as E
+    size = 160
+    cache = tmp_path / 'rows.json'
+    monkeypatch.setenv('YM_AUTOTUNE', '1')
+    monkeypatch.setenv('YM_TUNED_CACHE', str(cache))
+    monkeypatch.delenv('YM_NO_TUNED', raising=False)
+    monkeypatch.delenv('YM_TUNED_NEAREST', raising=False)
+    net, cfg = make_net('res50_coco', size, 5)
+    img = torch.randn(1, 3, size, size, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        feats = R.features(img, net.state_dict())
+    net = net.to(DEV)
+    saved, E._tuned = E._tuned, None
+    try:
+        with torch.no_grad():
+            first = [t.clone() for t in net(img.to(DEV))]
+        eng = net._engine(img.to(DEV))
+        src = {c.plan_source.split(':')[0] for c in eng.convs}
+        assert 'autotuned' in src and src <= {'table', 'autotuned'}
+        rows = __import__('json').load(open(cache))
+        assert {c.sig for c in eng.convs if c.plan_source == 'autotuned'} == set(rows)
+        _close(eng.class_logits, feats[0], 'class logits')
+        _close(eng.box_pred, feats[1], 'box')
+        E._tuned = None
+        net._engines.clear()
+        with torch.no_grad():
+            again = net(img.to(DEV))
+        assert {c.plan_source for c in net._engine(img.to(DEV)).convs} == {'table'}
+        for a, b in zip(first, again):
+            assert torch.equal(a, b)
+    finally:
+        E._tuned = saved
+        net._engines.clear()

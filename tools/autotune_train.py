@@ -20,18 +20,19 @@ def main():
     ap.add_argument('--out', default='gpurun_out/tuned_train.json')
     ap.add_argument('--cfgs', default='res101_coco,res50_coco,swin_tiny_coco')
     ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--sizes', default='544', help='--img_size values whose layer shapes are swept (rows exist for 544)')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
-    for name in args.cfgs.split(','):
-        cfg = build_cfg(name, 'train', 544, train_bs=args.batch, bs_per_gpu=args.batch)
+    for name, size in ((n, int(s)) for n in args.cfgs.split(',') for s in args.sizes.split(',')):
+        cfg = build_cfg(name, 'train', size, train_bs=args.batch, bs_per_gpu=args.batch)
         torch.manual_seed(0)
         net = Yolact(cfg).train().to(dev)
-        img = torch.randn(args.batch, 3, 544, 544, device=dev)
-        boxes, masks = synth_targets(args.batch, 544, seed=0)
+        img = torch.randn(args.batch, 3, size, size, device=dev)
+        boxes, masks = synth_targets(args.batch, size, seed=0)
         losses = net(img, [b.to(dev) for b in boxes], [m.to(dev) for m in masks])
         sum(losses).backward()
         torch.cuda.synchronize()
-        print(name, 'entries so far', len(train_engine._new_entries), flush=True)
+        print(name, size, 'entries so far', len(train_engine._new_entries), flush=True)
         del net, losses
         torch.cuda.empty_cache()
     os.makedirs(os.path.dirname(args.out) or '.', exist_ok=True)

@@ -26,16 +26,20 @@ ap.add_argument('--out', default='')
 ap.add_argument('--max-m', type=int, default=20000)
 ap.add_argument('--slack', type=float, default=1.2)
 ap.add_argument('--replays', type=int, default=40)
+ap.add_argument('--size', type=int, default=544, help='--img_size of the plan that is tuned')
+ap.add_argument('--alt', default='', help='comma-separated table files: their row for a shape (exact, or transferred from the nearest tuned '
+                'shape: plan_transfer.py) is a candidate too, whatever its own launch time')
 ap.add_argument('--inflight', type=int, default=1, help='> 1: optimise the img/s of a RequestPipeline with that many requests in flight; winners are written as <sig>_tp')
 args = ap.parse_args()
 dev = torch.device('cuda:0')
-net, cfg = bench.build_net(args.cfg, 544, dev)
-img = torch.randn(args.batch, 3, 544, 544, device=dev)
+net, cfg = bench.build_net(args.cfg, args.size, dev)
+img = torch.randn(args.batch, 3, args.size, args.size, device=dev)
+alts = [json.load(open(f)) for f in args.alt.split(',') if f]
 pipe = None
 if args.inflight > 1:
     os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
     from yolact_minimal_amd.pipeline import RequestPipeline
-    pipe = RequestPipeline(net, cfg, 544, 544, dev, depth=args.inflight, with_post=False, batch=args.batch, return_outputs=False)
+    pipe = RequestPipeline(net, cfg, args.size, args.size, dev, depth=args.inflight, with_post=False, batch=args.batch, return_outputs=False)
     pipe.warm_up(img)
     eng = pipe.engines[0]
 else:
@@ -153,11 +157,18 @@ for _, sig, t0 in sorted(order):
         alt = E.tuned_table().get(sig)
         if alt:
             cands.append((0.0, list(alt[:7]) + [alt[7] if len(alt) > 7 else 0]))
+    for tab in alts:                  # another table's choice for this shape (its own row, or the nearest tuned shape's, re-derived)
+        from yolact_minimal_amd import plan_transfer
+        row, _ = plan_transfer.lookup(tab, sig, M, d.Cout, d.k_pad // 32, d.nseg)
+        if row is not None:
+            row = list(row[:7]) + [0] * (7 - len(row[:7])) + [row[7] if len(row) > 7 else 0]
+            if row != cur and all(row != v for _, v in cands):
+                cands.append((0.0, row))
     cands.sort()
     tried = 0
     t_ref = min([t0] + [t for t, _ in cands if t > 0])
     for t, v in cands:
-        if v == cur or t > args.slack * t_ref or tried >= (7 if pipe is not None else 5):
+        if v == cur or t > args.slack * t_ref or tried >= (7 if pipe is not None else 5 + len(alts)):
             continue
         tried += 1
         put(sig, v)

@@ -18,11 +18,12 @@ Fusions (what never touches HBM as a separate tensor):
 """
 import json
 import os
+import sys
 
 import torch
 import torch.nn as nn
 
-from . import hip
+from . import hip, plan_transfer
 from .hip import ConvDesc, ACT_NONE, ACT_RELU, ACT_TANH, ACT_GELU
 
 
@@ -55,31 +56,77 @@ def _grid_wgs(hit):
     return g
 
 
+def autotune_on():
+    """YM_AUTOTUNE=1: an engine whose plan has launches without a row of their own (another --img_size / batch) measures them on
+    first use (InferEngine.autotune, ~0.5 s per distinct shape) and keeps the rows in a per-user cache file that later processes
+    read back: the find-db pattern.  Off by default: a first request then never pays for a sweep, and plans do not depend on
+    files outside the package."""
+    return os.environ.get('YM_AUTOTUNE', '0') == '1'
+
+
+def user_cache_path():
+    return os.environ.get('YM_TUNED_CACHE') or os.path.join(os.path.expanduser('~'), '.cache', 'yolact_minimal_amd', 'tuned_gfx950_user.json')
+
+
 def tuned_table():
-    """Per-shape (tile_m, tile_n, ksplit) choices measured on an MI355X by tools/autotune.py."""
+    """Per-shape (tile_m, tile_n, ksplit) choices measured on an MI355X by tools/autotune.py; with YM_AUTOTUNE=1 overlaid by the
+    rows this user's earlier runs measured (user_cache_path())."""
     global _tuned
     if _tuned is None:
         _tuned = {}
         if os.path.exists(TUNED_PATH) and os.environ.get('YM_NO_TUNED', '0') != '1':
             with open(TUNED_PATH) as f:
                 _tuned = json.load(f)
+            if autotune_on() and os.path.exists(user_cache_path()):
+                try:
+                    with open(user_cache_path()) as f:
+                        _tuned.update({k: v for k, v in json.load(f).items() if isinstance(v, list)})
+                except (OSError, ValueError) as e:      # a torn / foreign file must not stop inference
+                    print(f'yolact_minimal_amd: ignoring {user_cache_path()}: {e}', file=sys.stderr)
     return _tuned
+
+
+def _store_user_rows(rows):
+    """Merge `rows` into the user cache (read-modify-write through a temp file + rename: concurrent ranks lose rows at worst)."""
+    path = user_cache_path()
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    cur = {}
+    if os.path.exists(path):
+        try:
+            with open(path) as f:
+                cur = json.load(f)
+        except (OSError, ValueError):
+            cur = {}
+    cur.update(rows)
+    tmp = f'{path}.{os.getpid()}.tmp'
+    with open(tmp, 'w') as f:
+        json.dump(cur, f, indent=0, sort_keys=True)
+    os.replace(tmp, path)
 
 
 _build_mode = ['latency']
 
 
-def _entry(sig):
+def _entry(sig, M=0, N=0, nkt=0, nseg=1, with_source=False):
     """Tuned entry of a conv shape for the engine being built.  'latency' (one request at a time: the default) reads `sig`;
     'throughput' (the slots of a RequestPipeline with several requests in flight) reads `sig + '_tp'` first: choices that spread a
     launch over every CU (tail splits, one-wave workgroups) shorten a lone request and cost throughput when other requests want
-    those CUs -- tools/tune_forward.py --inflight N measures them on the pipeline's own img/s."""
+    those CUs -- tools/tune_forward.py --inflight N measures them on the pipeline's own img/s.
+    A shape without a row (another --img_size / batch) takes the row of the nearest tuned shape of its family, re-derived for its
+    M (plan_transfer.py); `with_source` also returns where the row came from ('table' / 'nearest:<key>' / 'heuristic')."""
     t = tuned_table()
-    if _build_mode[0] == 'throughput':
+    hit, src = None, 'heuristic'
+    if _build_mode[0] == 'throughput' and plan_transfer.mode() != 'only':
         hit = t.get(sig + '_tp')
-        if hit is not None:
-            return hit
-    return t.get(sig)
+        src = 'table'
+    if hit is None:
+        if M > 0:
+            hit, src = plan_transfer.lookup(t, sig, M, N, nkt, nseg)
+        else:
+            hit, src = t.get(sig), 'table'
+            if hit is None:
+                src = 'heuristic'
+    return (hit, src) if with_source else hit
 
 
 class _LinearAsConv:
@@ -125,6 +172,9 @@ class _Conv:
         self.tail = (0, 0)           # (tail_tiles, tail_ksplit): see ym_conv_desc
         self.grid_wgs = 0            # persistent kernel (stages 4x): workgroups launched, 0 = as many as the CUs hold
         self.mma = 0                 # 0 = f32 MFMA (parity mode); 3 / 6 = split-bf16 products (ym_conv_desc.mma)
+        self._hit = None             # the plan row this conv was bound with, and where it came from (_entry)
+        self._shape = (0, 0, 0, 1)   # (M, N, K tiles, output segments) of the bound launch
+        self.plan_source = 'heuristic'
 
     def refresh(self):
         """(Re)pack parameters from the nn.Modules into the kernel layout, on device."""
@@ -177,7 +227,9 @@ class _Conv:
         self.out_hw = (ho, wo)
         self.flops = 2.0 * b * ho * wo * self.cout * self.kh * self.kw * self.cin
         self.sig = f'M{b * ho * wo}_N{self.cout}_C{cin}_k{self.kh}_s{self.stride}_seg{len(segs)}_r{int(residual is not None)}'
-        hit = _entry(self.sig)
+        self._shape = (b * ho * wo, self.cout, self.k_pad // 32, len(segs))
+        hit, self.plan_source = _entry(self.sig, *self._shape, with_source=True)
+        self._hit = hit
         if hit and self.tile == (0, 0) and self.ksplit == 0 and self.kwaves == 0:
             self.tile, self.ksplit, self.kwaves = (hit[0], hit[1]), hit[2], (hit[3] if len(hit) > 3 else 0)
             self.stages = hit[4] if len(hit) > 4 else 0
@@ -200,11 +252,15 @@ class _Conv:
         d = self.desc
         ok = mma in (3, 6) and not self.stem and d.Cin % 32 == 0 and d.nlevels == 0
         self.mma = mma if ok else 0
-        hit = tuned_table().get(self.tuned_key()) if self.mma else None
+        hit = None
+        if self.mma and os.environ.get('YM_NO_TUNED', '0') != '1':      # this pipe's own row: exact, or the nearest tuned shape's
+            hit, _ = plan_transfer.lookup(tuned_table(), self.tuned_key(), *self._shape)
         if hit is None:
-            hit = _entry(self.sig)          # (no entry for this pipe: the f32 choice, incl. its wave kernel for tiny layers)
+            hit = self._hit                 # (no entry for this pipe: the f32 choice, incl. its wave kernel for tiny layers)
             if self.mma and hit and len(hit) > 4 and 52 <= hit[4] <= 54:
                 hit = [0, 0, 0, 0, 0, 0, 0]  # (the f32 choice is the weight-stationary kernel, whose tiles the split-bf16 kernel does not have)
+            if self.mma and hit and self.plan_source != 'table' and len(hit) > 3 and hit[3] > 0:
+                hit = [0, 0, 0, 0, 0, 0, 0]  # (a TRANSFERRED f32 row naming the wave kernel is no measurement against this pipe)
         d.mma = self.mma
         if hit and os.environ.get('YM_NO_TUNED', '0') != '1':     # each matrix pipe has its own measured tile / split-K / tail choice
             self.tile, self.ksplit, self.kwaves = (hit[0], hit[1]), hit[2], (hit[3] if len(hit) > 3 else 0)
@@ -250,7 +306,9 @@ def _bind_pyramid(layer, pyr, batch, shapes, segs):
     layer.out_hw = shapes[0]
     layer.flops = 2.0 * rows * layer.cout * layer.kh * layer.kw * layer.cin
     layer.sig = f'M{rows}_N{layer.cout}_C{cin}_k{layer.kh}_s1_seg{len(segs)}_r0_L{len(shapes)}'
-    hit = _entry(layer.sig)
+    layer._shape = (rows, layer.cout, layer.k_pad // 32, len(segs))
+    hit, layer.plan_source = _entry(layer.sig, *layer._shape, with_source=True)
+    layer._hit = hit
     if hit:
         layer.tile, layer.ksplit, layer.kwaves = (hit[0], hit[1]), hit[2], 0
         layer.stages = 0
@@ -291,8 +349,28 @@ class InferEngine:
         try:
             with torch.cuda.device(device):
                 self._build()
+                if autotune_on() and os.environ.get('YM_NO_TUNED', '0') != '1':
+                    self._autotune_missing()
         finally:
             _build_mode[0] = prev
+
+    def _autotune_missing(self):
+        """YM_AUTOTUNE=1: measure the launches of this plan that have no row of their own, keep the rows (process + user cache)."""
+        have = {c.sig for c in self.convs if c.plan_source == 'table'}
+        todo = {c.sig for c in self.convs} - have
+        if not todo:
+            return
+        rows = self.autotune(iters=10, skip=have)
+        rows = {k: (v if len(v) > 7 and v[7] else v[:7]) for k, v in rows.items()}
+        tuned_table().update(rows)
+        plan_transfer._index_cache.clear()
+        for c in self.convs:
+            if c.sig in rows:
+                c.plan_source, c._hit = 'autotuned', rows[c.sig]
+        try:
+            _store_user_rows(rows)
+        except OSError as e:
+            print(f'yolact_minimal_amd: could not write {user_cache_path()}: {e}', file=sys.stderr)
 
     # ---- construction ------------------------------------------------------------------------
     def _buf(self, *shape):
@@ -576,7 +654,7 @@ class InferEngine:
             _build_mode[0] = prev
         self.retune()
 
-    def autotune(self, iters=10, verbose=False, mma=0, concurrent=False):
+    def autotune(self, iters=10, verbose=False, mma=0, concurrent=False, skip=()):
         """Time every (tile, ksplit) candidate of every distinct conv shape on this GPU; keep the fastest.
         Returns {signature: [tile_m, tile_n, ksplit, kwaves, stages, tail_tiles, tail_ksplit, grid_wgs]} = rows of the tuned table;
         the timings are left in `self.autotune_detail` = {signature: (best_us, default_us)}.  Persistent candidates (stages 4x) are
@@ -584,7 +662,8 @@ class InferEngine:
         `concurrent`: tune for THROUGHPUT with requests in flight (bench.py --inflight 2) instead of for the latency of a launch
         that has the chip to itself: every candidate is timed as two copies of the launch running side by side on two streams
         (own split-K scratch and arrival counters each); the figure is the wall time per PAIR, so a choice that wins by spreading
-        thin over all CUs (many K slices + an exchange) loses to one that does the same work with fewer resources."""
+        thin over all CUs (many K slices + an exchange) loses to one that does the same work with fewer resources.
+        `skip`: signatures (table keys) that are left as they are (tools/autotune.py --skip-known)."""
         results = {}
         self.autotune_detail = {}
         big_ws = torch.empty(1 << 28, device=self.device, dtype=torch.uint8)
@@ -648,6 +727,8 @@ class InferEngine:
         seen = {}
         for c in self.convs:
             if mma and not split_ok(c):
+                continue
+            if c.sig + (f'_mma{mma}' if mma else '') in skip:
                 continue
             if c.sig in seen:
                 c.tile, c.ksplit, c.kwaves, c.stages, c.tail, c.grid_wgs = seen[c.sig]

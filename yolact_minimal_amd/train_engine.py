@@ -11,6 +11,7 @@ RCCL) — no ATen convolution, batch-norm or pooling kernel is ever called.  The
 head outputs (matching, OHEM ranking, cross-entropy, smooth-L1, mask BCE) is `yolact_minimal_amd/loss.py`.
 """
 import ctypes
+import math
 import os
 import weakref
 
@@ -67,7 +68,23 @@ def _configure_conv(d, key, stats=False):
     """Set tile/ksplit/kwaves of a ConvDesc from the tuned table (or sweep it when YM_TUNE_TRAIN=1).  `stats`: the launch carries
     fused BatchNorm sums, which the persistent kernel does not do: `<key>_st` holds the per-item choice measured for such launches
     where the plain entry (shared with inference) selects the persistent kernel."""
-    hit = (_table().get(key + '_st') if stats else None) or _table().get(key)
+    from . import plan_transfer
+    M_rows = d.B * d.Ho * d.Wo
+    hit = None
+    if plan_transfer.mode() != 'only':
+        hit = (_table().get(key + '_st') if stats else None) or _table().get(key)
+    if hit is None and not _TUNING and plan_transfer.mode() != 'off':
+        # another --img_size / batch: the row of the nearest tuned shape of the family, re-derived for this M (plan_transfer.py);
+        # with fused statistics the `_st` family competes with the plain one, the donor nearer in M wins
+        only = plan_transfer.mode() == 'only'
+        donors = [(abs(math.log2(nb[1] / M_rows)), i, k) for i, k in enumerate(([key + '_st'] if stats else []) + [key])
+                  for nb in [plan_transfer.nearest(_table(), k, only)] if nb is not None]
+        if donors:
+            k = min(donors)[2]
+            hit, _ = plan_transfer.lookup(_table(), k, M_rows, d.Cout, d.k_pad // 32, d.nseg)
+            if hit is not None and stats and k == key and len(hit) > 4 and 42 <= hit[4] <= 48:
+                hit = list(hit[:7])
+                hit[4] = 22 if hit[4] == 42 else 23     # the persistent walker does not cover launches with fused BatchNorm sums
     if hit is None and _TUNING:
         M, nkt = d.B * d.Ho * d.Wo, d.k_pad // 32
         big = scratch(torch.device('cuda', torch.cuda.current_device()), 1 << 28)
@@ -133,7 +150,12 @@ _MSPLIT_SCALE = float(os.environ.get('YM_WGRAD_MSPLIT_SCALE', '1'))
 
 
 def _configure_wgrad(d, key):
-    hit = _table().get(key)
+    from . import plan_transfer
+    hit = _table().get(key) if plan_transfer.mode() != 'only' else None
+    if hit is None and not _TUNING:
+        p = plan_transfer.parse(key)
+        if p:
+            hit, _ = plan_transfer.lookup(_table(), key, p[1], p[2], 0)
     if hit is None and _TUNING:
         big = scratch(torch.device('cuda', torch.cuda.current_device()), 1 << 28)
         best = (1e30, 0, 2)
