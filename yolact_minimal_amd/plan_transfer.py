@@ -9,7 +9,7 @@ tuned shape of the same family is transferred:
 
 * family = same table prefix (forward / `T_` data gradient / `W_` weight gradient), filter size, stride, segment count, residual
   flag, pyramid level count and suffix (`_st`, `_tp`, `_mma3`); stems (Cin = 4) only match stems;
-* nearest = smallest |log2 M/M'| (x1.5 for a smaller donor) + 8 |log2 N/N'| + 8 |log2 C/C'| with M within 4x and N, C within 2x —
+* nearest = smallest |log2 M/M'| (x1.5 for a smaller donor) + 8 |log2 N/N'| + 8 |log2 C/C'| with M within 2.46x and N, C within 2x —
   in practice the SAME layer at the nearest measured resolution;
 * what is kept: the kernel family (tile, wave / workgroup kernel, staging ring, persistent walker); what is re-derived for the new
   M: the K split (same number of workgroups in flight as the donor launch had), the tail split (the donor's rule — the tiles of
@@ -26,6 +26,9 @@ import re
 _SIG = re.compile(r'^(T_|W_)?M(\d+)_N(\d+)_C(\d+)_k(\d+)_s(\d+)(?:_seg(\d+)_r(\d))?(_L\d+)?(_st|_tp|_mma\d)?$')
 _KS_ALLOWED = (1, 2, 3, 4, 6, 8, 12, 16, 24)
 TILE_COUNTERS = 16384        # = hip.TILE_COUNTERS (int32 arrival counters the engines allocate)
+
+M_REACH = 1.3               # |log2 M/M'| a donor may be away: 2.46x (res101 bs=8 training at 320 px, donors 2.9x away: 23.4 ms per step
+                            # against 20.9 on the planner heuristic; at 384 px, 2.0x away: 24.9 against 29.0)
 
 _index_cache = {}
 
@@ -70,7 +73,7 @@ def nearest(table, sig, exclude_exact=False):
         if exclude_exact and key == sig:
             continue
         dm, dn, dc = abs(math.log2(M / m2)), abs(math.log2(N / n2)), abs(math.log2(C / c2))
-        if dm > 2.0 or dn > 1.0 or dc > 1.0:
+        if dm > M_REACH or dn > 1.0 or dc > 1.0:
             continue
         if m2 < M:
             dm *= 1.5        # a row measured on a LARGER launch scales down (K split re-derived) better than a small launch's choice
@@ -121,8 +124,8 @@ def transfer_conv(row, M_donor, M, N, nkt, nseg=1, counters=True):
                 ts -= 1
             if ts > 1:
                 out_tail = (w % 256 or 256, ts)
-        if kw > nkt:
-            kw = max(1, min(kw, nkt))
+        if kw > nkt:                                 # K waves of the wave kernel: 1 / 2 / 4 / 8, at most one per K tile
+            kw = max(k for k in (1, 2, 4, 8) if k <= max(1, nkt))
     out = [tm, tn, out_ks, kw, st, out_tail[0], out_tail[1]]
     if g:
         out.append(g)
