@@ -294,7 +294,11 @@ def eval_loop_bench(cfg_name, img_size, device, images=40, h=480, w=640):
     def loader(n):
         return [(img, gt.clone(), gt_masks, h, w) for _ in range(n)]
     for key, kw, n in (('prep_metrics', dict(coco_api=False), images), ('prep_metrics_no_stage_fences', dict(coco_api=False, sync_stages=False), images),
-                       ('coco_api_dense_masks_over_pcie', dict(coco_api=True), max(4, images // 5)), ('coco_api_device_rle', dict(coco_api='device'), images)):
+                       ('coco_api_device_rle', dict(coco_api='device'), images), ('coco_api_dense_masks_over_pcie', dict(coco_api=True), max(4, images // 5))):
+        # (the dense branch last: a process uses ONE metric branch, and after the 123 MB pageable D2H copies of the dense one the small
+        #  host reads of the next leg were 3x slower -- 1.6 instead of 0.47 ms of metric stage for the device-RLE leg in one process)
+        if os.environ.get('YM_EVAL_LEGS') and key not in os.environ['YM_EVAL_LEGS'].split(','):
+            continue
         L.eval_loop(net, cfg, loader(3), **kw)                        # warm-up (plans, graph capture, allocator)
         _, mj, seen, secs = L.eval_loop(net, cfg, loader(n), **kw)
         row = dict(img_s=round(n / secs, 1), ms_per_img=round(secs / n * 1e3, 3), images=n, images_with_detections=seen)
@@ -305,7 +309,7 @@ def eval_loop_bench(cfg_name, img_size, device, images=40, h=480, w=640):
             row['records_per_image'] = round(len(mj.mask_data) / max(1, n), 1)
         out[key] = row
     # what bounds the dense branch: the D2H of the image's masks (pageable destination, as `.cpu()` allocates it)
-    n_det = out['coco_api_dense_masks_over_pcie'].get('records_per_image') or 100
+    n_det = out.get('coco_api_dense_masks_over_pcie', {}).get('records_per_image') or 100
     m = torch.zeros(int(round(n_det)), h, w, device=device)
     m.cpu()
     torch.cuda.synchronize()
@@ -706,8 +710,25 @@ def spawn_ranks(n):
 
 def main():
     args = parse()
+    if args.leg == 'eval_loop':
+        torch.cuda.set_device(0)
+        if os.environ.get('YM_GC_OFF') == '1':        # (experiment: the collector off altogether)
+            import gc
+            gc.disable()
+        else:                                          # the launcher's process policy (dropin/run.py::host_gc_policy; YM_DROPIN_GC=0: defaults)
+            sys.path.insert(0, os.path.join(REPO, 'dropin'))
+            import run as dropin_run
+            dropin_run.host_gc_policy()
+        fd = os.dup(1)
+        os.dup2(2, 1)
+        out = eval_loop_bench(args.cfg, args.img_size, torch.device('cuda', 0))
+        os.write(fd, (json.dumps(out) + '\n').encode())
+        return
     if args.leg == 'train_reference_loop':
         torch.cuda.set_device(0)
+        sys.path.insert(0, os.path.join(REPO, 'dropin'))
+        import run as dropin_run
+        dropin_run.host_gc_policy()                    # (what `dropin/run.py train.py` does before the script; YM_DROPIN_GC=0: defaults)
         fd = os.dup(1)
         os.dup2(2, 1)
         out = train_reference_loop_bench(args.cfg, args.img_size, args.train_batch, args.train_steps, 2, 0, torch.device('cuda', 0))
@@ -920,7 +941,16 @@ def main():
                     extra['other_sizes'] = dict(error=f'{type(e).__name__}: {e}'[:400])
             if args.batch == 1 and not args.no_post:
                 try:
-                    extra['eval_loop'] = eval_loop_bench(args.cfg, args.img_size, device)
+                    # a process of its own, as `dropin/run.py eval.py` is one (GPU_MAX_HW_QUEUES=8 like the launcher exports for eval.py):
+                    # inside this process, after the pipelines / engines of the other legs, one of the loop's legs picks up ~2 ms of
+                    # host-side allocator / wait time per image, a different one from run to run (283 vs 171 img/s for the same loop)
+                    import subprocess
+                    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+                    env['GPU_MAX_HW_QUEUES'] = '8'
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), '--leg', 'eval_loop', '--cfg', args.cfg, '--img_size',
+                                        str(args.img_size)], env=env, capture_output=True, text=True, timeout=900)
+                    extra['eval_loop'] = json.loads(r.stdout.strip().splitlines()[-1])
+                    extra['eval_loop']['process'] = 'own (as dropin/run.py eval.py)'
                 except Exception as e:
                     extra['eval_loop'] = dict(error=f'{type(e).__name__}: {e}'[:400])
             extra['train_aug'] = train_aug_bench(device, cpu=not args.no_cpu_baseline)

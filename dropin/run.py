@@ -17,7 +17,6 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 
 
-
 def hw_queues_for(script):
     """ROCm multiplexes HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable when the runtime
     starts, i.e. before the script's `import torch` touches HIP.  Serving (eval.py / detect.py: requests in flight on separate
@@ -27,6 +26,24 @@ def hw_queues_for(script):
     with 4 (profiles/r06_reference_loop_timings.txt).  An exported GPU_MAX_HW_QUEUES always wins."""
     name = os.path.basename(script)
     return '8' if name.startswith(('eval', 'detect')) else None
+
+
+def host_gc_policy():
+    """The reference's loops build a few hundred small containers per image (eval.py:59-67: two record dicts per detection kept in
+    `MakeJson`; `APDataObject` points; per-step loss lists in train.py).  CPython's generational collector answers a growing set of
+    survivors with FULL collections, each one a walk over the whole heap — mostly torch's import-time objects — which at 3 ms of
+    device work per image is no longer noise: the `--coco_api` loop with device RLE ran at 211-246 img/s with the default policy
+    and 344 with the collector off (`YM_GC_OFF=1 python bench.py --leg eval_loop`).  So, once the imports are done: collect, move
+    what exists to the permanent generation (`gc.freeze`: never scanned again) and let the young generation fill further before a
+    pass.  Nothing is leaked or disabled; `YM_DROPIN_GC=0` keeps the interpreter's defaults."""
+    if os.environ.get('YM_DROPIN_GC', '1') == '0':
+        return
+    import gc
+    import torch  # noqa: F401  (the heap worth freezing; GPU_MAX_HW_QUEUES is exported before this line)
+    import yolact_minimal_amd.modules.yolact  # noqa: F401
+    gc.collect()
+    gc.freeze()
+    gc.set_threshold(20000, 20, 20)
 
 
 def main():
@@ -40,6 +57,7 @@ def main():
     rest = [p for p in sys.path if os.path.abspath(p or os.getcwd()) not in (HERE, REPO, checkout)]
     sys.path[:] = [HERE, REPO, checkout] + rest
     sys.argv = [script] + sys.argv[2:]
+    host_gc_policy()
     runpy.run_path(script, run_name='__main__')
 
 

@@ -1323,3 +1323,39 @@ def test_side_stream_gradients_equal_single_stream(cfg_name, fused_head, monkeyp
     # (AdamW normalises every element's update by its own running |g|: where |g| ~ 1e-9 the fp64-atomics noise of the statistics
     # decides the update's size, a few 1e-6 after two steps; SGD's update is linear in g)
     torch.testing.assert_close(ref.opt.flat, tst.opt.flat, rtol=1e-4, atol=2e-5 if cfg_name.startswith('swin') else 1e-6)
+
+
+def test_autotune_on_first_use_measures_training_launches_into_the_user_cache(tmp_path, monkeypatch):
+    """YM_AUTOTUNE=1 (off by default): a training launch whose shape has no row — forward, data gradient, weight gradient — is swept
+    inline on first use and the three rows are written through to the per-user cache; gradients still match autograd on the CPU."""
+    import json
+    from yolact_minimal_amd import engine as E, train_engine as T
+    from yolact_minimal_amd.train_engine import ConvBias
+    cache = tmp_path / 'rows.json'
+    monkeypatch.setenv('YM_AUTOTUNE', '1')
+    monkeypatch.setenv('YM_TUNED_CACHE', str(cache))
+    saved, E._tuned = E._tuned, None
+    T.tuned_table_changed()
+    try:
+        cin, cout, k, hw = 96, 160, 3, 11
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(2, cin, hw, hw, generator=g)
+        w = torch.randn(cout, cin, k, k, generator=g) * (1 / (cin * k * k) ** 0.5)
+        b = torch.randn(cout, generator=g) * 0.1
+        xc, wc, bc = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+        y = F.relu(F.conv2d(xc, wc, bc, 1, 1))
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy)
+        xg, wg, bg = _nhwc(x).to(DEV).requires_grad_(), w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+        yg = ConvBias.apply(xg, wg, bg, 1, 1, 1, cout, None)
+        yg.backward(_nhwc(gy).to(DEV))
+        torch.cuda.synchronize()
+        torch.testing.assert_close(_nchw(yg).cpu(), y.detach(), rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(_nchw(xg.grad).cpu(), xc.grad, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(wg.grad.cpu(), wc.grad, rtol=1e-4, atol=2e-5)
+        rows = json.load(open(cache))
+        M = 2 * hw * hw
+        assert {f'M{M}_N{cout}_C{cin}_k3_s1_seg1_r0', f'T_M{M}_N{cin}_C{cout}_k3_s1', f'W_M{M}_N{cout}_C{cin}_k3_s1'} <= set(rows), sorted(rows)
+    finally:
+        E._tuned = saved
+        T.tuned_table_changed()

@@ -35,6 +35,26 @@ _TUNING = os.environ.get('YM_TUNE_TRAIN', '0') == '1'     # sweep unseen shapes 
 _new_entries = {}
 
 
+def _tuning():
+    """Inline sweeps: tools/autotune_train.py (YM_TUNE_TRAIN=1 at import) or the opt-in tune-on-first-use mode (YM_AUTOTUNE=1, read
+    per call like engine.autotune_on)."""
+    return _TUNING or os.environ.get('YM_AUTOTUNE', '0') == '1'
+
+
+def _remember(key, hit):
+    """A row the inline sweep measured: kept for tools/autotune_train.py (dump_new_entries) and, with YM_AUTOTUNE=1, written through
+    to the per-user cache that later processes overlay on the shipped table (engine.tuned_table)."""
+    _table()[key] = hit
+    _new_entries[key] = hit
+    from .engine import autotune_on, _store_user_rows, user_cache_path
+    if autotune_on():
+        try:
+            _store_user_rows({key: hit})
+        except OSError as e:
+            import sys
+            print(f'yolact_minimal_amd: could not write {user_cache_path()}: {e}', file=sys.stderr)
+
+
 def train_mma():
     return int(os.environ.get('YM_TRAIN_MMA', '0') or 0)
 
@@ -73,7 +93,7 @@ def _configure_conv(d, key, stats=False):
     hit = None
     if plan_transfer.mode() != 'only':
         hit = (_table().get(key + '_st') if stats else None) or _table().get(key)
-    if hit is None and not _TUNING and plan_transfer.mode() != 'off':
+    if hit is None and not _tuning() and plan_transfer.mode() != 'off':
         # another --img_size / batch: the row of the nearest tuned shape of the family, re-derived for this M (plan_transfer.py);
         # with fused statistics the `_st` family competes with the plain one, the donor nearer in M wins
         only = plan_transfer.mode() == 'only'
@@ -85,7 +105,7 @@ def _configure_conv(d, key, stats=False):
             if hit is not None and stats and k == key and len(hit) > 4 and 42 <= hit[4] <= 48:
                 hit = list(hit[:7])
                 hit[4] = 22 if hit[4] == 42 else 23     # the persistent walker does not cover launches with fused BatchNorm sums
-    if hit is None and _TUNING:
+    if hit is None and _tuning():
         M, nkt = d.B * d.Ho * d.Wo, d.k_pad // 32
         big = scratch(torch.device('cuda', torch.cuda.current_device()), 1 << 28)
         d.tile_counters = _tile_counters(torch.device('cuda', torch.cuda.current_device()))
@@ -119,8 +139,7 @@ def _configure_conv(d, key, stats=False):
             if t < best[0] * 0.98:
                 best = (t, tile, ks, kwv, stg, tail)
         hit = [best[1][0], best[1][1], best[2], best[3], best[4], best[5][0], best[5][1]]
-        _table()[key] = hit
-        _new_entries[key] = hit
+        _remember(key, hit)
     if hit is not None:
         d.tile_m, d.tile_n, d.ksplit = hit[0], hit[1], hit[2]
         d.kwaves = hit[3] if len(hit) > 3 else 0
@@ -152,11 +171,11 @@ _MSPLIT_SCALE = float(os.environ.get('YM_WGRAD_MSPLIT_SCALE', '1'))
 def _configure_wgrad(d, key):
     from . import plan_transfer
     hit = _table().get(key) if plan_transfer.mode() != 'only' else None
-    if hit is None and not _TUNING:
+    if hit is None and not _tuning():
         p = plan_transfer.parse(key)
         if p:
             hit, _ = plan_transfer.lookup(_table(), key, p[1], p[2], 0)
-    if hit is None and _TUNING:
+    if hit is None and _tuning():
         big = scratch(torch.device('cuda', torch.cuda.current_device()), 1 << 28)
         best = (1e30, 0, 2)
         tbn = 64 if d.Cout_real <= 64 else 128
@@ -178,8 +197,7 @@ def _configure_wgrad(d, key):
                 if t < best[0] * 0.98:
                     best = (t, ms, nb)
         hit = [best[1], best[2]]
-        _table()[key] = hit
-        _new_entries[key] = hit
+        _remember(key, hit)
     if hit is not None:
         d.msplit = hit[0]
         d.lds_buffers = hit[1] if len(hit) > 1 else 2

@@ -14,6 +14,7 @@ The only host<->device synchronisation is one 4-byte read of the detection count
 (the reference's boolean-mask gathers synchronise several times per call).
 """
 import ctypes
+import os
 
 import torch
 
