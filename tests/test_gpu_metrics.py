@@ -46,7 +46,7 @@ def test_prep_metrics_matches_reference_golden(case):
     assert row2[1:] == [round(v, 2) for v in GOLD[f'c{case}_map_box']] and row3[1:] == [round(v, 2) for v in GOLD[f'c{case}_map_mask']]
 
 
-@pytest.mark.parametrize('n,g,h,w', [(100, 20, 480, 640), (130, 150, 61, 67), (1, 1, 5, 3), (3, 2, 544, 544)])
+@pytest.mark.parametrize('n,g,h,w', [(100, 20, 480, 640), (130, 150, 61, 67), (1, 1, 5, 3), (3, 2, 544, 544), (7, 5, 100, 100), (9, 4, 768, 1024)])
 def test_mask_iou_full_size_and_edges(n, g, h, w):
     """BASELINE-size masks (100 x 480 x 640), more than one 128-row group on both sides, odd P (unaligned rows), empty masks
     (0/0 -> NaN): bit-identical to the fp32 matmul of the oracle."""

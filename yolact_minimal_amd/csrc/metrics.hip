@@ -8,82 +8,86 @@
 
 namespace {
 
-constexpr int CHUNK = 1024;            // pixels per workgroup pass = 16 x 64-bit words per mask row (2 x 17 KB of LDS)
-constexpr int WORDS = CHUNK / 64;
+// pixels per workgroup pass = SEGS x 256 (4 x SEGS 64-bit words per mask row; 2 x 128 rows of them in LDS).  The host picks SEGS so
+// that the chunks of a row fill the 256 CUs in whole rounds (pick_segs): 480x640 masks = 300 chunks of 1024 pixels were 1.17 rounds
+// (31.4 us for 100 + 15 masks), 240 chunks of 1280 are one (26.2 us).
 constexpr int MAXR = 128;              // rows of each side held in LDS at once
+constexpr int RPI = 4;                 // rows a wave has in flight per iteration of the packing pass
 
 // Bits of a mask-row chunk: lane l of a 256-pixel segment holds pixels 4l..4l+3, one ballot per component = four 64-bit
 // words.  The bit order inside a chunk is a fixed permutation of the pixel order, the same for both operands, so
 // popcount(a & b) is unchanged.
 // grid: (pixel chunks, groups of 128 gt rows).  Every workgroup writes its own partial counts inter[chunk][n][g], area_a[chunk][n],
 // area_b[chunk][g] with plain stores (global atomics were the bottleneck: 1500 per workgroup); the finalize kernel sums the chunks.
+template <int SEGS>
 __global__ __launch_bounds__(512) void k_mask_inter(const float* __restrict__ A, int n, const float* __restrict__ Bm, int g, long long P,
                                                     int* __restrict__ inter, int* __restrict__ area_a, int* __restrict__ area_b) {
+    constexpr int CHUNK = SEGS * 256, WORDS = SEGS * 4;
     __shared__ unsigned long long sa[MAXR][WORDS + 1];
     __shared__ unsigned long long sb[MAXR][WORDS + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const long long p0 = (long long)blockIdx.x * CHUNK;
     const int g0 = blockIdx.y * MAXR, gn = min(MAXR, g - g0);
-    const bool aligned = (P & 3) == 0;         // float4 loads need 16-byte aligned rows
+    const bool fast = (P & 3) == 0 && p0 + CHUNK <= P;     // float4 loads need 16-byte aligned rows and a whole chunk
     inter += (size_t)blockIdx.x * n * g;
     area_a += (size_t)blockIdx.x * n;
     area_b += (size_t)blockIdx.x * g;
     for (int a0 = 0; a0 < n; a0 += MAXR) {
         const int an = min(MAXR, n - a0);
         __syncthreads();
-        // pack rows: one wave takes a whole row chunk (CHUNK/256 float4 loads per lane issued back to back, two rows per
-        // iteration = 8 independent 1 KB requests in flight per wave: the pass is HBM-latency bound otherwise)
-        constexpr int SEGS = CHUNK / 256;
+        // pack rows: one wave takes a whole row chunk.  The pass is HBM-latency bound, so on the fast path (16-byte aligned rows,
+        // a whole chunk inside the row: every chunk of a 480x640 mask) a wave requests RPI rows -- CHUNK/256 float4 loads per lane
+        // and row -- before it turns the first one into ballots; lane q < WORDS keeps word q, one LDS store per row.
         const int rows = an + (a0 == 0 ? gn : 0);
-        for (int r = wave; r < rows; r += 2 * nw) {
-            unsigned long long w[2][SEGS][4];
+        if (fast) {
+            for (int r = wave; r < rows; r += RPI * nw) {
+                f32x4 v[RPI][SEGS];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int rr = r + u * nw;
-                if (rr >= rows) continue;
-                const float* row = rr < an ? A + (size_t)(a0 + rr) * P : Bm + (size_t)(g0 + rr - an) * P;
-                if (aligned) {
-                    f32x4 v[SEGS];
+                for (int u = 0; u < RPI; ++u) {
+                    const int rr = min(r + u * nw, rows - 1);       // (past the end: the last row again, not used)
+                    const float* row = (rr < an ? A + (size_t)(a0 + rr) * P : Bm + (size_t)(g0 + rr - an) * P) + p0 + 4 * lane;
 #pragma unroll
-                    for (int sg = 0; sg < SEGS; ++sg) {
-                        const long long p = p0 + sg * 256 + 4 * lane;
-                        v[sg] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (p + 3 < P) v[sg] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + p));
-                        else {
+                    for (int sg = 0; sg < SEGS; ++sg) v[u][sg] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + sg * 256));
+                }
 #pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (p + e < P) v[sg][e] = row[p + e];
+                for (int u = 0; u < RPI; ++u) {
+                    const int rr = r + u * nw;
+                    if (rr < rows) {
+                        unsigned long long mine = 0;
+                        int c = 0;
+#pragma unroll
+                        for (int sg = 0; sg < SEGS; ++sg)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const unsigned long long w = __ballot(v[u][sg][e] != 0.f);
+                                mine = lane == sg * 4 + e ? w : mine;
+                                c += __popcll(w);
+                            }
+                        const bool is_a = rr < an;
+                        if (lane < WORDS) (is_a ? sa[rr] : sb[rr - an])[lane] = mine;
+                        // areas (once per row: a rows only from the first gt group, gt rows only from the first a pass)
+                        if (lane == 0) {
+                            if (is_a) { if (blockIdx.y == 0) area_a[a0 + rr] = c; }
+                            else area_b[g0 + rr - an] = c;
                         }
                     }
-#pragma unroll
-                    for (int sg = 0; sg < SEGS; ++sg)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) w[u][sg][e] = __ballot(v[sg][e] != 0.f);
-                } else {
-#pragma unroll
-                    for (int sg = 0; sg < SEGS; ++sg)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const long long p = p0 + sg * 256 + e * 64 + lane;
-                            w[u][sg][e] = __ballot(p < P && row[p] != 0.f);
-                        }
+                    __builtin_amdgcn_sched_barrier(0);    // (row by row: the ballots of a row are wave-uniform SGPR pairs)
                 }
             }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int rr = r + u * nw;
-                if (rr >= rows) continue;
+        } else {
+            // the last, partial chunk of a row / rows that are not 16-byte aligned: pixel by pixel, one row per wave and iteration
+            for (int rr = wave; rr < rows; rr += nw) {
                 const bool is_a = rr < an;
-                unsigned long long* dst = is_a ? sa[rr] : sb[rr - an];
+                const float* row = is_a ? A + (size_t)(a0 + rr) * P : Bm + (size_t)(g0 + rr - an) * P;
+                unsigned long long mine = 0;
                 int c = 0;
-#pragma unroll
-                for (int sg = 0; sg < SEGS; ++sg)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (lane == sg * 4 + e) dst[sg * 4 + e] = w[u][sg][e];
-                        c += __popcll(w[u][sg][e]);
-                    }
-                // areas (once per row: a rows only from the first gt group, gt rows only from the first a pass)
+                for (int q = 0; q < WORDS; ++q) {
+                    const long long p = p0 + q * 64 + lane;
+                    const unsigned long long w = __ballot(p < P && row[p] != 0.f);
+                    mine = lane == q ? w : mine;
+                    c += __popcll(w);
+                }
+                if (lane < WORDS) (is_a ? sa[rr] : sb[rr - an])[lane] = mine;
                 if (lane == 0) {
                     if (is_a) { if (blockIdx.y == 0) area_a[a0 + rr] = c; }
                     else area_b[g0 + rr - an] = c;
@@ -101,16 +105,19 @@ __global__ __launch_bounds__(512) void k_mask_inter(const float* __restrict__ A,
     }
 }
 
-// sum the per-chunk partials (exact integers) and apply the reference's formula; 64 pairs x 4 chunk slices per workgroup
-__global__ __launch_bounds__(256) void k_mask_iou_finalize(const int* __restrict__ inter, const int* __restrict__ area_a,
-                                                           const int* __restrict__ area_b, int chunks, int n, int g, float* __restrict__ iou) {
-    __shared__ int s_i[4][64], s_a[4][64], s_b[4][64];
+// sum the per-chunk partials (exact integers) and apply the reference's formula; 64 pairs x FSL chunk slices per workgroup (the
+// slices' loads are independent: 4 slices took 16.5 us for 300 chunks -- a serial chain of 75 L2 round trips per thread)
+constexpr int FSL = 16;
+__global__ __launch_bounds__(64 * FSL) void k_mask_iou_finalize(const int* __restrict__ inter, const int* __restrict__ area_a,
+                                                                const int* __restrict__ area_b, int chunks, int n, int g, float* __restrict__ iou) {
+    __shared__ int s_i[FSL][64], s_a[FSL][64], s_b[FSL][64];
     const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
     int it = 0, aa = 0, ab = 0;
     if (e < n * g) {
         const int i = e / g, j = e - i * g;
-        for (int c = sl; c < chunks; c += 4) {
+#pragma unroll 4
+        for (int c = sl; c < chunks; c += FSL) {
             it += inter[(size_t)c * n * g + e];
             aa += area_a[(size_t)c * n + i];
             ab += area_b[(size_t)c * g + j];
@@ -119,9 +126,10 @@ __global__ __launch_bounds__(256) void k_mask_iou_finalize(const int* __restrict
     s_i[sl][lane] = it; s_a[sl][lane] = aa; s_b[sl][lane] = ab;
     __syncthreads();
     if (sl == 0 && e < n * g) {
-        const float fi = (float)(s_i[0][lane] + s_i[1][lane] + s_i[2][lane] + s_i[3][lane]);
-        const float fa = (float)(s_a[0][lane] + s_a[1][lane] + s_a[2][lane] + s_a[3][lane]);
-        const float fb = (float)(s_b[0][lane] + s_b[1][lane] + s_b[2][lane] + s_b[3][lane]);
+        int ti = 0, ta = 0, tb = 0;
+#pragma unroll
+        for (int q = 0; q < FSL; ++q) { ti += s_i[q][lane]; ta += s_a[q][lane]; tb += s_b[q][lane]; }
+        const float fi = (float)ti, fa = (float)ta, fb = (float)tb;
         iou[e] = __fdiv_rn(fi, (fa + fb) - fi);          // inter / ((area1.t() + area2) - inter); 0/0 -> NaN like the reference
     }
 }
@@ -174,8 +182,22 @@ __global__ __launch_bounds__(128) void k_match_detections(const float* __restric
 
 }  // namespace
 
+// 256-pixel segments per chunk: the choice with the fewest (rounds over 256 CUs) x (work per chunk); ties go to the larger chunk
+// (fewer partial counts for the finalize pass)
+static int pick_segs(long long P) {
+    int best = 4;
+    long long best_cost = -1;
+    for (int sg = 3; sg <= 5; ++sg) {
+        const long long chunks = (P + sg * 256 - 1) / (sg * 256);
+        const long long cost = ((chunks + 255) / 256) * sg;
+        if (best_cost < 0 || cost <= best_cost) { best = sg; best_cost = cost; }
+    }
+    return best;
+}
+
 extern "C" size_t ym_mask_iou_workspace_bytes(int n, int g, int64_t P) {
-    const size_t chunks = (size_t)((P + CHUNK - 1) / CHUNK);
+    const int chunk = pick_segs(P) * 256;
+    const size_t chunks = (size_t)((P + chunk - 1) / chunk);
     return chunks * ((size_t)n * g + n + g) * sizeof(int) + 256;
 }
 
@@ -186,13 +208,16 @@ extern "C" int ym_mask_iou(const float* masks_a, int n, const float* masks_b, in
     YM_REQUIRE((long long)n * g < (1ll << 24), "mask_iou: n*g too large");
     if (workspace_bytes < ym_mask_iou_workspace_bytes(n, g, P)) { ym_set_error("mask_iou: workspace too small"); return YM_ENOSPC; }
     hipStream_t st = (hipStream_t)s;
-    const int chunks = (int)((P + CHUNK - 1) / CHUNK);
+    const int segs = pick_segs(P), chunk = segs * 256;
+    const int chunks = (int)((P + chunk - 1) / chunk);
     int* inter = (int*)workspace;
     int* area_a = inter + (size_t)chunks * n * g;
     int* area_b = area_a + (size_t)chunks * n;
     const dim3 grid((unsigned)chunks, (unsigned)((g + MAXR - 1) / MAXR));
-    hipLaunchKernelGGL(k_mask_inter, grid, dim3(512), 0, st, masks_a, n, masks_b, g, (long long)P, inter, area_a, area_b);
-    hipLaunchKernelGGL(k_mask_iou_finalize, dim3((n * g + 63) / 64), dim3(256), 0, st, inter, area_a, area_b, chunks, n, g, iou);
+    if (segs == 3) hipLaunchKernelGGL(k_mask_inter<3>, grid, dim3(512), 0, st, masks_a, n, masks_b, g, (long long)P, inter, area_a, area_b);
+    else if (segs == 4) hipLaunchKernelGGL(k_mask_inter<4>, grid, dim3(512), 0, st, masks_a, n, masks_b, g, (long long)P, inter, area_a, area_b);
+    else hipLaunchKernelGGL(k_mask_inter<5>, grid, dim3(512), 0, st, masks_a, n, masks_b, g, (long long)P, inter, area_a, area_b);
+    hipLaunchKernelGGL(k_mask_iou_finalize, dim3((n * g + 63) / 64), dim3(64 * FSL), 0, st, inter, area_a, area_b, chunks, n, g, iou);
     return ym_check_launch("mask_iou");
 }
 
