@@ -654,7 +654,7 @@ class InferEngine:
             _build_mode[0] = prev
         self.retune()
 
-    def autotune(self, iters=10, verbose=False, mma=0, concurrent=False, skip=()):
+    def autotune(self, iters=10, verbose=False, mma=0, concurrent=False, skip=(), cus=256):
         """Time every (tile, ksplit) candidate of every distinct conv shape on this GPU; keep the fastest.
         Returns {signature: [tile_m, tile_n, ksplit, kwaves, stages, tail_tiles, tail_ksplit, grid_wgs]} = rows of the tuned table;
         the timings are left in `self.autotune_detail` = {signature: (best_us, default_us)}.  Persistent candidates (stages 4x) are
@@ -663,7 +663,8 @@ class InferEngine:
         that has the chip to itself: every candidate is timed as two copies of the launch running side by side on two streams
         (own split-K scratch and arrival counters each); the figure is the wall time per PAIR, so a choice that wins by spreading
         thin over all CUs (many K slices + an exchange) loses to one that does the same work with fewer resources.
-        `skip`: signatures (table keys) that are left as they are (tools/autotune.py --skip-known)."""
+        `skip`: signatures (table keys) that are left as they are (tools/autotune.py --skip-known).
+        `cus`: compute units the launches can use (a CU-masked stream, cu_mask.py: the tail-split candidates follow it)."""
         results = {}
         self.autotune_detail = {}
         big_ws = torch.empty(1 << 28, device=self.device, dtype=torch.uint8)
@@ -762,8 +763,8 @@ class InferEngine:
                             cands.append(((tm, tn), ks, 0, 43, (0, 0)))    # persistent kernel (conv_persist.hip), ring of 3 / 6
                             cands.append(((tm, tn), ks, 0, 46, (0, 0)))
                 # workgroup-quantisation fix: split the tiles of the last partial round (over 256 CUs x 1 or 2 workgroups)
-                if not c.stem and d.nseg == 1 and d.tile_counters and 256 < wgs <= hip.TILE_COUNTERS:
-                    for r in sorted({wgs % 256, wgs % 512} - {0}):
+                if not c.stem and d.nseg == 1 and d.tile_counters and cus < wgs <= hip.TILE_COUNTERS:
+                    for r in sorted({wgs % cus, wgs % (2 * cus)} - {0}):
                         for ts in (2, 3, 4, 6, 8):
                             if ts * 2 > nkt or r * ts > 2048:
                                 continue
@@ -791,8 +792,8 @@ class InferEngine:
                                 wave_cands.append(((tm, tn), 1, kwv, 22, (0, 0), 0))
                                 wave_cands += [((tm, tn), 1, kwv, 22, (0, 0), wpb) for wpb in (1, 2) if wpb >= kwv and kwv < 4]
                     tiles32 = -(-M // 32) * -(-d.Cout // 32)
-                    if 256 < tiles32 <= hip.TILE_COUNTERS and d.nseg == 1 and d.tile_counters:
-                        wave_cands += [((32, 32), 1, 4, 22, (tiles32 % 256 or 256, ts), 0) for ts in (4, 6, 8) if ts * 2 <= nkt]
+                    if cus < tiles32 <= hip.TILE_COUNTERS and d.nseg == 1 and d.tile_counters:
+                        wave_cands += [((32, 32), 1, 4, 22, (tiles32 % cus or cus, ts), 0) for ts in (4, 6, 8) if ts * 2 <= nkt]
             if mma:                                          # split-bf16: register staging with one (0) or two (3) register sets
                 cands = sorted({(tile, ks, kwv, st, tail) for tile, ks, kwv, stg, tail in cands for st in ((0, 3) if kwv == 0 else (0,))})
             best = (base, (0, 0), 0, 0, 0, (0, 0), 0)
