@@ -26,6 +26,11 @@ db=$(YM_CONV_MMA=3 run infer_bs8_bf16x3 $BENCH --batch 8 --steps 20 --warmup 5)
 [ -n "$db" ] && python $R/tools/prof_summary.py "$db" "$OUT/${TAG}_infer_bs8_res101_bf16x3_kernel_stats.md" > /dev/null
 db=$(run infer_bs8 $BENCH --batch 8 --steps 20 --warmup 5)
 [ -n "$db" ] && python $R/tools/prof_summary.py "$db" "$OUT/${TAG}_infer_bs8_res101_kernel_stats.md" > /dev/null
+# BASELINE configs 2 and 5: res50_coco / swin_tiny_coco bs=8 inference, one batch at a time
+db=$(run infer_bs8_res50 $BENCH --cfg res50_coco --batch 8 --steps 20 --warmup 5)
+[ -n "$db" ] && python $R/tools/prof_summary.py "$db" "$OUT/${TAG}_infer_bs8_res50_kernel_stats.md" > /dev/null
+db=$(run infer_bs8_swin $BENCH --cfg swin_tiny_coco --batch 8 --steps 20 --warmup 5)
+[ -n "$db" ] && python $R/tools/prof_summary.py "$db" "$OUT/${TAG}_infer_bs8_swin_kernel_stats.md" > /dev/null
 db=$(run train python $R/tools/train_profile.py --steps 10)
 [ -n "$db" ] && python $R/tools/prof_summary.py "$db" "$OUT/${TAG}_train_res101_bs8_kernel_stats.md" > /dev/null && python $R/tools/gap_summary.py "$db" 30 k_sgd > "$OUT/${TAG}_train_res101_bs8_gaps.txt"
 # the reference's own training loop (torch DDP + torch.optim through dropin/, timer fences): tools/ref_loop_profile.py
