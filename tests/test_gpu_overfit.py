@@ -1,0 +1,50 @@
+"""Long-run behaviour of the training + evaluation path: 600 steps on a 16-picture synthetic shapes dataset, then the mAP of the
+training pictures through `nms` -> `after_nms` -> `prep_metrics` -> `calc_map` — beside the REAL reference's own run of the same
+recipe (same seeded weights, pictures, batch order and schedule; `oracle/overfit_reference.py`, CPU, 5 minutes, frozen as
+tests/golden/overfit_reference_128.json).  Two fp32 implementations do not follow the same trajectory for 600 steps (discrete
+ReLU / OHEM / top-k flips feed back into the weights), so the bar is on what a user would compare: the first step's losses
+(same weights: 1e-3), the loss level at the end, and the mAP (measured: box 89.4 vs 90.1, mask 77.5 vs 76.4)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_overfit_reaches_the_reference_map(golden_dir):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tools'))
+    from overfit_demo import run
+    ref = json.load(open(os.path.join(golden_dir, 'overfit_reference_128.json')))
+    got = run(steps=ref['steps'], n_images=ref['images'], size=ref['size'], batch=ref['batch'], cfg_name=ref['cfg'], seed=ref['seed'],
+              log=lambda *_: None, log_every=10)
+    assert got['losses'][0][0] == 0 and ref['losses'][0][0] == 0
+    np.testing.assert_allclose(got['losses'][0][1], ref['losses'][0][1], rtol=1e-3)          # step 0: the same weights
+    tail = [sum(v) for s, v in got['losses'] if s >= 500]
+    ref_tail = [sum(v) for s, v in ref['losses'] if s >= 500]
+    assert all(np.isfinite(tail)) and np.median(tail) < 3 * max(np.median(ref_tail), 0.1), (tail, ref_tail)
+    assert got['images_with_detections'] == ref['images']
+    # mAP "all" and mAP@50 of both kinds, against the reference's run
+    assert abs(got['box_map'][0] - ref['box_map'][0]) < 6 and abs(got['mask_map'][0] - ref['mask_map'][0]) < 6, (got['box_map'], got['mask_map'])
+    assert got['box_map'][1] >= ref['box_map'][1] - 5 and got['mask_map'][1] >= ref['mask_map'][1] - 5
+
+
+def test_overfit_reproduces_the_reference_dead_mask_branch(golden_dir):
+    """The same recipe at 192 px: in the REFERENCE's own run the mask branch dies at the first step (step 0 trains at the full
+    rate, train.py:103-109, on a random-init net: the prototype ReLU never fires again, the mask loss sits at ln 2 x 6.125 x the
+    crop factor = 5.6-5.7 while the other three losses fall, mask mAP 0).  The HIP path has to show the same run, not a better one."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tools'))
+    from overfit_demo import run
+    ref = json.load(open(os.path.join(golden_dir, 'overfit_reference_192.json')))
+    got = run(steps=ref['steps'], n_images=ref['images'], size=ref['size'], batch=ref['batch'], cfg_name=ref['cfg'], seed=ref['seed'],
+              log=lambda *_: None, log_every=10)
+    np.testing.assert_allclose(got['losses'][0][1], ref['losses'][0][1], rtol=1e-3)
+    plateau = np.median([v[2] for s, v in got['losses'] if s >= 100])
+    ref_plateau = np.median([v[2] for s, v in ref['losses'] if s >= 100])
+    assert 5.4 < ref_plateau < 5.9 and abs(plateau - ref_plateau) < 0.05 * ref_plateau, (plateau, ref_plateau)
+    others = np.median([v[0] + v[1] + v[3] for s, v in got['losses'] if s >= 100])
+    ref_others = np.median([v[0] + v[1] + v[3] for s, v in ref['losses'] if s >= 100])
+    assert others < 3 * ref_others + 0.1, (others, ref_others)
+    assert got['mask_map'][0] == ref['mask_map'][0] == 0.0

@@ -1,0 +1,145 @@
+"""Train -> evaluate -> mAP on a tiny synthetic dataset, all on the HIP path: the closest offline stand-in for the north star's
+acceptance line ("box / mask mAP within 0.1 of the reference on COCO val2017": no dataset and no trained weights here).
+
+What it shows: the training step (`Trainer.step`: forward, the four losses, backward, SGD with the reference's schedule,
+train.py:102-130) drives a RANDOM-INIT res50 YOLACT to a working detector on images it has seen, and the evaluation path
+(`net.eval()` forward -> `nms` -> `after_nms` -> `prep_metrics` -> `calc_map`, eval.py:36-110) reports it — i.e. the two halves
+of the path agree about boxes, classes, prototypes and coefficients beyond the per-step parity the goldens pin.
+
+Data: `--images` pictures of `--size` px with 2-3 filled shapes each (class = shape and colour: rectangle / ellipse / triangle /
+diamond, the four `CUSTOM_CLASSES` slots of `res50_custom`), on a noisy background; boxes are the shapes' tight boxes, masks their
+pixels.  Everything is seeded.
+
+    python tools/overfit_demo.py --steps 1500            # prints the loss every 100 steps and the final mAP table (JSON last)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+
+COLOURS = np.array([[1.6, -0.8, -0.8], [-0.8, 1.6, -0.8], [-0.8, -0.8, 1.6], [1.4, 1.4, -1.0]], np.float32)
+
+
+def shape_mask(kind, size, cx, cy, rx, ry):
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32)
+    dx, dy = (xx - cx) / rx, (yy - cy) / ry
+    if kind == 0:                                   # rectangle
+        return (np.abs(dx) <= 1) & (np.abs(dy) <= 1)
+    if kind == 1:                                   # ellipse
+        return dx * dx + dy * dy <= 1
+    if kind == 2:                                   # upright triangle (apex on top)
+        return (dy <= 1) & (dy >= -1) & (np.abs(dx) <= (dy + 1) / 2)
+    return np.abs(dx) + np.abs(dy) <= 1             # diamond
+
+
+def make_dataset(n_images, size, seed=0):
+    """[(image [3, S, S] float32 (already normalised), gt [n, 5] (x1 y1 x2 y2 in 0..1, class), masks [n, S, S] float32)]."""
+    rng = np.random.default_rng(seed)
+    data = []
+    for _ in range(n_images):
+        img = rng.normal(0.0, 0.25, (3, size, size)).astype(np.float32)
+        taken = np.zeros((size, size), bool)
+        gts, masks = [], []
+        for _ in range(int(rng.integers(2, 4))):
+            for _try in range(20):
+                kind = int(rng.integers(0, 4))
+                rx, ry = rng.uniform(0.09, 0.2, 2) * size
+                cx, cy = rng.uniform(rx + 2, size - rx - 2), rng.uniform(ry + 2, size - ry - 2)
+                m = shape_mask(kind, size, cx, cy, rx, ry)
+                if m.sum() > 40 and not (m & taken).any():
+                    break
+            else:
+                continue
+            taken |= m
+            ys, xs = np.nonzero(m)
+            gts.append([xs.min() / size, ys.min() / size, (xs.max() + 1) / size, (ys.max() + 1) / size, kind])
+            masks.append(m.astype(np.float32))
+            img[:, m] = COLOURS[kind][:, None] + rng.normal(0.0, 0.1, (3, int(m.sum()))).astype(np.float32)
+        data.append((torch.from_numpy(img), torch.tensor(gts, dtype=torch.float32), torch.from_numpy(np.stack(masks))))
+    return data
+
+
+def evaluate(net, cfg, data, device, size):
+    """eval.py:36-110 on the training pictures: one image at a time, fast-NMS, masks at the picture's own size."""
+    from yolact_minimal_amd.utils.common_utils import APDataObject, prep_metrics, calc_map
+    from yolact_minimal_amd.utils.output_utils import nms, after_nms
+    thres = [x / 100 for x in range(50, 100, 5)]
+    nc = len(cfg.class_names)
+    ap = {k: [[APDataObject() for _ in range(nc)] for _ in thres] for k in ('box', 'mask')}
+    net.eval()
+    found = 0
+    with torch.no_grad():
+        for img, gt, masks in data:
+            out = net(img[None].to(device))
+            ids, sc, bx, cf, pr = nms(out[0], out[1], out[2], out[3], net.anchors, cfg)
+            ids, sc, boxes_p, masks_p = after_nms(ids, sc, bx, cf, pr, size, size, cfg)
+            if ids is None:
+                continue
+            found += 1
+            prep_metrics(ap, list(ids.cpu().numpy().astype(int)), list(sc.cpu().numpy().astype(float)), boxes_p, masks_p,
+                         gt.clone().to(device), masks.to(device), size, size, thres)
+    table, row_box, row_mask = calc_map(ap, thres, nc, step=0)
+    net.train()
+    return table, row_box, row_mask, found
+
+
+def run(steps=1500, n_images=16, size=256, batch=8, cfg_name='res50_custom', seed=0, lr=None, log=print, eval_every=0, log_every=100):
+    from yolact_minimal_amd.config import build_cfg
+    from yolact_minimal_amd.modules.yolact import Yolact
+    from yolact_minimal_amd.trainer import Trainer
+    device = torch.device('cuda:0')
+    cfg = build_cfg(cfg_name, 'train', size, train_bs=batch, bs_per_gpu=batch)
+    if lr is not None:
+        cfg.lr = lr
+    torch.manual_seed(seed)
+    net = Yolact(cfg)
+    tr = Trainer(net, cfg, device)
+    data = make_dataset(n_images, size, seed)
+    imgs = torch.stack([d[0] for d in data]).to(device)
+    gts = [d[1].to(device) for d in data]
+    mks = [d[2].to(device) for d in data]
+    order = np.random.default_rng(seed + 1)
+    hist, curve = [], []
+    t0 = time.time()
+    for step in range(steps):
+        pick = order.choice(n_images, batch, replace=False)
+        losses = tr.step(imgs[pick], [gts[i] for i in pick], [mks[i] for i in pick])
+        if step % log_every == 0 or step == steps - 1:
+            vals = [round(float(l.detach()), 4) for l in losses]
+            hist.append((step, vals))
+            log(f'step {step:5d}  lr {tr.opt.lr:.5f}  loss c/b/m/s {vals}  total {sum(vals):.3f}')
+        if eval_every and step and step % eval_every == 0:
+            _, rb, rm, _ = evaluate(net, cfg, data, device, size)
+            curve.append((step, rb[1], rm[1]))
+            log(f'         box mAP {rb[1]}  mask mAP {rm[1]}')
+    torch.cuda.synchronize()
+    train_s = time.time() - t0
+    table, row_box, row_mask, found = evaluate(net, cfg, data, device, size)
+    return dict(cfg=cfg_name, size=size, images=n_images, batch=batch, steps=steps, train_s=round(train_s, 1), losses=hist,
+                box_map=row_box[1:], mask_map=row_mask[1:], images_with_detections=found, curve=curve, table=table)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--steps', type=int, default=1500)
+    ap.add_argument('--images', type=int, default=16)
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--cfg', default='res50_custom')
+    ap.add_argument('--lr', type=float, default=None)
+    ap.add_argument('--eval-every', type=int, default=0)
+    ap.add_argument('--log-every', type=int, default=100)
+    a = ap.parse_args()
+    r = run(a.steps, a.images, a.size, a.batch, a.cfg, lr=a.lr, eval_every=a.eval_every, log_every=a.log_every)
+    print(r.pop('table'))
+    print(json.dumps(r))
+
+
+if __name__ == '__main__':
+    main()
