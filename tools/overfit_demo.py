@@ -121,8 +121,13 @@ def run(steps=1500, n_images=16, size=256, batch=8, cfg_name='res50_custom', see
     torch.cuda.synchronize()
     train_s = time.time() - t0
     table, row_box, row_mask, found = evaluate(net, cfg, data, device, size)
+    # the same detector through `--traditional_nms` (greedy per-class NMS, utils/output_utils.py:84-123 + cython_nms.pyx)
+    cfg.traditional_nms = True
+    _, trad_box, trad_mask, _ = evaluate(net, cfg, data, device, size)
+    cfg.traditional_nms = False
     return dict(cfg=cfg_name, size=size, images=n_images, batch=batch, steps=steps, train_s=round(train_s, 1), losses=hist,
-                box_map=row_box[1:], mask_map=row_mask[1:], images_with_detections=found, curve=curve, table=table)
+                box_map=row_box[1:], mask_map=row_mask[1:], images_with_detections=found, curve=curve, table=table,
+                box_map_traditional_nms=trad_box[1:], mask_map_traditional_nms=trad_mask[1:])
 
 
 def main():
