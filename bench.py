@@ -573,6 +573,28 @@ def ann_to_mask_bench(device, iters=30, cpu=True):
     return out
 
 
+def train_to_map_bench():
+    """Train -> evaluate -> mAP on the synthetic shapes dataset (tools/overfit_demo.py: 600 `Trainer` steps on a random-init
+    res50_custom at 128 px, then nms -> after_nms -> prep_metrics -> calc_map on the training pictures), with the numbers of the
+    REAL reference's own run of the same recipe beside it (frozen by oracle/overfit_reference.py as a golden fixture: data, not
+    the oracle).  The offline stand-in for the north star's mAP line."""
+    sys.path.insert(0, os.path.join(REPO, 'tools'))
+    from overfit_demo import run
+    ref = json.load(open(os.path.join(REPO, 'tests', 'golden', 'overfit_reference_128.json')))
+    got = run(steps=ref['steps'], n_images=ref['images'], size=ref['size'], batch=ref['batch'], cfg_name=ref['cfg'], seed=ref['seed'],
+              log=lambda *_: None, log_every=100)
+    return dict(workload=f"{ref['cfg']} {ref['size']} px bs={ref['batch']}, {ref['steps']} steps on {ref['images']} synthetic pictures, "
+                         'scored on the same pictures (eval.py:36-110 statements)',
+                train_s=got['train_s'], steps_per_s=round(ref['steps'] / got['train_s'], 1),
+                box_map=got['box_map'][0], mask_map=got['mask_map'][0], box_map50=got['box_map'][1], mask_map50=got['mask_map'][1],
+                box_map_traditional_nms=got['box_map_traditional_nms'][0], mask_map_traditional_nms=got['mask_map_traditional_nms'][0],
+                first_step_losses=got['losses'][0][1], last_step_losses=got['losses'][-1][1],
+                reference_cpu=dict(box_map=ref['box_map'][0], mask_map=ref['mask_map'][0], box_map50=ref['box_map'][1],
+                                   mask_map50=ref['mask_map'][1], first_step_losses=ref['losses'][0][1],
+                                   last_step_losses=ref['losses'][-1][1], train_s=ref['cpu_s'],
+                                   source='tests/golden/overfit_reference_128.json (the real reference, imported, CPU)'))
+
+
 def train_bench(cfg_name, img_size, batch, steps, warmup, world, local_rank, device, barrier):
     """DDP training: one step = forward + loss + backward (+ RCCL gradient all-reduce overlapped by DDP hooks) +
     SGD step on `batch` synthetic images per GPU (targets: 4 boxes + rectangular masks per image)."""
@@ -732,6 +754,13 @@ def main():
         fd = os.dup(1)
         os.dup2(2, 1)
         out = train_reference_loop_bench(args.cfg, args.img_size, args.train_batch, args.train_steps, 2, 0, torch.device('cuda', 0))
+        os.write(fd, (json.dumps(out) + '\n').encode())
+        return
+    if args.leg == 'train_to_map':
+        torch.cuda.set_device(0)
+        fd = os.dup(1)
+        os.dup2(2, 1)
+        out = train_to_map_bench()
         os.write(fd, (json.dumps(out) + '\n').encode())
         return
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -984,6 +1013,14 @@ def main():
                     os.environ['YM_TRAIN_MMA'] = '0'
                 torch.cuda.empty_cache()
                 extra['train_bs16'] = train_bench(args.cfg, args.img_size, 16, 4, 2, 1, local_rank, device, lambda: None)
+                try:
+                    import subprocess
+                    env = {k: v for k, v in os.environ.items() if k not in ('GPU_MAX_HW_QUEUES', 'RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), '--leg', 'train_to_map'], env=env, capture_output=True,
+                                       text=True, timeout=600)
+                    extra['train_to_map'] = json.loads(r.stdout.strip().splitlines()[-1])
+                except Exception as e:
+                    extra['train_to_map'] = dict(error=f'{type(e).__name__}: {e}'[:400])
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             # the oracle's throughput depends on the thread count (128 threads on a 256-cpu shared host are SLOWER than 8: the
