@@ -588,6 +588,7 @@ def train_to_map_bench():
                 train_s=got['train_s'], steps_per_s=round(ref['steps'] / got['train_s'], 1),
                 box_map=got['box_map'][0], mask_map=got['mask_map'][0], box_map50=got['box_map'][1], mask_map50=got['mask_map'][1],
                 box_map_traditional_nms=got['box_map_traditional_nms'][0], mask_map_traditional_nms=got['mask_map_traditional_nms'][0],
+                serving_path_identical_pictures=got['serving_path_identical_pictures'], detections=got['detections'],
                 first_step_losses=got['losses'][0][1], last_step_losses=got['losses'][-1][1],
                 reference_cpu=dict(box_map=ref['box_map'][0], mask_map=ref['mask_map'][0], box_map50=ref['box_map'][1],
                                    mask_map50=ref['mask_map'][1], first_step_losses=ref['losses'][0][1],

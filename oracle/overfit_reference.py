@@ -71,7 +71,10 @@ def main():
     torch.manual_seed(args.seed)
     net = ref_yolact.Yolact(cfg)
     net.train()
-    optimizer = optim.SGD(net.parameters(), lr=cfg.lr, momentum=0.9, weight_decay=5e-4)
+    if 'res' in cfg.__class__.__name__:                                   # train.py:60-63
+        optimizer = optim.SGD(net.parameters(), lr=cfg.lr, momentum=0.9, weight_decay=5e-4)
+    else:
+        optimizer = optim.AdamW(net.parameters(), lr=cfg.lr, weight_decay=0.05)
     data = make_dataset(args.images, args.size, args.seed)
     imgs = torch.stack([d[0] for d in data])
     order = np.random.default_rng(args.seed + 1)

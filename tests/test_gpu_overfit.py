@@ -29,6 +29,9 @@ def test_overfit_reaches_the_reference_map(golden_dir):
     # mAP "all" and mAP@50 of both kinds, against the reference's run
     assert abs(got['box_map'][0] - ref['box_map'][0]) < 6 and abs(got['mask_map'][0] - ref['mask_map'][0]) < 6, (got['box_map'], got['mask_map'])
     assert got['box_map'][1] >= ref['box_map'][1] - 5 and got['mask_map'][1] >= ref['mask_map'][1] - 5
+    # ... and through the serving path (RequestPipeline, four requests in flight, hipGraph engines, batched post-processing kernels):
+    # every picture comes back with the detections of eval.py's sequential calls, bit for bit
+    assert got['serving_path_identical_pictures'] == ref['images'] and got['detections'] > 2 * ref['images'], got
     # the same trained detector through `--traditional_nms` (greedy per-class NMS; unpinned by the reference): on separated
     # objects the two suppression rules keep the same detections up to near-duplicates
     assert abs(got['box_map_traditional_nms'][0] - got['box_map'][0]) < 5 and abs(got['mask_map_traditional_nms'][0] - got['mask_map'][0]) < 5, got

@@ -89,6 +89,39 @@ def evaluate(net, cfg, data, device, size):
     return table, row_box, row_mask, found
 
 
+def serving_agrees(net, cfg, data, device, size, depth=4):
+    """The trained detector through the serving path (`RequestPipeline`: `depth` requests in flight, hipGraph engines, batched nms /
+    after_nms kernels, one pinned count read per request) against eval.py's sequential calls, picture by picture: how many pictures
+    come back with identical ids / scores / pixel boxes / masks."""
+    from yolact_minimal_amd.pipeline import RequestPipeline
+    from yolact_minimal_amd.utils.output_utils import nms, after_nms
+    net.eval()
+    same, n_det = 0, 0
+    with torch.no_grad():
+        imgs = [d[0][None].to(device).contiguous() for d in data]
+        seq = []
+        for x in imgs:
+            out = net(x)
+            seq.append(after_nms(*nms(out[0], out[1], out[2], out[3], net.anchors, cfg), size, size, cfg))
+        pipe = RequestPipeline(net, cfg, size, size, device, depth=depth, out_hw=(size, size))
+        pipe.warm_up(imgs[0], rounds=1)
+        res = []
+        for x in imgs:
+            r = pipe.submit(x)
+            if r is not None:
+                res.append(r)
+        res += [r for r in pipe.drain() if r is not None]
+    assert len(res) == len(seq), (len(res), len(seq))
+    for a, b in zip(seq, res):
+        if a[0] is None or b[0] is None:
+            same += a[0] is None and b[0] is None
+            continue
+        n_det += int(a[0].shape[0])
+        same += all(x.shape == y.shape and bool(torch.equal(x, y)) for x, y in zip(a, b))
+    net.train()
+    return same, n_det
+
+
 def run(steps=1500, n_images=16, size=256, batch=8, cfg_name='res50_custom', seed=0, lr=None, log=print, eval_every=0, log_every=100):
     from yolact_minimal_amd.config import build_cfg
     from yolact_minimal_amd.modules.yolact import Yolact
@@ -125,8 +158,10 @@ def run(steps=1500, n_images=16, size=256, batch=8, cfg_name='res50_custom', see
     cfg.traditional_nms = True
     _, trad_box, trad_mask, _ = evaluate(net, cfg, data, device, size)
     cfg.traditional_nms = False
+    same, n_det = serving_agrees(net, cfg, data, device, size)
     return dict(cfg=cfg_name, size=size, images=n_images, batch=batch, steps=steps, train_s=round(train_s, 1), losses=hist,
                 box_map=row_box[1:], mask_map=row_mask[1:], images_with_detections=found, curve=curve, table=table,
+                serving_path_identical_pictures=same, detections=n_det,
                 box_map_traditional_nms=trad_box[1:], mask_map_traditional_nms=trad_mask[1:])
 
 
@@ -138,10 +173,11 @@ def main():
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--cfg', default='res50_custom')
     ap.add_argument('--lr', type=float, default=None)
+    ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--eval-every', type=int, default=0)
     ap.add_argument('--log-every', type=int, default=100)
     a = ap.parse_args()
-    r = run(a.steps, a.images, a.size, a.batch, a.cfg, lr=a.lr, eval_every=a.eval_every, log_every=a.log_every)
+    r = run(a.steps, a.images, a.size, a.batch, a.cfg, seed=a.seed, lr=a.lr, eval_every=a.eval_every, log_every=a.log_every)
     print(r.pop('table'))
     print(json.dumps(r))
 
