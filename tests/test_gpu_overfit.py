@@ -7,7 +7,8 @@ ReLU / OHEM / top-k flips feed back into the weights), so the bar is on what a u
 seed 0: 89.4 / 77.5 vs 90.1 / 76.4; seed 1: 90.1 / 78.6 vs 81.3 / 70.9; 256 px bs=4: 87.9 / 93.3 vs 89.2 / 94.4 -- after 600 steps the
 mAP of ONE recipe moves by up to 9 points with the rounding of the implementation (seed 1) -- and within this build with the
 launch plans in force (summation order: the 256 px case scores 87.9 / 93.3 in a process of its own and 87.0 / 93.2 after the
-tests that precede it in the suite; one suite run of several put seed 1 outside an earlier 10-point bar) -- so the bar is 15 points
+tests that precede it in the suite; BatchNorm statistics are summed with fp64 atomics in no fixed order, a last-bit difference that
+reaches an fp32 mean about once in 30 runs of 600 steps: one suite run put seed 1 outside an earlier 10-point bar) -- so the bar is 15 points
 on "all" and 12 on mAP@50 (one-sided): far from what a broken path scores (the dead mask branch below: mask mAP 0)."""
 import json
 import os
