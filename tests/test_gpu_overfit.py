@@ -4,7 +4,9 @@ recipe (same seeded weights, pictures, batch order and schedule; `oracle/overfit
 tests/golden/overfit_reference_128.json).  Two fp32 implementations do not follow the same trajectory for 600 steps (discrete
 ReLU / OHEM / top-k flips feed back into the weights), so the bar is on what a user would compare: the first step's losses
 (same weights: 1e-3), the loss level at the end, and the mAP.  Measured (this build vs the reference, box / mask mAP): 128 px bs=8
-seed 0: 89.4 / 77.5 vs 90.1 / 76.4; seed 1: 90.1 / 78.6 vs 81.3 / 70.9; 256 px bs=4: 87.9 / 93.3 vs 89.2 / 94.4 -- after 600 steps the
+seed 0: 89.4 / 77.5 vs 90.1 / 76.4; seed 1: 90.1 / 78.6 vs 81.3 / 70.9; 256 px bs=4: 87.9 / 93.3 vs 89.2 / 94.4; 1400 steps (through
+the rate drop at 1200): 92.0 / 78.0 vs 92.3 / 76.4; res101_custom (not a test case): 71.1 / 62.6 vs 81.8 / 70.0; swin_tiny_coco (AdamW, DropPath; 76 of its
+80 classes have no ground truth here and score AP 0, so "all" reads 100 x 4 / 80): 4.48 / 3.85 vs 4.51 / 3.87 -- after 600 steps the
 mAP of ONE recipe moves by up to 9 points with the rounding of the implementation (seed 1) -- and within this build with the
 launch plans in force (summation order: the 256 px case scores 87.9 / 93.3 in a process of its own and 87.0 / 93.2 after the
 tests that precede it in the suite; BatchNorm statistics are summed with fp64 atomics in no fixed order, a last-bit difference that
@@ -20,7 +22,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('case', ['128', '128_seed1', '256_b4'])
+@pytest.mark.parametrize('case', ['128', '128_seed1', '256_b4', '128_1400', '128_swin'])
 def test_overfit_reaches_the_reference_map(golden_dir, case):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tools'))
     from overfit_demo import run
@@ -30,19 +32,27 @@ def test_overfit_reaches_the_reference_map(golden_dir, case):
     print(f"overfit[{case}]: box {got['box_map'][:2]} mask {got['mask_map'][:2]} serving {got['serving_path_identical_pictures']} / {ref['images']} "
           f"detections {got['detections']} last {got['losses'][-1][1]}  (reference box {ref['box_map'][:2]} mask {ref['mask_map'][:2]})")
     assert got['losses'][0][0] == 0 and ref['losses'][0][0] == 0
-    np.testing.assert_allclose(got['losses'][0][1], ref['losses'][0][1], rtol=1e-3)          # step 0: the same weights
-    tail = [sum(v) for s, v in got['losses'] if s >= 500]
-    ref_tail = [sum(v) for s, v in ref['losses'] if s >= 500]
+    # step 0: the same weights (Swin-T: DropPath draws come from the CPU generator there and from the device's here: 5 %)
+    np.testing.assert_allclose(got['losses'][0][1], ref['losses'][0][1], rtol=5e-2 if 'swin' in case else 1e-3)
+    tail = [sum(v) for s, v in got['losses'] if s >= ref['steps'] - 100]
+    ref_tail = [sum(v) for s, v in ref['losses'] if s >= ref['steps'] - 100]
     assert all(np.isfinite(tail)) and np.median(tail) < 3 * max(np.median(ref_tail), 0.1), (tail, ref_tail)
     assert got['images_with_detections'] == ref['images']
     # mAP "all" and mAP@50 of both kinds, against the reference's run
     assert abs(got['box_map'][0] - ref['box_map'][0]) < 15 and abs(got['mask_map'][0] - ref['mask_map'][0]) < 15, (got['box_map'], got['mask_map'])
+    if 'swin' in case:          # (76 empty classes scale everything by 4 / 80: the bar scales with it)
+        assert abs(got['box_map'][0] - ref['box_map'][0]) < 0.75 and abs(got['mask_map'][0] - ref['mask_map'][0]) < 0.75, (got['box_map'], got['mask_map'])
     assert got['box_map'][1] >= ref['box_map'][1] - 12 and got['mask_map'][1] >= ref['mask_map'][1] - 12, (got['box_map'], got['mask_map'])
     # ... and through the serving path (RequestPipeline, four requests in flight, hipGraph engines, batched post-processing kernels):
     # every picture comes back with the detections of eval.py's sequential calls, bit for bit
     assert got['serving_path_identical_pictures'] == ref['images'] and got['detections'] > 2 * ref['images'], got
     # the same trained detector through `--traditional_nms` (greedy per-class NMS; unpinned by the reference): on separated
     # objects the two suppression rules keep the same detections up to near-duplicates
+    # (not for the 80-class Swin-T config: the reference's fast_nms fills the 100 slots with below-threshold scores of other classes --
+    #  no second score filter after utils/output_utils.py:26-33 -- which `calc_map` counts as classes with AP 0, while traditional_nms
+    #  filters per class (:94): 88.8 / 78.7 instead of 4.4 / 3.9 on the same detector.  Both are the reference's behaviour.)
+    if 'swin' in case:
+        return
     assert abs(got['box_map_traditional_nms'][0] - got['box_map'][0]) < 5 and abs(got['mask_map_traditional_nms'][0] - got['mask_map'][0]) < 5, \
         (got['box_map'], got['box_map_traditional_nms'], got['mask_map'], got['mask_map_traditional_nms'])
 
