@@ -32,6 +32,7 @@ def evaluate(net, data, size, nc, anchors):
     ap = M.new_ap_data(nc, len(thres))
     net.eval()
     found = 0
+    n_det = [0, 0]                    # detections returned, detections above 0.3
     with torch.no_grad():
         for img, gt, masks in data:
             out = net(img[None])
@@ -42,10 +43,12 @@ def evaluate(net, data, size, nc, anchors):
             if ids is None:
                 continue
             found += 1
+            n_det[0] += len(ids)
+            n_det[1] += int((sc > 0.3).sum())
             M.prep_metrics(ap, [int(i) for i in ids], [float(s) for s in sc], boxes_p, masks_p, gt.clone(), masks, size, size, thres)
     net.train()
     res = M.calc_map(ap, thres, nc)
-    return res, found
+    return res, found, n_det
 
 
 def main():
@@ -61,9 +64,16 @@ def main():
     a.add_argument('--out', default='')
     args = a.parse_args()
     ref_config, ref_yolact, _, _ = import_reference()
-    torch.set_num_threads(8)
+    # under torch.distributed.run (gloo, CPU): train.py:76's DDP(net) over the ranks, `--batch` = train.py --train_bs (global), every
+    # rank trains its contiguous shard of the same seeded pick (DistributedSampler-style), rank 0 scores
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    torch.set_num_threads(max(1, 8 // world))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend='gloo', init_method='env://')
+    per = args.batch // world
     ns = argparse.Namespace(cfg=args.cfg, img_size=args.size, weight=None, traditional_nms=False, val_num=-1, coco_api=False,
-                            resume=None, train_bs=args.batch, bs_per_gpu=args.batch, val_interval=4000)
+                            resume=None, train_bs=args.batch, bs_per_gpu=args.batch // world, val_interval=4000)
     ns.mode, ns.cuda, ns.gpu_id = 'train', False, None
     cfg = getattr(ref_config, args.cfg)(ns)
     if args.lr is not None:
@@ -71,6 +81,9 @@ def main():
     torch.manual_seed(args.seed)
     net = ref_yolact.Yolact(cfg)
     net.train()
+    module = net
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(net, broadcast_buffers=True)       # train.py:76 (CPU: no device ids)
     if 'res' in cfg.__class__.__name__:                                   # train.py:60-63
         optimizer = optim.SGD(net.parameters(), lr=cfg.lr, momentum=0.9, weight_decay=5e-4)
     else:
@@ -80,7 +93,7 @@ def main():
     order = np.random.default_rng(args.seed + 1)
     hist, t0 = [], time.time()
     for step in range(args.steps):
-        pick = order.choice(args.images, args.batch, replace=False)
+        pick = order.choice(args.images, args.batch, replace=False)[rank * per:(rank + 1) * per]
         if cfg.warmup_until > 0 and step <= cfg.warmup_until:
             for g in optimizer.param_groups:
                 g['lr'] = (cfg.lr - cfg.warmup_init) * (step / cfg.warmup_until) + cfg.warmup_init
@@ -92,18 +105,24 @@ def main():
         optimizer.zero_grad()
         total.backward()
         optimizer.step()
-        if step % args.log_every == 0 or step == args.steps - 1:
+        if rank == 0 and (step % args.log_every == 0 or step == args.steps - 1):
             vals = [round(float(l), 4) for l in losses]
             hist.append((step, vals))
             print(f'step {step:5d}  lr {optimizer.param_groups[0]["lr"]:.5f}  loss c/b/m/s {vals}  ({time.time() - t0:.0f}s)', flush=True)
+    if world > 1 and rank != 0:
+        dist.barrier()
+        return
+    net = module
     anchors = torch.tensor(net.anchors).reshape(-1, 4)
-    res, found = evaluate(net, data, args.size, len(cfg.class_names), anchors)
+    res, found, n_det = evaluate(net, data, args.size, len(cfg.class_names), anchors)
     out = dict(cfg=args.cfg, size=args.size, images=args.images, batch=args.batch, steps=args.steps, seed=args.seed, lr=cfg.lr,
                losses=hist, box_map=[round(v, 2) for v in res['box']], mask_map=[round(v, 2) for v in res['mask']],
-               images_with_detections=found, cpu_s=round(time.time() - t0, 1))
+               images_with_detections=found, detections=n_det[0], detections_above_0p3=n_det[1], cpu_s=round(time.time() - t0, 1), world=world)
     print(json.dumps(out))
     if args.out:
         json.dump(out, open(args.out, 'w'))
+    if world > 1:
+        dist.barrier()
 
 
 if __name__ == '__main__':

@@ -74,3 +74,29 @@ def test_overfit_reproduces_the_reference_dead_mask_branch(golden_dir):
     ref_others = np.median([v[0] + v[1] + v[3] for s, v in ref['losses'] if 50 <= s <= 150])
     assert others < 3 * ref_others + 0.1, (others, ref_others)
     assert ref['mask_map'][0] == 0.0 and got['mask_map'][0] < 5.0, got['mask_map']
+
+
+def test_overfit_two_rank_ddp(golden_dir):
+    """The DDP recipe (train.py:76 + --train_bs 8 on two ranks of 4 pictures each): two real processes (torch.distributed.run; gloo,
+    so that both ranks may share this box's single GPU) train 600 steps with the flat-buffer gradient reducer and the per-step
+    BatchNorm-buffer broadcast, rank 0 scores.  Beside it the REAL reference under torch's DDP on two CPU ranks (gloo), same shards
+    (`python -m torch.distributed.run --nproc-per-node 2 -m oracle.overfit_reference ...`).  Replicas must end bit-identical."""
+    import subprocess
+    from tests.conftest import REPO
+    ref = json.load(open(os.path.join(golden_dir, 'overfit_reference_128_ddp2.json')))
+    assert ref['world'] == 2
+    env = dict(os.environ, YM_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29547', os.path.join(REPO, 'tools', 'overfit_demo.py'), '--size', str(ref['size']), '--steps', str(ref['steps']),
+           '--batch', str(ref['batch']), '--cfg', ref['cfg'], '--seed', str(ref['seed'])]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    got = json.loads([l for l in out.stdout.splitlines() if l.startswith('OVERFIT ')][-1][8:])
+    print(f"overfit[ddp2]: box {got['box_map'][:2]} mask {got['mask_map'][:2]} replicas identical {got['replicas_identical']}  "
+          f"(reference box {ref['box_map'][:2]} mask {ref['mask_map'][:2]})")
+    assert got['world'] == 2 and got['replicas_identical'] is True
+    np.testing.assert_allclose(got['losses'][0][1], ref['losses'][0][1], rtol=1e-3)       # rank 0's shard of step 0
+    assert all(np.isfinite(v).all() for _, v in got['losses']) and sum(got['losses'][-1][1]) < 1.0
+    assert abs(got['box_map'][0] - ref['box_map'][0]) < 15 and abs(got['mask_map'][0] - ref['mask_map'][0]) < 15, (got['box_map'], got['mask_map'])
+    assert got['box_map'][1] >= ref['box_map'][1] - 12 and got['mask_map'][1] >= ref['mask_map'][1] - 12, (got['box_map'], got['mask_map'])
+    assert got['serving_path_identical_pictures'] == ref['images']

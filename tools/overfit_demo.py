@@ -11,6 +11,8 @@ diamond, the four `CUSTOM_CLASSES` slots of `res50_custom`), on a noisy backgrou
 pixels.  Everything is seeded.
 
     python tools/overfit_demo.py --steps 1500            # prints the loss every 100 steps and the final mAP table (JSON last)
+    YM_DIST_BACKEND=gloo python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 tools/overfit_demo.py --size 128 \
+        --steps 600                                      # two ranks of 4 pictures each (sharing one GPU), rank 0 scores
 """
 import argparse
 import json
@@ -74,6 +76,7 @@ def evaluate(net, cfg, data, device, size):
     ap = {k: [[APDataObject() for _ in range(nc)] for _ in thres] for k in ('box', 'mask')}
     net.eval()
     found = 0
+    strong = [0]                      # detections above 0.3 (what a user would draw)
     with torch.no_grad():
         for img, gt, masks in data:
             out = net(img[None].to(device))
@@ -82,10 +85,12 @@ def evaluate(net, cfg, data, device, size):
             if ids is None:
                 continue
             found += 1
+            strong[0] += int((sc > 0.3).sum())
             prep_metrics(ap, list(ids.cpu().numpy().astype(int)), list(sc.cpu().numpy().astype(float)), boxes_p, masks_p,
                          gt.clone().to(device), masks.to(device), size, size, thres)
     table, row_box, row_mask = calc_map(ap, thres, nc, step=0)
     net.train()
+    evaluate.detections_above_0p3 = strong[0]
     return table, row_box, row_mask, found
 
 
@@ -125,14 +130,21 @@ def serving_agrees(net, cfg, data, device, size, depth=4):
 def run(steps=1500, n_images=16, size=256, batch=8, cfg_name='res50_custom', seed=0, lr=None, log=print, eval_every=0, log_every=100):
     from yolact_minimal_amd.config import build_cfg
     from yolact_minimal_amd.modules.yolact import Yolact
-    from yolact_minimal_amd.trainer import Trainer
-    device = torch.device('cuda:0')
-    cfg = build_cfg(cfg_name, 'train', size, train_bs=batch, bs_per_gpu=batch)
+    from yolact_minimal_amd.trainer import Trainer, init_distributed, shard_batch
+    # under torch.distributed.run: `batch` is the GLOBAL batch (train.py --train_bs), every rank trains its contiguous shard of the
+    # same seeded pick, rank 0 scores (YM_DIST_BACKEND=gloo lets the ranks share one GPU; RCCL refuses duplicate devices)
+    rank, world, local_rank = init_distributed()
+    device = torch.device('cuda', local_rank % torch.cuda.device_count())
+    torch.cuda.set_device(device)
+    mine = shard_batch(batch, rank, world)
+    cfg = build_cfg(cfg_name, 'train', size, train_bs=batch, bs_per_gpu=batch // world)
     if lr is not None:
         cfg.lr = lr
     torch.manual_seed(seed)
     net = Yolact(cfg)
-    tr = Trainer(net, cfg, device)
+    tr = Trainer(net, cfg, device, world, local_rank % torch.cuda.device_count())
+    if rank != 0:
+        log = lambda *_: None                                                   # noqa: E731
     data = make_dataset(n_images, size, seed)
     imgs = torch.stack([d[0] for d in data]).to(device)
     gts = [d[1].to(device) for d in data]
@@ -141,7 +153,7 @@ def run(steps=1500, n_images=16, size=256, batch=8, cfg_name='res50_custom', see
     hist, curve = [], []
     t0 = time.time()
     for step in range(steps):
-        pick = order.choice(n_images, batch, replace=False)
+        pick = order.choice(n_images, batch, replace=False)[list(mine)]
         losses = tr.step(imgs[pick], [gts[i] for i in pick], [mks[i] for i in pick])
         if step % log_every == 0 or step == steps - 1:
             vals = [round(float(l.detach()), 4) for l in losses]
@@ -153,15 +165,29 @@ def run(steps=1500, n_images=16, size=256, batch=8, cfg_name='res50_custom', see
             log(f'         box mAP {rb[1]}  mask mAP {rm[1]}')
     torch.cuda.synchronize()
     train_s = time.time() - t0
+    replicas_identical = None
+    if world > 1:
+        import torch.distributed as dist
+        digest = torch.stack([tr.opt.flat.double().sum(), tr.opt.flat.double().abs().sum(), tr.opt.buf.double().abs().sum()])
+        digest = digest if dist.get_backend() == 'nccl' else digest.cpu()
+        gathered = [torch.zeros_like(digest) for _ in range(world)]
+        dist.all_gather(gathered, digest)
+        replicas_identical = all(bool(torch.equal(gathered[0].cpu(), g.cpu())) for g in gathered)
+        if rank != 0:
+            dist.barrier()                       # (rank 0 scores alone, like train.py:162-174)
+            return None
     table, row_box, row_mask, found = evaluate(net, cfg, data, device, size)
+    strong = evaluate.detections_above_0p3
     # the same detector through `--traditional_nms` (greedy per-class NMS, utils/output_utils.py:84-123 + cython_nms.pyx)
     cfg.traditional_nms = True
     _, trad_box, trad_mask, _ = evaluate(net, cfg, data, device, size)
     cfg.traditional_nms = False
     same, n_det = serving_agrees(net, cfg, data, device, size)
+    if world > 1:
+        dist.barrier()
     return dict(cfg=cfg_name, size=size, images=n_images, batch=batch, steps=steps, train_s=round(train_s, 1), losses=hist,
                 box_map=row_box[1:], mask_map=row_mask[1:], images_with_detections=found, curve=curve, table=table,
-                serving_path_identical_pictures=same, detections=n_det,
+                serving_path_identical_pictures=same, detections=n_det, detections_above_0p3=strong, world=world, replicas_identical=replicas_identical,
                 box_map_traditional_nms=trad_box[1:], mask_map_traditional_nms=trad_mask[1:])
 
 
@@ -178,8 +204,9 @@ def main():
     ap.add_argument('--log-every', type=int, default=100)
     a = ap.parse_args()
     r = run(a.steps, a.images, a.size, a.batch, a.cfg, seed=a.seed, lr=a.lr, eval_every=a.eval_every, log_every=a.log_every)
-    print(r.pop('table'))
-    print(json.dumps(r))
+    if r is not None:                            # (rank 0)
+        print(r.pop('table'))
+        print('OVERFIT ' + json.dumps(r) if r['world'] > 1 else json.dumps(r))
 
 
 if __name__ == '__main__':
