@@ -8,10 +8,9 @@ seed 0: 89.4 / 77.5 vs 90.1 / 76.4; seed 1: 90.1 / 78.6 vs 81.3 / 70.9; 256 px b
 the rate drop at 1200): 92.0 / 78.0 vs 92.3 / 76.4; res101_custom (not a test case): 71.1 / 62.6 vs 81.8 / 70.0; swin_tiny_coco (AdamW, DropPath; 76 of its
 80 classes have no ground truth here and score AP 0, so "all" reads 100 x 4 / 80): 4.48 / 3.85 vs 4.51 / 3.87 -- after 600 steps the
 mAP of ONE recipe moves by up to 9 points with the rounding of the implementation (seed 1) -- and within this build with the
-state of the mask-loss sub-sampling generator (`loss.py::mask_generator`: seeded once per process, so the 256 px case, the only
-one with more positives than `masks_to_train`, scores 87.9 / 93.3 in a process of its own and 87.0 / 93.2 after the tests that
-precede it in the suite; BatchNorm statistics are summed with fp64 atomics in no fixed order, a last-bit difference that
-reaches an fp32 mean about once in 30 runs of 600 steps: one suite run put seed 1 outside an earlier 10-point bar) -- so the bar is 15 points
+order of the fp64 atomics that sum the BatchNorm statistics, the one unordered sum of a step: the 128 px cases repeat to the digit
+except for about one run in 30 (one suite run put seed 1 outside an earlier 10-point bar), the 256 px case has two recurring
+outcomes, 87.9 / 93.3 and 87.0 / 93.2 -- so the bar is 15 points
 on "all" and 12 on mAP@50 (one-sided): far from what a broken path scores (the dead mask branch below: mask mAP 0)."""
 import json
 import os
